@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X MWF hot path (driver contract: one JSON line on rank 0).
+
+Workload (BASELINE.json configs[2], "C3"): `--rooms` concurrent rooms per GPU (default 1000), 4 nodes x 4 mics,
+16 kHz, 10 s clips (L = 160000), 512-pt STFT / hop 256, oracle IRM mask, two-step Tango with the z exchange
+kept on the GPU (all nodes of a room live on one device).  One "step" = the whole path over the
+whole batch: oracle mask (2 STFTs/node) -> STFT -> covariance -> GEVD-MWF solve -> z -> exchange -> covariance
+-> solve -> filter -> iSTFT, inputs and outputs resident in HBM.  metric = node-frames/s (1 node-frame = one
+hop of all M mics of one node); x real-time = audio seconds per room / seconds per step.
+
+Multi-GPU: rooms shard across ranks with no data-path collective (weak scaling: `--rooms` per GPU); the only
+communication is the timing barrier / max-reduce the contract asks for.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
+
+
+def b_alg(M, K, F, H):
+    """algorithmic bytes per node-frame of the whole path ('enhanced' outputs)."""
+    if K == 1:
+        return 8 * M * H + 4 * F + 4 * H
+    return 16 * M * H + 8 * F + 16 * (K - 1) * F + 8 * F + 4 * H
+
+
+def kernel_alg_bytes(M, K, F, H):
+    """Compulsory bytes per node-frame of each stage given its C-ABI contract (inputs once + outputs once);
+    DESIGN.md section 'Kernels' derives them."""
+    P2 = M + K - 1
+    return {
+        'mask_oracle': 2 * H * 4 + F * 4,                     # s_ref, n_ref hop samples in, mask out
+        'stft': M * H * 4 + M * F * 8,                        # hop samples of M mics in, M*F bins out
+        'cov1': M * F * 8 + F * 4,                            # X + mask in (covariances: amortised over T)
+        'apply1': M * F * 8 + F * 8,                          # X in, z out
+        'cov2': M * F * 8 + F * 4 + (K - 1) * F * 8,          # X + mask + remote z in
+        'apply2': M * F * 8 + (K - 1) * F * 8 + F * 8,        # X + remote z in, yf out
+        'istft': F * 8 + H * 4,                               # yf in, hop samples out
+    }
+
+
+def cpu_baseline(K, M, L, seconds_hint=25.0):
+    """The reference's CPU path (literal loop nest, oracle/tango_oracle.py:offline_tango_literal -- pinned
+    bit-exact against the reference's own code) on ONE room of the same workload, one host core."""
+    import numpy as np
+    from disco_amd import synth
+    from oracle import tango_oracle as to
+    y, s, n, _ = synth.make_room_numpy(0, K=K, M=M, L=L)
+    t0 = time.perf_counter()
+    to.offline_tango_literal(y, s, n, vads=['irm1', 'irm1'])
+    dt = time.perf_counter() - t0
+    T = 1 + L // 256
+    return {'value': K * T / dt, 'unit': 'node-frames/s', 'cores': 1, 'kind': 'port',
+            'sample': f'1 room ({K} nodes x {M} mics, {L} samples = {K * T} node-frames), literal reference loop nest '
+                      f'(tango.py:326-457 restated, bit-exact vs reference), STFTs included, {dt:.1f} s on 1 of '
+                      f'{os.cpu_count()} host cores',
+            'x_realtime': (L / 16000.0) / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--rooms', type=int, default=1000, help='rooms per GPU')
+    ap.add_argument('--nodes', type=int, default=4)
+    ap.add_argument('--mics', type=int, default=4)
+    ap.add_argument('--length', type=int, default=160000)
+    ap.add_argument('--n-fft', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-stage-timing', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from disco_amd import _lib, synth
+    from disco_amd.engine import Engine
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE {world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    R, K, M, Ls, N = args.rooms, args.nodes, args.mics, args.length, args.n_fft
+    H, F = N // 2, N // 2 + 1
+    lib = _lib.load()
+    eng = Engine(rooms=R, nodes=K, mics=M, length=Ls, n_fft=N, device=local_rank, lib=lib)
+    T = eng.T
+    assert torch.cuda.current_stream().cuda_stream == 0, 'bench times the null stream the library launches on'
+
+    # synthetic rooms, generated on the GPU (SURVEY 8d recipe); rank r owns rooms [r*R, (r+1)*R)
+    y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, Ls, first_room=rank * R, device=dev, ref_only_sn=True)
+    mask = torch.empty((R, K, T, F), dtype=torch.float32, device=dev)
+    out = torch.empty((R, K, Ls), dtype=torch.float32, device=dev)
+    ws = torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
+    G = R * K
+
+    def step():
+        eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), None))
+        eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                         None, None, ws.data_ptr(), ws.numel(), None))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert bool(torch.isfinite(out).all())
+    ms_per_step = 1e3 * dt / args.steps
+    node_frames = world * R * K * T
+    value = node_frames / (dt / args.steps)
+    x_rt = (Ls / 16000.0) / (dt / args.steps)
+
+    # ---- per-stage timing with HIP events on the launch stream (rank 0, N=1), for the roofline object
+    roofline, stages = None, None
+    if rank == 0 and not args.no_stage_timing:
+        X = torch.empty((R, K, T, F, M), dtype=torch.complex64, device=dev)
+        z = torch.empty((R, K, T, F), dtype=torch.complex64, device=dev)
+        yf = torch.empty_like(z)
+        P2 = M + K - 1
+        Rss = torch.empty((R, K, F, P2, P2), dtype=torch.complex64, device=dev)
+        Rnn = torch.empty_like(Rss)
+        w = torch.empty((R, K, F, P2), dtype=torch.complex64, device=dev)
+        p = lambda t: t.data_ptr()
+        calls = [
+            ('mask_oracle', lambda: lib.disco_mask_oracle(eng.ctx, p(s_ref), p(n_ref), G, p(mask), None)),
+            ('stft', lambda: lib.disco_stft(eng.ctx, p(y), G, M, p(X), None)),
+            ('cov1', lambda: lib.disco_cov_masked(eng.ctx, p(X), p(mask), None, None, 0, M, p(Rss), p(Rnn), None)),
+            ('solve1', lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, M, 1.0, p(w), None, None)),
+            ('apply1', lambda: lib.disco_apply(eng.ctx, p(X), None, p(w), M, 1, p(z), None)),
+        ]
+        if K > 1:
+            calls += [
+                ('cov2', lambda: lib.disco_cov_masked(eng.ctx, p(X), p(mask), p(z), p(z), 1, P2, p(Rss), p(Rnn), None)),
+                ('solve2', lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, P2, 1.0, p(w), None, None)),
+                ('apply2', lambda: lib.disco_apply(eng.ctx, p(X), p(z), p(w), P2, 1, p(yf), None)),
+                ('istft', lambda: lib.disco_istft(eng.ctx, p(yf), G, p(out), None)),
+            ]
+        else:
+            calls += [('istft', lambda: lib.disco_istft(eng.ctx, p(z), G, p(out), None))]
+        reps = max(2, min(args.steps, 5))
+        acc = {name: 0.0 for name, _ in calls}
+        for rep in range(reps + 1):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(calls) + 1)]
+            evs[0].record()
+            for i, (name, fn) in enumerate(calls):
+                eng._chk(fn())
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            if rep == 0:
+                continue            # warm-up of the per-stage sequence
+            for i, (name, _) in enumerate(calls):
+                acc[name] += evs[i].elapsed_time(evs[i + 1]) / reps
+        kab = kernel_alg_bytes(M, K, F, H)
+        stages = {}
+        for name, ms in acc.items():
+            ent = {'ms': round(ms, 4)}
+            if name in kab:
+                ent['alg_bytes'] = kab[name] * R * K * T
+                ent['GBps'] = round(ent['alg_bytes'] / (ms * 1e-3) / 1e9, 1)
+            stages[name] = ent
+        dom = max((n_ for n_ in acc if n_ in kab), key=lambda n_: acc[n_])
+        achieved = stages[dom]['alg_bytes'] / (acc[dom] * 1e-3)
+        traffic = None
+        tfile = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved / 1e9, 1), 'peak': HBM_PEAK / 1e9,
+                    'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': traffic,
+                    'alg_bytes_per_launch': stages[dom]['alg_bytes'], 'avg_launch_ms': round(acc[dom], 4),
+                    'pipeline': {'B_alg_per_node_frame': b_alg(M, K, F, H),
+                                 'achieved_GBps': round(value / world * b_alg(M, K, F, H) / 1e9, 1),
+                                 'frac': round(value / world * b_alg(M, K, F, H) / HBM_PEAK, 4)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(K, M, Ls)
+
+    if rank == 0:
+        line = {
+            'metric': 'STFT node-frames/s, whole MWF path (STFT->mask->cov->GEVD-MWF->z exchange->MWF->iSTFT)',
+            'value': value, 'unit': 'node-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'x_realtime': x_rt,
+            'config': {'workload': f'C3: {R} rooms/GPU x {K} nodes x {M} mics, 16 kHz, L={Ls}, {N}-pt STFT hop {H}, '
+                                   f'oracle irm1 mask, two-step Tango (mask_for_z=local), outputs=enhanced',
+                       'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
+                       'parallelism': f'rooms sharded over {world} GPU(s), no data-path collective'},
+            'roofline': roofline, 'cpu_baseline': cpu, 'stages': stages,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

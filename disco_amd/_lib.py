@@ -1,0 +1,74 @@
+"""ctypes binding of libdisco_hip.so (the C ABI of include/disco_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is visible, `load()` / `Engine`
+raise.  (tests/ may bind the same prototypes onto the hipemu *test* build through `bind`; the package
+itself never does.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libdisco_hip.so')
+
+E_ARG, E_UNSUPPORTED, E_HIP_BASE = -1, -2, -1000
+MASK_TYPES = {'irm': 0, 'ibm': 1, 'iam': 2}
+PAD_MODES = {'reflect': 0, 'constant': 1}
+
+
+class DiscoCfg(C.Structure):
+    """struct disco_cfg (include/disco_hip.h); mirrors the constants of tango.py:28-38."""
+    _fields_ = [('rooms', C.c_int32), ('nodes', C.c_int32), ('mics', C.c_int32), ('length', C.c_int32),
+                ('n_fft', C.c_int32), ('hop', C.c_int32), ('ref_mic', C.c_int32), ('mask_type', C.c_int32),
+                ('mask_pow', C.c_int32), ('mask_bin_thr_db', C.c_float), ('mu', C.c_float),
+                ('pad_mode', C.c_int32), ('device', C.c_int32), ('reserved', C.c_int32 * 3)]
+
+
+# name -> (restype, argtypes); every symbol the header declares
+_vp, _i64, _int, _sz, _f = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float
+PROTOTYPES = {
+    'disco_version': (C.c_char_p, []),
+    'disco_create': (_int, [C.POINTER(_vp), C.POINTER(DiscoCfg)]),
+    'disco_destroy': (None, [_vp]),
+    'disco_last_error': (C.c_char_p, [_vp]),
+    'disco_n_frames': (_int, [_vp]),
+    'disco_n_freq': (_int, [_vp]),
+    'disco_workspace_bytes': (_sz, [_vp]),
+    'disco_dev_alloc': (_int, [_vp, _sz, C.POINTER(_vp)]),
+    'disco_dev_free': (_int, [_vp, _vp]),
+    'disco_h2d': (_int, [_vp, _vp, _vp, _sz, _vp]),
+    'disco_d2h': (_int, [_vp, _vp, _vp, _sz, _vp]),
+    'disco_sync': (_int, [_vp, _vp]),
+    'disco_stft': (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    'disco_istft': (_int, [_vp, _vp, _i64, _vp, _vp]),
+    'disco_tf_mask': (_int, [_vp, _vp, _vp, _i64, _int, _int, _f, _vp, _vp]),
+    'disco_mask_oracle': (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    'disco_cov_masked': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    'disco_gevd_mwf_r1': (_int, [_vp, _vp, _vp, _i64, _int, _f, _vp, _vp, _vp]),
+    'disco_apply': (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
+    'disco_noise_residual': (_int, [_vp, _vp, _vp, _vp, _vp]),
+    'disco_tango_enhance': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+def bind(cdll):
+    """Attach the prototypes of include/disco_hip.h to a loaded library; raises AttributeError on a missing symbol."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_lib = None
+
+
+def load():
+    """Load the gfx950 library.  Fails loudly -- there is no other implementation to fall back to."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950).  disco_amd has no CPU path.')
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib

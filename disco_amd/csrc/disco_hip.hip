@@ -1,0 +1,452 @@
+// libdisco_hip.so -- host side of the C ABI declared in include/disco_hip.h (gfx950 only).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/disco_hip.h"
+#include "k_apply.h"
+#include "k_cov.h"
+#include "k_solve.h"
+#include "k_stft.h"
+
+using namespace disco;
+
+struct disco_ctx {
+    disco_cfg cfg;
+    int T, F;
+    float* d_win;
+    c32* d_tw;
+    void* own_ws;
+    size_t own_ws_bytes;
+    void* scratch;            // covariance chunk partials (grown on demand)
+    size_t scratch_bytes;
+    char err[512];
+};
+
+static char g_create_err[512] = "";
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s", #call, hipGetErrorString(e_)); \
+            return DISCO_E_HIP_BASE - (int)e_;                                                  \
+        }                                                                                       \
+    } while (0)
+
+static int fail(disco_ctx* ctx, int code, const char* msg) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+    return code;
+}
+
+static int check_launch(disco_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "launch of %s failed: %s", what, hipGetErrorString(e));
+        return DISCO_E_HIP_BASE - (int)e;
+    }
+    return 0;
+}
+
+extern "C" const char* disco_version(void) { return "disco_hip 0.1.0 (gfx950)"; }
+
+extern "C" const char* disco_last_error(const disco_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
+    if (!out || !cfg) {
+        snprintf(g_create_err, sizeof(g_create_err), "disco_create: null argument");
+        return DISCO_E_ARG;
+    }
+    *out = nullptr;
+    if (cfg->rooms < 1 || cfg->nodes < 1 || cfg->mics < 1 || cfg->length < 1 || cfg->mask_pow < 0 ||
+        cfg->ref_mic < 0 || cfg->ref_mic >= cfg->mics) {
+        snprintf(g_create_err, sizeof(g_create_err), "disco_create: rooms/nodes/mics/length/ref_mic out of range");
+        return DISCO_E_ARG;
+    }
+    if (cfg->n_fft != 512 && cfg->n_fft != 1024) {
+        snprintf(g_create_err, sizeof(g_create_err), "disco_create: n_fft must be 512 or 1024");
+        return DISCO_E_UNSUPPORTED;
+    }
+    if (cfg->hop * 2 != cfg->n_fft) {
+        snprintf(g_create_err, sizeof(g_create_err), "disco_create: hop must equal n_fft/2");
+        return DISCO_E_UNSUPPORTED;
+    }
+    if (cfg->pad_mode == DISCO_PAD_REFLECT && cfg->length <= cfg->n_fft / 2) {
+        snprintf(g_create_err, sizeof(g_create_err), "disco_create: reflect padding needs length > n_fft/2");
+        return DISCO_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev) {
+        snprintf(g_create_err, sizeof(g_create_err), "disco_create: no HIP device %d (found %d)", cfg->device, ndev);
+        return DISCO_E_HIP_BASE;
+    }
+    disco_ctx* ctx = new (std::nothrow) disco_ctx();
+    if (!ctx) return DISCO_E_ARG;
+    ctx->cfg = *cfg;
+    ctx->T = 1 + cfg->length / cfg->hop;
+    ctx->F = cfg->n_fft / 2 + 1;
+    ctx->d_win = nullptr;
+    ctx->d_tw = nullptr;
+    ctx->own_ws = nullptr;
+    ctx->own_ws_bytes = 0;
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    ctx->err[0] = 0;
+    const int N = cfg->n_fft;
+    std::vector<float> win(N);
+    std::vector<c32> tw(N);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int i = 0; i < N; ++i) {
+        win[i] = (float)(0.5 - 0.5 * std::cos(two_pi * i / N));          // scipy get_window('hann', N, fftbins=True)
+        tw[i].x = (float)std::cos(two_pi * i / N);
+        tw[i].y = (float)(-std::sin(two_pi * i / N));
+    }
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_win, N * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tw, N * sizeof(c32));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_win, win.data(), N * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tw, tw.data(), N * sizeof(c32), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        snprintf(g_create_err, sizeof(g_create_err), "disco_create: HIP error %s", hipGetErrorString(e));
+        disco_destroy(ctx);
+        return DISCO_E_HIP_BASE - (int)e;
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void disco_destroy(disco_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->d_win) (void)hipFree(ctx->d_win);
+    if (ctx->d_tw) (void)hipFree(ctx->d_tw);
+    if (ctx->own_ws) (void)hipFree(ctx->own_ws);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    delete ctx;
+}
+
+extern "C" int disco_n_frames(const disco_ctx* ctx) { return ctx ? ctx->T : DISCO_E_ARG; }
+extern "C" int disco_n_freq(const disco_ctx* ctx) { return ctx ? ctx->F : DISCO_E_ARG; }
+
+extern "C" int disco_dev_alloc(disco_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return DISCO_E_ARG;
+    HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return 0;
+}
+extern "C" int disco_dev_free(disco_ctx* ctx, void* dptr) {
+    if (!ctx) return DISCO_E_ARG;
+    HIPCHK(ctx, hipFree(dptr));
+    return 0;
+}
+extern "C" int disco_h2d(disco_ctx* ctx, void* dst, const void* src, size_t bytes, disco_stream s) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return DISCO_E_ARG;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+    return 0;
+}
+extern "C" int disco_d2h(disco_ctx* ctx, void* dst, const void* src, size_t bytes, disco_stream s) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return DISCO_E_ARG;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return 0;
+}
+extern "C" int disco_sync(disco_ctx* ctx, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// STFT family
+// ---------------------------------------------------------------------------------------------------------
+static inline unsigned stft_grid(long long n_items) {
+    const long long per_block = (long long)STFT_WAVES * STFT_ITERS;
+    return (unsigned)((n_items + per_block - 1) / per_block);
+}
+
+extern "C" int disco_stft(disco_ctx* ctx, const float* x, int64_t n_sig, int chans, disco_c32* X, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!x || !X || n_sig < 1 || chans < 1) return fail(ctx, DISCO_E_ARG, "disco_stft: bad argument");
+    const long long n_items = (long long)n_sig * ctx->T * ((chans + 1) / 2);
+    if (stft_grid(n_items) == 0 || n_items / (STFT_WAVES * STFT_ITERS) > 0x7fffffffLL)
+        return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft: batch too large for one launch");
+    const disco_cfg& c = ctx->cfg;
+    if (c.n_fft == 512)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<512>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0, (hipStream_t)s, x,
+                           (c32*)X, ctx->d_win, ctx->d_tw, chans, c.length, ctx->T, c.pad_mode, n_items);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<1024>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0, (hipStream_t)s, x,
+                           (c32*)X, ctx->d_win, ctx->d_tw, chans, c.length, ctx->T, c.pad_mode, n_items);
+    return check_launch(ctx, "k_stft");
+}
+
+extern "C" int disco_mask_oracle(disco_ctx* ctx, const float* s_ref, const float* n_ref, int64_t n_sig, float* mask,
+                                 disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!s_ref || !n_ref || !mask || n_sig < 1) return fail(ctx, DISCO_E_ARG, "disco_mask_oracle: bad argument");
+    const disco_cfg& c = ctx->cfg;
+    if (c.mask_type < DISCO_MASK_IRM || c.mask_type > DISCO_MASK_IAM)
+        return fail(ctx, DISCO_E_ARG, "disco_mask_oracle: unknown mask type");
+    const long long n_items = (long long)n_sig * ctx->T;
+    const float thr = powf(10.f, c.mask_bin_thr_db / 10.f);                 // math_utils.py db2lin (power)
+    if (c.n_fft == 512)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_oracle<512>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0,
+                           (hipStream_t)s, s_ref, n_ref, mask, ctx->d_win, ctx->d_tw, c.length, ctx->T, c.pad_mode,
+                           c.mask_type, c.mask_pow, thr, n_items);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_oracle<1024>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0,
+                           (hipStream_t)s, s_ref, n_ref, mask, ctx->d_win, ctx->d_tw, c.length, ctx->T, c.pad_mode,
+                           c.mask_type, c.mask_pow, thr, n_items);
+    return check_launch(ctx, "k_mask_oracle");
+}
+
+extern "C" int disco_tf_mask(disco_ctx* ctx, const disco_c32* S, const disco_c32* N, int64_t n_elem, int mask_type,
+                             int mask_pow, float bin_thr_db, float* mask, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!S || !N || !mask || n_elem < 1 || mask_pow < 0) return fail(ctx, DISCO_E_ARG, "disco_tf_mask: bad argument");
+    if (mask_type < DISCO_MASK_IRM || mask_type > DISCO_MASK_IAM) return fail(ctx, DISCO_E_ARG, "disco_tf_mask: unknown mask type");
+    const unsigned grid = (unsigned)std::min<long long>((n_elem + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_tf_mask, dim3(grid), dim3(256), 0, (hipStream_t)s, (const c32*)S, (const c32*)N, mask,
+                       (long long)n_elem, mask_type, mask_pow, powf(10.f, bin_thr_db / 10.f));
+    return check_launch(ctx, "k_tf_mask");
+}
+
+extern "C" int disco_istft(disco_ctx* ctx, const disco_c32* Z, int64_t n_sig, float* out, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!Z || !out || n_sig < 1) return fail(ctx, DISCO_E_ARG, "disco_istft: bad argument");
+    const disco_cfg& c = ctx->cfg;
+    const int n_seg = (c.length + c.hop - 1) / c.hop;
+    const int bps = (n_seg + ISTFT_SEGS - 1) / ISTFT_SEGS;
+    const long long grid = (long long)n_sig * bps;
+    if (grid > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_istft: batch too large for one launch");
+    if (c.n_fft == 512)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_istft<512>), dim3((unsigned)grid), dim3(64 * STFT_WAVES), 0, (hipStream_t)s,
+                           (const c32*)Z, out, ctx->d_win, ctx->d_tw, c.length, ctx->T, bps);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_istft<1024>), dim3((unsigned)grid), dim3(64 * STFT_WAVES), 0, (hipStream_t)s,
+                           (const c32*)Z, out, ctx->d_win, ctx->d_tw, c.length, ctx->T, bps);
+    return check_launch(ctx, "k_istft");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// covariance / solve / apply
+// ---------------------------------------------------------------------------------------------------------
+// (M, KR) instantiation table: every split of P = M + KR <= 8 channels.
+#define DISCO_FOR_MKR(X_) \
+    X_(1, 0) X_(1, 1) X_(1, 2) X_(1, 3) X_(1, 4) X_(1, 5) X_(1, 6) X_(1, 7) \
+    X_(2, 0) X_(2, 1) X_(2, 2) X_(2, 3) X_(2, 4) X_(2, 5) X_(2, 6)          \
+    X_(3, 0) X_(3, 1) X_(3, 2) X_(3, 3) X_(3, 4) X_(3, 5)                   \
+    X_(4, 0) X_(4, 1) X_(4, 2) X_(4, 3) X_(4, 4)                            \
+    X_(5, 0) X_(5, 1) X_(5, 2) X_(5, 3)                                     \
+    X_(6, 0) X_(6, 1) X_(6, 2)                                              \
+    X_(7, 0) X_(7, 1)                                                       \
+    X_(8, 0)
+
+static int cov_chunks(const disco_ctx* ctx) {
+    const long long g = (long long)ctx->cfg.rooms * ctx->cfg.nodes;
+    long long c = (2048 + g - 1) / g;
+    if (c > 8) c = 8;
+    if (c > ctx->T) c = ctx->T;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+static int ensure_scratch(disco_ctx* ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return 0;
+    if (ctx->scratch) {
+        HIPCHK(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return 0;
+}
+
+extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs,
+                                const disco_c32* Zn, int mask_remote, int P, disco_c32* Rss, disco_c32* Rnn,
+                                disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, KR = P - M;
+    if (!X || !mask || !Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
+    if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: P must be M or M + K - 1");
+    if (KR > 0 && (!Zs || !Zn)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Zs/Zn required when P > M");
+    if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: P > 8 not supported yet");
+    const int chunks = cov_chunks(ctx);
+    const long long G = (long long)c.rooms * c.nodes;
+    const int NP = P * (P + 1) / 2;
+    const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
+    int rc = ensure_scratch(ctx, need);
+    if (rc) return rc;
+    CovArgs a;
+    a.X = (const c32*)X;
+    a.mask = mask;
+    a.Zs = (const c32*)Zs;
+    a.Zn = (const c32*)Zn;
+    a.part = (float4*)ctx->scratch;
+    a.K = c.nodes;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    a.chunks = chunks;
+    a.mask_remote = mask_remote;
+    const bool same = (Zs == Zn);
+    const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
+    bool launched = false;
+#define X_(M_, KR_)                                                                                                  \
+    if (!launched && M == M_ && KR == KR_) {                                                                         \
+        if (KR_ == 0 || same)                                                                                        \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, true>), grid, block, 0, (hipStream_t)s, a);            \
+        else                                                                                                         \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, false>), grid, block, 0, (hipStream_t)s, a);           \
+        launched = true;                                                                                             \
+    }
+    DISCO_FOR_MKR(X_)
+#undef X_
+    if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: unsupported (M, K) combination");
+    rc = check_launch(ctx, "k_cov");
+    if (rc) return rc;
+    const long long n_gf = G * ctx->F;
+    hipLaunchKernelGGL(k_cov_finalize, dim3((unsigned)std::min<long long>((n_gf + 127) / 128, 65535)), dim3(128), 0,
+                       (hipStream_t)s, (const float4*)ctx->scratch, (c32*)Rss, (c32*)Rnn, n_gf, ctx->F, chunks, P,
+                       1.0f / (float)ctx->T);
+    return check_launch(ctx, "k_cov_finalize");
+}
+
+template <int P>
+static void launch_solve(const c32* Rss, const c32* Rnn, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s) {
+    const int probs = SolveGeom<P>::PROBS;
+    const long long grid = (n_prob + probs - 1) / probs;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1<P>), dim3((unsigned)grid), dim3(SolveGeom<P>::THREADS), 0, s, Rss, Rnn,
+                       n_prob, mu, w, t1);
+}
+
+extern "C" int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const disco_c32* Rnn, int64_t n_prob, int P,
+                                 float mu, disco_c32* w, disco_c32* t1, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!Rss || !Rnn || !w || n_prob < 1) return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1: bad argument");
+    if (P < 1 || P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: P must be in 1..16");
+    if (n_prob / 4 > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: batch too large");
+    const c32* A = (const c32*)Rss;
+    const c32* B = (const c32*)Rnn;
+    hipStream_t st = (hipStream_t)s;
+    switch (P) {
+#define C_(P_) case P_: launch_solve<P_>(A, B, n_prob, (double)mu, (c32*)w, (c32*)t1, st); break;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+#undef C_
+    }
+    return check_launch(ctx, "k_gevd_mwf_r1");
+}
+
+extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, int P, int conj_w,
+                           disco_c32* out, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, KR = P - M;
+    if (!X || !w || !out) return fail(ctx, DISCO_E_ARG, "disco_apply: null argument");
+    if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_apply: P must be M or M + K - 1");
+    if (KR > 0 && !Z) return fail(ctx, DISCO_E_ARG, "disco_apply: Z required when P > M");
+    if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_apply: P > 8 not supported yet");
+    const long long G = (long long)c.rooms * c.nodes;
+    const long long TF = (long long)ctx->T * ctx->F;
+    int bpn = (int)std::min<long long>((TF + 255) / 256, 64);
+    while ((long long)bpn * G > 0x7fffffffLL && bpn > 1) bpn >>= 1;
+    const dim3 grid((unsigned)(G * bpn)), block(256);
+    bool launched = false;
+#define X_(M_, KR_)                                                                                                  \
+    if (!launched && M == M_ && KR == KR_) {                                                                         \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply<M_, KR_>), grid, block, 0, (hipStream_t)s, (const c32*)X,         \
+                           (const c32*)Z, (const c32*)w, (c32*)out, c.nodes, ctx->T, ctx->F, conj_w, bpn);           \
+        launched = true;                                                                                             \
+    }
+    DISCO_FOR_MKR(X_)
+#undef X_
+    if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_apply: unsupported (M, K) combination");
+    return check_launch(ctx, "k_apply");
+}
+
+extern "C" int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const disco_c32* z, disco_c32* zn, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!X || !z || !zn) return fail(ctx, DISCO_E_ARG, "disco_noise_residual: null argument");
+    const disco_cfg& c = ctx->cfg;
+    const long long n = (long long)c.rooms * c.nodes * ctx->T * ctx->F;
+    hipLaunchKernelGGL(k_noise_residual, dim3((unsigned)std::min<long long>((n + 255) / 256, 16384)), dim3(256), 0,
+                       (hipStream_t)s, (const c32*)X, (const c32*)z, (c32*)zn, n, c.mics, c.ref_mic);
+    return check_launch(ctx, "k_noise_residual");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// whole path
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct WsLayout {
+    size_t X, z, yf, Rss, Rnn, w, total;
+};
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+WsLayout ws_layout(const disco_ctx* ctx) {
+    const disco_cfg& c = ctx->cfg;
+    const size_t G = (size_t)c.rooms * c.nodes, TF = (size_t)ctx->T * ctx->F;
+    const size_t Pmax = (size_t)c.mics + c.nodes - 1;
+    WsLayout l;
+    size_t o = 0;
+    l.X = o;   o = align_up(o + G * TF * c.mics * sizeof(c32));
+    l.z = o;   o = align_up(o + G * TF * sizeof(c32));
+    l.yf = o;  o = align_up(o + G * TF * sizeof(c32));
+    l.Rss = o; o = align_up(o + G * ctx->F * Pmax * Pmax * sizeof(c32));
+    l.Rnn = o; o = align_up(o + G * ctx->F * Pmax * Pmax * sizeof(c32));
+    l.w = o;   o = align_up(o + G * ctx->F * Pmax * sizeof(c32));
+    l.total = o;
+    return l;
+}
+}  // namespace
+
+extern "C" size_t disco_workspace_bytes(const disco_ctx* ctx) { return ctx ? ws_layout(ctx).total : 0; }
+
+extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
+                                   disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: null argument");
+    const disco_cfg& c = ctx->cfg;
+    const WsLayout l = ws_layout(ctx);
+    char* ws = (char*)workspace;
+    if (ws) {
+        if (workspace_bytes < l.total) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: workspace too small");
+    } else {
+        if (ctx->own_ws_bytes < l.total) {
+            if (ctx->own_ws) {
+                HIPCHK(ctx, hipFree(ctx->own_ws));
+                ctx->own_ws = nullptr;
+                ctx->own_ws_bytes = 0;
+            }
+            HIPCHK(ctx, hipMalloc(&ctx->own_ws, l.total));
+            ctx->own_ws_bytes = l.total;
+        }
+        ws = (char*)ctx->own_ws;
+    }
+    disco_c32* X = (disco_c32*)(ws + l.X);
+    disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
+    disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
+    disco_c32* Rss = (disco_c32*)(ws + l.Rss);
+    disco_c32* Rnn = (disco_c32*)(ws + l.Rnn);
+    disco_c32* w = (disco_c32*)(ws + l.w);
+    const int64_t G = (int64_t)c.rooms * c.nodes;
+    const int M = c.mics, P2 = c.mics + c.nodes - 1;
+    int rc;
+    // step 1 (tango.py:326-376)
+    if ((rc = disco_stft(ctx, y, G, M, X, s))) return rc;
+    if ((rc = disco_cov_masked(ctx, X, mask_z, nullptr, nullptr, 0, M, Rss, Rnn, s))) return rc;
+    if ((rc = disco_gevd_mwf_r1(ctx, Rss, Rnn, G * ctx->F, M, c.mu, w, nullptr, s))) return rc;
+    if ((rc = disco_apply(ctx, X, nullptr, w, M, 1, z, s))) return rc;
+    if (c.nodes == 1 && mask_w == mask_z) {
+        // single node, same mask: step 2 would rebuild the very same statistics from the very same inputs
+        // (P = M, nothing to append), so w_glo == w_loc and yf == z_y bit for bit (config C2).
+        if (yf) HIPCHK(ctx, hipMemcpyAsync(yf, z, (size_t)G * ctx->T * ctx->F * sizeof(c32), hipMemcpyDeviceToDevice, (hipStream_t)s));
+        return disco_istft(ctx, z, G, out, s);
+    }
+    // exchange + step 2 (tango.py:378-450), mask_for_z = 'local'
+    if ((rc = disco_cov_masked(ctx, X, mask_w, z, z, 1, P2, Rss, Rnn, s))) return rc;
+    if ((rc = disco_gevd_mwf_r1(ctx, Rss, Rnn, G * ctx->F, P2, c.mu, w, nullptr, s))) return rc;
+    if ((rc = disco_apply(ctx, X, z, w, P2, 1, yo, s))) return rc;
+    return disco_istft(ctx, yo, G, out, s);
+}

@@ -1,0 +1,145 @@
+// Masked batch spatial covariance (tango.py:357-364 local, 433-440 global).
+//
+// One thread per frequency bin walks the frames of its (room, node, frame-chunk): consecutive lanes read
+// consecutive bins of the frame-major STFT, i.e. one contiguous 8*M-byte vector per lane and a contiguous
+// 512*M-byte span per wave-load.  The P(P+1)/2 upper-triangle entries of Rss and Rnn live in registers for
+// the whole walk; the Nyquist bin (F = 64 n + 1) gets its own wave with lanes striding over frames and a
+// shuffle reduction.  Chunk partials are summed, scaled by 1/T and mirrored by k_cov_finalize.
+#pragma once
+#include "common.h"
+
+namespace disco {
+
+template <int P>
+__device__ __forceinline__ constexpr int tri_index(int i, int j) { return i * P - (i * (i - 1)) / 2 + (j - i); }
+
+struct CovArgs {
+    const c32* X;        // [R][K][T][F][M]
+    const float* mask;   // [R][K][T][F]
+    const c32* Zs;       // [R][K][T][F] or null
+    const c32* Zn;       // [R][K][T][F] or null
+    float4* part;        // [R*K][chunks][F][NP] of (Rss.re, Rss.im, Rnn.re, Rnn.im) sums
+    int K, T, F, chunks, mask_remote;
+};
+
+template <int M, int KR, bool SAMEZ>
+__device__ __forceinline__ void cov_walk(const CovArgs& a, long long g, int f, int t_begin, int t_end, int t_step,
+                                         c32* acc_s, c32* acc_n) {
+    constexpr int P = M + KR;
+    const int K = a.K, T = a.T, F = a.F;
+    const long long r = g / K;
+    const int k = (int)(g % K);
+    const c32* Xg = a.X + (g * T * (long long)F) * M;
+    const float* mg = a.mask + g * T * (long long)F;
+    for (int t = t_begin; t < t_end; t += t_step) {
+        const long long tf = (long long)t * F + f;
+        const float m = mg[tf];
+        const float mc = 1.f - m;
+        c32 vs[P], vn[P];
+        const c32* xp = Xg + tf * M;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const c32 x = xp[i];
+            vs[i] = make_float2(m * x.x, m * x.y);
+            vn[i] = make_float2(mc * x.x, mc * x.y);
+        }
+        if constexpr (KR > 0) {
+            const float gs = a.mask_remote ? m : 1.f;
+            const float gn = a.mask_remote ? mc : 1.f;
+#pragma unroll
+            for (int jj = 0; jj < KR; ++jj) {
+                const int j = jj < k ? jj : jj + 1;               // concatenate_signals order: z_j (j<k), z_j (j>k)
+                const long long zo = ((r * K + j) * T) * (long long)F + tf;
+                const c32 zs = a.Zs[zo];
+                const c32 zn = SAMEZ ? zs : a.Zn[zo];
+                vs[M + jj] = make_float2(gs * zs.x, gs * zs.y);
+                vn[M + jj] = make_float2(gn * zn.x, gn * zn.y);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+#pragma unroll
+            for (int j = i; j < P; ++j) {
+                const int q = tri_index<P>(i, j);
+                // v_i conj(v_j)
+                acc_s[q].x = fmaf(vs[i].x, vs[j].x, fmaf(vs[i].y, vs[j].y, acc_s[q].x));
+                acc_n[q].x = fmaf(vn[i].x, vn[j].x, fmaf(vn[i].y, vn[j].y, acc_n[q].x));
+                if (j != i) {
+                    acc_s[q].y = fmaf(vs[i].y, vs[j].x, fmaf(-vs[i].x, vs[j].y, acc_s[q].y));
+                    acc_n[q].y = fmaf(vn[i].y, vn[j].x, fmaf(-vn[i].x, vn[j].y, acc_n[q].y));
+                }
+            }
+        }
+    }
+}
+
+// grid = R*K*chunks blocks of (F - 1) + 64 threads: threads [0, F-1) own bins, the last wave owns bin F-1.
+template <int M, int KR, bool SAMEZ>
+__global__ void k_cov(CovArgs a) {
+    constexpr int P = M + KR, NP = P * (P + 1) / 2;
+    const long long g = blockIdx.x / a.chunks;
+    const int c = (int)(blockIdx.x % a.chunks);
+    const int t0 = (int)(((long long)a.T * c) / a.chunks), t1 = (int)(((long long)a.T * (c + 1)) / a.chunks);
+    const int nbin = a.F - 1;
+    const bool nyq = (int)threadIdx.x >= nbin;
+    const int lane = threadIdx.x & 63;
+    c32 acc_s[NP], acc_n[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
+    if (!nyq) {
+        cov_walk<M, KR, SAMEZ>(a, g, threadIdx.x, t0, t1, 1, acc_s, acc_n);
+    } else {
+        cov_walk<M, KR, SAMEZ>(a, g, nbin, t0 + lane, t1, 64, acc_s, acc_n);
+    }
+    if (nyq) {      // whole wave: reduce the 64 per-lane partial sums of the Nyquist bin
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                acc_s[q].x += __shfl_xor(acc_s[q].x, off);
+                acc_s[q].y += __shfl_xor(acc_s[q].y, off);
+                acc_n[q].x += __shfl_xor(acc_n[q].x, off);
+                acc_n[q].y += __shfl_xor(acc_n[q].y, off);
+            }
+        }
+    }
+    if (!nyq || lane == 0) {
+        const int f = nyq ? nbin : (int)threadIdx.x;
+        float4* o = a.part + (((g * a.chunks + c) * a.F) + f) * (long long)NP;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) o[q] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+    }
+}
+
+// part [n_gf/F][chunks][F][NP] -> Rss, Rnn [n_gf][P][P], mean over T, Hermitian mirror.
+__global__ void k_cov_finalize(const float4* __restrict__ part, c32* __restrict__ Rss, c32* __restrict__ Rnn,
+                               long long n_gf, int F, int chunks, int P, float inv_T) {
+    const int NP = P * (P + 1) / 2;
+    for (long long gf = (long long)blockIdx.x * blockDim.x + threadIdx.x; gf < n_gf; gf += (long long)gridDim.x * blockDim.x) {
+        const long long g = gf / F;
+        const int f = (int)(gf % F);
+        int q = 0;
+        for (int i = 0; i < P; ++i)
+            for (int j = i; j < P; ++j, ++q) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = 0; c < chunks; ++c) {
+                    const float4 p = part[(((g * chunks + c) * F) + f) * (long long)NP + q];
+                    s.x += p.x;
+                    s.y += p.y;
+                    s.z += p.z;
+                    s.w += p.w;
+                }
+                if (i == j) s.y = s.w = 0.f;
+                c32* rs = Rss + gf * P * P;
+                c32* rn = Rnn + gf * P * P;
+                rs[i * P + j] = make_float2(s.x * inv_T, s.y * inv_T);
+                rn[i * P + j] = make_float2(s.z * inv_T, s.w * inv_T);
+                if (i != j) {
+                    rs[j * P + i] = make_float2(s.x * inv_T, -s.y * inv_T);
+                    rn[j * P + i] = make_float2(s.z * inv_T, -s.w * inv_T);
+                }
+            }
+    }
+}
+
+}  // namespace disco

@@ -1,0 +1,208 @@
+// Batched rank-1 GEVD-MWF solve -- intern_filter(Rxx, Rnn, mu, type='gevd', rank=1),
+// disco_theque/se_utils/internal_formulas.py:56-73, for Hermitian pencils of size P <= 16.
+//
+// The reference calls LAPACK's non-symmetric complex64 generalized eigensolver and forms
+//     w = Q D (D + mu I)^-1 Q^-1 [:, 0]  (D keeps only the largest, clamped eigenvalue),  t1 = Q[:,0] (Q^-1)[0,0].
+// Both are invariant to the scale/phase of the top eigenvector q0, and for a Hermitian pencil with
+// Rnn = L L^H,  C = L^-1 Rxx L^-H = V diag(d) V^H  one has Q = L^-H V, Q^-1 = V^H L^H, hence
+//     t1 = L^-H v0 * L[0,0] * conj(v0[0]),     w = t1 * d0 / (d0 + mu),   d0 clamped to [eps, 1e6]
+// (oracle/mwf_oracle.py:gevd_mwf_r1_hermitian; checked against the reference's own outputs).
+//
+// Mapping: a group of G = 4 / 8 / 16 lanes owns one problem, lane j owns column j.  Everything is float64:
+// cooperative Cholesky through LDS, two forward substitutions (column j of L^-1 Rxx, then column j of C),
+// then a ONE-SIDED (Hestenes) Jacobi on the columns of C with a round-robin tournament: each round every lane
+// fetches its partner's column with shuffles, both compute the same plane rotation, each updates its own
+// column.  On convergence the columns are d_j v_j; the longest one gives (d0, v0).
+#pragma once
+#include "common.h"
+
+namespace disco {
+
+constexpr double SOLVE_EPS = 2.220446049250313e-16;     // internal_formulas.py:6  sys.float_info.epsilon
+constexpr double SOLVE_ETA = 1e6;                       // internal_formulas.py:7
+
+template <int P>
+struct SolveGeom {
+    static constexpr int G = P <= 4 ? 4 : (P <= 8 ? 8 : 16);
+    static constexpr int THREADS = P <= 8 ? 128 : 64;           // keeps the two LDS matrices under 64 KiB
+    static constexpr int PROBS = THREADS / G;
+};
+
+template <int P>
+__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(const c32* __restrict__ Rss, const c32* __restrict__ Rnn,
+                                                                long long n_prob, double mu,
+                                                                c32* __restrict__ w_out, c32* __restrict__ t1_out) {
+    constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
+    __shared__ c64 s_L[PROBS][P][P + 1];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]
+    __shared__ c64 s_Y[PROBS][P][P + 1];
+    const int j = threadIdx.x % G;             // column owned by this lane
+    const int slot = threadIdx.x / G;
+    const long long pid = (long long)blockIdx.x * PROBS + slot;
+    const bool live = pid < n_prob;
+    const bool col = live && j < P;
+    c64 (*Lm)[P + 1] = s_L[slot];
+    c64 (*Ym)[P + 1] = s_Y[slot];
+    const c32* A = Rss + pid * P * P;
+    const c32* B = Rnn + pid * P * P;
+
+    // ---- stage Rnn (lower triangle) in LDS as float64
+    if (j < P) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            c64 b = make_double2(c == j ? 1.0 : 0.0, 0.0);
+            if (live) {
+                const c32 t = B[j * P + c];
+                b = make_double2((double)t.x, (double)t.y);
+            }
+            Lm[j][c] = b;
+        }
+    }
+    __syncthreads();
+
+    // ---- Cholesky, one column per step; every lane keeps the (real) diagonal in registers
+    double dd[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        double d2 = Lm[c][c].x;
+#pragma unroll
+        for (int k = 0; k < c; ++k) d2 -= Lm[c][k].x * Lm[c][k].x + Lm[c][k].y * Lm[c][k].y;
+        const double d = sqrt(fmax(d2, 1e-300));
+        dd[c] = d;
+        if (j > c && j < P) {
+            c64 s = Lm[j][c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lm[j][k], Lm[c][k]));
+            Lm[j][c] = zscale(s, 1.0 / d);
+        }
+        __syncthreads();
+    }
+
+    // ---- column j of Y = L^-1 Rxx   (Rxx[i][j] = conj(Rxx[j][i]): read row j, contiguous)
+    c64 y[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        c64 a = make_double2(0.0, 0.0);
+        if (col) {
+            const c32 t = A[j * P + i];
+            a = make_double2((double)t.x, -(double)t.y);
+        }
+#pragma unroll
+        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[i][k], y[k]));
+        y[i] = zscale(a, 1.0 / dd[i]);
+    }
+    if (j < P) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) Ym[i][j] = y[i];
+    }
+    __syncthreads();
+
+    // ---- column j of C = L^-1 Y^H  (C Hermitian): rhs = conj(row j of Y)
+    c64 g[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        c64 a = make_double2(0.0, 0.0);
+        if (j < P) a = make_double2(Ym[j][i].x, -Ym[j][i].y);
+#pragma unroll
+        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[i][k], g[k]));
+        g[i] = zscale(a, 1.0 / dd[i]);
+    }
+
+    // ---- one-sided Jacobi, round-robin over G players (lanes >= P carry zero columns)
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        int rotated = 0;
+        for (int rd = 0; rd < G - 1; ++rd) {
+            int pj;
+            if (j == G - 1) pj = rd;
+            else if (j == rd) pj = G - 1;
+            else {
+                pj = 2 * rd - j;
+                pj = pj < 0 ? pj + (G - 1) : (pj >= G - 1 ? pj - (G - 1) : pj);
+            }
+            c64 o[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                o[i].x = __shfl(g[i].x, pj, G);
+                o[i].y = __shfl(g[i].y, pj, G);
+            }
+            const bool lo = j < pj;                       // own column plays "p" (first), partner's plays "q"
+            double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const c64 gp = lo ? g[i] : o[i], gq = lo ? o[i] : g[i];
+                alpha += gp.x * gp.x + gp.y * gp.y;
+                beta += gq.x * gq.x + gq.y * gq.y;
+                gr += gp.x * gq.x + gp.y * gq.y;          // gamma = gp^H gq
+                gi += gp.x * gq.y - gp.y * gq.x;
+            }
+            const double g2 = gr * gr + gi * gi;
+            if (g2 > 1e-28 * alpha * beta && g2 > 0.0) {
+                rotated = 1;
+                const double ag = sqrt(g2);
+                const double zeta = (beta - alpha) / (2.0 * ag);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                const c64 ph = make_double2(gr / ag, gi / ag);        // e^{i phi}
+                // gp' = cs gp - sn e^{-i phi} gq ;  gq' = sn e^{i phi} gp + cs gq
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    if (lo) {
+                        const c64 r = zmulc(o[i], ph);                // e^{-i phi} gq
+                        g[i] = make_double2(cs * g[i].x - sn * r.x, cs * g[i].y - sn * r.y);
+                    } else {
+                        const c64 r = zmul(o[i], ph);                 // e^{i phi} gp
+                        g[i] = make_double2(sn * r.x + cs * g[i].x, sn * r.y + cs * g[i].y);
+                    }
+                }
+            }
+        }
+        if (!__any(rotated)) break;
+    }
+
+    // ---- longest column = d0 v0 ; arg-max over the group (ties: lowest lane)
+    double nrm = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) nrm += g[i].x * g[i].x + g[i].y * g[i].y;
+    double best = nrm;
+    int bj = j;
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off, G);
+        const int oj = __shfl_xor(bj, off, G);
+        if (ob > best || (ob == best && oj < bj)) {
+            best = ob;
+            bj = oj;
+        }
+    }
+    c64 v0[P];
+    const double d0 = sqrt(best);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        v0[i].x = __shfl(g[i].x, bj, G);
+        v0[i].y = __shfl(g[i].y, bj, G);
+        if (d0 > 0.0) v0[i] = zscale(v0[i], 1.0 / d0);
+        else v0[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
+    }
+
+    // ---- q = L^-H v0 (back substitution), then scale
+    c64 q[P];
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) {
+        c64 a = v0[i];
+#pragma unroll
+        for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Lm[k][i].x, -Lm[k][i].y), q[k]));
+        q[i] = zscale(a, 1.0 / dd[i]);
+    }
+    const double dcl = fmin(fmax(d0, SOLVE_EPS), SOLVE_ETA);
+    const c64 gsc = make_double2(dd[0] * v0[0].x, -dd[0] * v0[0].y);     // L[0,0] conj(v0[0]) = (Q^-1)[0,0]
+    const double gain = dcl / (dcl + mu);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (col && i == j) {
+            const c64 t1 = zmul(q[i], gsc);
+            if (t1_out) t1_out[pid * P + i] = make_float2((float)t1.x, (float)t1.y);
+            w_out[pid * P + i] = make_float2((float)(t1.x * gain), (float)(t1.y * gain));
+        }
+    }
+}
+
+}  // namespace disco

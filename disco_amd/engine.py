@@ -1,0 +1,225 @@
+"""Python driver of the HIP engine: one `Engine` = one `disco_ctx` (one device, one batch geometry).
+
+Arrays may be given as numpy arrays (copied host->device through the library's own hipMemcpy), as `DevBuf`
+(device resident, returned by every method), or as torch ROCm tensors (zero-copy through `data_ptr()`).
+All compute happens in libdisco_hip.so; this file only marshals pointers.  No CPU fallback exists.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DiscoError(RuntimeError):
+    pass
+
+
+class DevBuf:
+    """A device allocation owned by an Engine, with shape/dtype metadata."""
+
+    def __init__(self, eng, shape, dtype):
+        self.eng = eng
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        eng._chk(eng.lib.disco_dev_alloc(eng.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        self.eng._chk(self.eng.lib.disco_d2h(self.eng.ctx, out.ctypes.data, self.ptr, self.nbytes, None))
+        self.eng.sync()
+        return out
+
+    def reshape(self, *shape):
+        v = object.__new__(DevBuf)
+        v.eng, v.dtype, v.nbytes, v.ptr = self.eng, self.dtype, self.nbytes, self.ptr
+        v.shape = tuple(shape)
+        v._base = self
+        assert int(np.prod(v.shape, dtype=np.int64)) * v.dtype.itemsize == self.nbytes
+        return v
+
+    def free(self):
+        if getattr(self, 'ptr', None) and not hasattr(self, '_base'):
+            self.eng.lib.disco_dev_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.eng.ctx:
+                self.free()
+        except Exception:
+            pass
+
+
+def parse_mask_type(mask):
+    """'irm1' -> (DISCO_MASK_IRM, 1); raises ValueError like tango.py:223 / dnn/utils.py:69."""
+    if not isinstance(mask, str) or len(mask) != 4 or mask[:3] not in L.MASK_TYPES or not mask[3].isdigit():
+        raise ValueError('Unknown mask type. Should be "irmX", "ibmX" or "iamX"')
+    return L.MASK_TYPES[mask[:3]], int(mask[3])
+
+
+class Engine:
+    def __init__(self, rooms, nodes, mics, length, n_fft=512, hop=None, ref_mic=0, mask='irm1', bin_thr=0.0,
+                 mu=1.0, pad_mode='reflect', device=0, lib=None):
+        self.lib = lib if lib is not None else L.load()
+        mt, mp = parse_mask_type(mask)
+        hop = n_fft // 2 if hop is None else hop
+        self.cfg = L.DiscoCfg(rooms=rooms, nodes=nodes, mics=mics, length=length, n_fft=n_fft, hop=hop,
+                              ref_mic=ref_mic, mask_type=mt, mask_pow=mp, mask_bin_thr_db=bin_thr, mu=mu,
+                              pad_mode=L.PAD_MODES[pad_mode], device=device)
+        ctx = C.c_void_p()
+        rc = self.lib.disco_create(C.byref(ctx), C.byref(self.cfg))
+        self.ctx = ctx.value if rc == 0 else None
+        if rc != 0:
+            raise DiscoError(f'disco_create failed ({rc}): {self.lib.disco_last_error(None).decode()}')
+        self.R, self.K, self.M, self.Lsamp = rooms, nodes, mics, length
+        self.T = self.lib.disco_n_frames(self.ctx)
+        self.F = self.lib.disco_n_freq(self.ctx)
+        self.stream = None
+
+    # ---- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise DiscoError(f'libdisco_hip error {rc}: {self.lib.disco_last_error(self.ctx).decode()}')
+
+    def close(self):
+        if self.ctx:
+            self.lib.disco_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.lib.disco_sync(self.ctx, self.stream))
+
+    def to_device(self, a, dtype):
+        """-> (device pointer, keep-alive object)."""
+        if a is None:
+            return None, None
+        if isinstance(a, DevBuf):
+            assert a.dtype == np.dtype(dtype), (a.dtype, dtype)
+            return a.ptr, a
+        if hasattr(a, 'data_ptr'):                       # torch tensor on the GPU
+            assert a.is_contiguous()
+            return a.data_ptr(), a
+        a = np.ascontiguousarray(a, dtype=dtype)
+        b = DevBuf(self, a.shape, dtype)
+        self._chk(self.lib.disco_h2d(self.ctx, b.ptr, a.ctypes.data, b.nbytes, self.stream))
+        self.sync()
+        return b.ptr, b
+
+    def empty(self, shape, dtype):
+        return DevBuf(self, shape, dtype)
+
+    # ---- stage kernels (names follow include/disco_hip.h)
+    def stft(self, x):
+        """x (n_sig, chans, L) float32 -> X (n_sig, T, F, chans) complex64   [lb.core.stft, tango.py:335]"""
+        n_sig, chans, Ls = x.shape
+        assert Ls == self.Lsamp
+        px, kx = self.to_device(x, np.float32)
+        X = self.empty((n_sig, self.T, self.F, chans), np.complex64)
+        self._chk(self.lib.disco_stft(self.ctx, px, n_sig, chans, X.ptr, self.stream))
+        return X
+
+    def istft(self, Z):
+        """Z (n_sig, T, F) complex64 -> (n_sig, L) float32   [lb.core.istft, tango.py:528]"""
+        n_sig = Z.shape[0]
+        assert tuple(Z.shape[1:]) == (self.T, self.F)
+        pz, kz = self.to_device(Z, np.complex64)
+        out = self.empty((n_sig, self.Lsamp), np.float32)
+        self._chk(self.lib.disco_istft(self.ctx, pz, n_sig, out.ptr, self.stream))
+        return out
+
+    def tf_mask(self, S, N, type='irm1', bin_thr=0.0):
+        mt, mp = parse_mask_type(type)
+        assert tuple(S.shape) == tuple(N.shape)
+        ps, ks = self.to_device(S, np.complex64)
+        pn, kn = self.to_device(N, np.complex64)
+        m = self.empty(S.shape, np.float32)
+        self._chk(self.lib.disco_tf_mask(self.ctx, ps, pn, int(np.prod(S.shape)), mt, mp, bin_thr, m.ptr, self.stream))
+        return m
+
+    def mask_oracle(self, s_ref, n_ref):
+        """s_ref, n_ref (n_sig, L) -> mask (n_sig, T, F)   [get_mask at the reference mic, tango.py:338-342]"""
+        n_sig = s_ref.shape[0]
+        ps, ks = self.to_device(s_ref, np.float32)
+        pn, kn = self.to_device(n_ref, np.float32)
+        m = self.empty((n_sig, self.T, self.F), np.float32)
+        self._chk(self.lib.disco_mask_oracle(self.ctx, ps, pn, n_sig, m.ptr, self.stream))
+        return m
+
+    def cov_masked(self, X, mask, Zs=None, Zn=None, mask_remote=True):
+        """X (R,K,T,F,M), mask (R,K,T,F)[, Zs, Zn (R,K,T,F)] -> Rss, Rnn (R,K,F,P,P)   [tango.py:357-364, 433-440]"""
+        P = self.M + (self.K - 1 if Zs is not None else 0)
+        px, kx = self.to_device(X, np.complex64)
+        pm, km = self.to_device(mask, np.float32)
+        pzs, kzs = self.to_device(Zs, np.complex64)
+        if Zn is Zs:
+            pzn, kzn = pzs, kzs
+        else:
+            pzn, kzn = self.to_device(Zn, np.complex64)
+        Rss = self.empty((self.R, self.K, self.F, P, P), np.complex64)
+        Rnn = self.empty((self.R, self.K, self.F, P, P), np.complex64)
+        self._chk(self.lib.disco_cov_masked(self.ctx, px, pm, pzs, pzn, int(bool(mask_remote)), P, Rss.ptr, Rnn.ptr,
+                                            self.stream))
+        return Rss, Rnn
+
+    def gevd_mwf_r1(self, Rss, Rnn, mu=None, want_t1=True):
+        """Rss, Rnn (..., P, P) -> w, t1 (..., P)   [intern_filter(..., 'gevd', rank=1), internal_formulas.py:56-73]"""
+        shape = tuple(Rss.shape)
+        P = shape[-1]
+        n_prob = int(np.prod(shape[:-2], dtype=np.int64))
+        pa, ka = self.to_device(Rss, np.complex64)
+        pb, kb = self.to_device(Rnn, np.complex64)
+        w = self.empty(shape[:-1], np.complex64)
+        t1 = self.empty(shape[:-1], np.complex64) if want_t1 else None
+        self._chk(self.lib.disco_gevd_mwf_r1(self.ctx, pa, pb, n_prob, P, self.cfg.mu if mu is None else mu, w.ptr,
+                                             t1.ptr if want_t1 else None, self.stream))
+        return w, t1
+
+    def apply(self, X, w, Z=None, conj=True):
+        """out = w^H [X ; Z_-k] (conj=True) or w^T [...]   [tango.py:369-374, 445-450]"""
+        P = self.M + (self.K - 1 if Z is not None else 0)
+        px, kx = self.to_device(X, np.complex64)
+        pz, kz = self.to_device(Z, np.complex64)
+        pw, kw = self.to_device(w, np.complex64)
+        out = self.empty((self.R, self.K, self.T, self.F), np.complex64)
+        self._chk(self.lib.disco_apply(self.ctx, px, pz, pw, P, int(bool(conj)), out.ptr, self.stream))
+        return out
+
+    def noise_residual(self, X, z):
+        px, kx = self.to_device(X, np.complex64)
+        pz, kz = self.to_device(z, np.complex64)
+        zn = self.empty((self.R, self.K, self.T, self.F), np.complex64)
+        self._chk(self.lib.disco_noise_residual(self.ctx, px, pz, zn.ptr, self.stream))
+        return zn
+
+    # ---- whole path
+    def workspace_bytes(self):
+        return int(self.lib.disco_workspace_bytes(self.ctx))
+
+    def tango_enhance(self, y, mask_z, mask_w=None, want_z=True, want_yf=True, out=None, workspace=None):
+        """y (R,K,M,L), masks (R,K,T,F) -> out (R,K,L) [, z_y, yf (R,K,T,F)]: offline_tango's y branch + iSTFT."""
+        py, ky = self.to_device(y, np.float32)
+        pmz, kmz = self.to_device(mask_z, np.float32)
+        if mask_w is None or mask_w is mask_z:
+            pmw, kmw = pmz, kmz
+        else:
+            pmw, kmw = self.to_device(mask_w, np.float32)
+        if out is None:
+            out = self.empty((self.R, self.K, self.Lsamp), np.float32)
+        po, ko = self.to_device(out, np.float32)
+        z = self.empty((self.R, self.K, self.T, self.F), np.complex64) if want_z else None
+        yf = self.empty((self.R, self.K, self.T, self.F), np.complex64) if want_yf else None
+        pws, kws = (None, None) if workspace is None else self.to_device(workspace, np.uint8)
+        wsb = 0 if workspace is None else (workspace.nbytes if hasattr(workspace, 'nbytes') else workspace.numel())
+        self._chk(self.lib.disco_tango_enhance(self.ctx, py, pmz, pmw, po, z.ptr if z else None, yf.ptr if yf else None,
+                                               pws, wsb, self.stream))
+        return out, z, yf

@@ -1,0 +1,156 @@
+/*
+ * disco_hip.h -- C ABI of libdisco_hip.so: the MI355X (gfx950) implementation of DISCO's
+ * distributed multichannel-Wiener-filter speech-enhancement hot path.
+ *
+ * The reference (nfurnon/disco) is pure Python and has no FFI seam; its boundary for this path is the
+ * Python call surface listed below.  Every entry point of this header replaces one of those functions
+ * (or one loop nest inside `offline_tango`); the Python shim in disco_amd/ keeps the reference's names
+ * and argument meaning on top of it.  The ctypes binding a reference maintainer would add is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - All array arguments are DEVICE pointers owned by the caller (except where "host" is stated).
+ *   - complex64 is interleaved (re, im) float pairs  == numpy complex64 == disco_c32.
+ *   - Every compute call is asynchronous on the given hipStream_t (pass NULL for the default stream);
+ *     no hidden synchronisation.  A disco_ctx is bound to one device and is not thread-safe.
+ *   - Return value: 0 on success, DISCO_E_ARG (-1) bad argument, DISCO_E_UNSUPPORTED (-2) unsupported
+ *     shape, -1000 - hipError_t for a HIP failure.  Never throws, never aborts.
+ *     disco_last_error(ctx) returns a static/ctx-owned message for the last failing call.
+ *
+ * Layouts (frame-major; R rooms, K nodes/room, M mics/node, L samples, T = 1 + L/hop frames,
+ * F = n_fft/2 + 1 bins, P = channels seen by a filter: M in step 1, M + K - 1 in step 2):
+ *   time signals   float    [R][K][M][L]            (the reference's [node][channel] -> time, tango.py:259-261)
+ *   STFT           disco_c32[R][K][T][F][M]         (mic innermost: one coalesced 8*M-byte vector per (t,f))
+ *   masks          float    [R][K][T][F]
+ *   z / filtered   disco_c32[R][K][T][F]
+ *   covariances    disco_c32[R][K][F][P][P]         (row-major Hermitian, what intern_filter(Rxx, Rnn) takes per bin)
+ *   filters w, t1  disco_c32[R][K][F][P]
+ *   The Python-visible (F, T) arrays of the reference are transposes of the [T][F] planes.
+ */
+#ifndef DISCO_HIP_H
+#define DISCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISCO_E_ARG          (-1)
+#define DISCO_E_UNSUPPORTED  (-2)
+#define DISCO_E_HIP_BASE     (-1000)
+
+#define DISCO_MASK_IRM 0
+#define DISCO_MASK_IBM 1
+#define DISCO_MASK_IAM 2
+
+#define DISCO_PAD_REFLECT  0   /* librosa < 0.10 (the reference's era)  */
+#define DISCO_PAD_CONSTANT 1   /* librosa >= 0.10                        */
+
+typedef struct disco_c32 { float re, im; } disco_c32;
+typedef struct disco_ctx disco_ctx;
+typedef void* disco_stream;                 /* a hipStream_t */
+
+/* Mirrors the module constants of tango.py:28-38 (N_FFT, N_HOP, nb_ch, ref_mics, SNR/mask choices)
+ * plus the batch size.  All int/float, no pointers: safe to fill from any FFI. */
+typedef struct disco_cfg {
+    int32_t rooms;          /* R  independent rooms in the batch                                  */
+    int32_t nodes;          /* K  nodes per room            (len(nb_ch), tango.py:31)              */
+    int32_t mics;           /* M  microphones per node      (nb_ch[k], uniform)                    */
+    int32_t length;         /* L  samples per channel                                               */
+    int32_t n_fft;          /* N_FFT, 512 or 1024           (tango.py:28)                           */
+    int32_t hop;            /* N_HOP, must be n_fft/2       (tango.py:29)                           */
+    int32_t ref_mic;        /* ref_mics[k]                  (tango.py:32)                           */
+    int32_t mask_type;      /* DISCO_MASK_*  ('irmX'/'ibmX'/'iamX', dnn/utils.py:57-67)             */
+    int32_t mask_pow;       /* X of 'irmX'                                                          */
+    float   mask_bin_thr_db;/* bin_thr of tf_mask                                                   */
+    float   mu;             /* speech-distortion constant of intern_filter (1 at every call site)   */
+    int32_t pad_mode;       /* DISCO_PAD_*                                                          */
+    int32_t device;         /* HIP device ordinal                                                   */
+    int32_t reserved[3];
+} disco_cfg;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+const char* disco_version(void);
+int  disco_create(disco_ctx** out, const disco_cfg* cfg);
+void disco_destroy(disco_ctx* ctx);
+const char* disco_last_error(const disco_ctx* ctx);      /* ctx may be NULL: last create() error       */
+int  disco_n_frames(const disco_ctx* ctx);               /* T = 1 + L/hop   (librosa center=True)      */
+int  disco_n_freq(const disco_ctx* ctx);                 /* F = n_fft/2 + 1                            */
+/* Bytes of device workspace disco_tango_enhance needs for this cfg (STFT + z + yf + covariances). */
+size_t disco_workspace_bytes(const disco_ctx* ctx);
+
+/* ---- plain device-memory helpers (so a numpy-only host can drive the library without torch) -------- */
+int  disco_dev_alloc(disco_ctx* ctx, size_t bytes, void** dptr);
+int  disco_dev_free(disco_ctx* ctx, void* dptr);
+int  disco_h2d(disco_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, disco_stream s);
+int  disco_d2h(disco_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, disco_stream s);
+int  disco_sync(disco_ctx* ctx, disco_stream s);         /* hipStreamSynchronize                        */
+
+/* ---- stage kernels --------------------------------------------------------------------------------- */
+
+/* librosa.core.stft(x, n_fft, hop, center=True)  -- tango.py:335-337, math_utils.py:134-140 (my_stft).
+ * x: float [n_sig][chans][L]  ->  X: disco_c32 [n_sig][T][F][chans].  n_sig = R*K and chans = M on the hot path. */
+int disco_stft(disco_ctx* ctx, const float* x, int64_t n_sig, int chans, disco_c32* X, disco_stream s);
+
+/* librosa.core.istft(Z, hop, win_length=n_fft, center=True, length=L) -- tango.py:528-539, math_utils.py:143-152.
+ * Z: disco_c32 [n_sig][T][F]  ->  out: float [n_sig][L]. */
+int disco_istft(disco_ctx* ctx, const disco_c32* Z, int64_t n_sig, float* out, disco_stream s);
+
+/* tf_mask(s, n, type, bin_thr) on STFT planes -- dnn/utils.py:44-71.  Elementwise over n_elem bins. */
+int disco_tf_mask(disco_ctx* ctx, const disco_c32* S, const disco_c32* N, int64_t n_elem,
+                  int mask_type, int mask_pow, float bin_thr_db, float* mask, disco_stream s);
+
+/* Oracle mask straight from time signals (get_mask -> tf_mask at the reference mic, tango.py:338-342):
+ * s_ref, n_ref: float [n_sig][L] (target / noise image at the reference mic) -> mask float [n_sig][T][F].
+ * Fuses the two STFTs (one complex FFT for the pair) with the mask; uses cfg.mask_type / mask_pow. */
+int disco_mask_oracle(disco_ctx* ctx, const float* s_ref, const float* n_ref, int64_t n_sig,
+                      float* mask, disco_stream s);
+
+/* Masked batch spatial covariance -- the loop nests tango.py:357-364 (step 1, P = M, Zs = Zn = NULL)
+ * and tango.py:433-440 (step 2, P = M + K - 1).
+ *   v_s(t,f) = [ m*X_k ; g_s*Zs_j (j<k) ; g_s*Zs_j (j>k) ],   Rss[f] = mean_t v_s v_s^H
+ *   v_n(t,f) = [(1-m)*X_k ; g_n*Zn_j ...               ],   Rnn[f] = mean_t v_n v_n^H
+ * with g_s = m, g_n = 1-m when mask_remote != 0 (mask_for_z='local', tango.py:416-418) and 1 otherwise.
+ * X [R][K][T][F][M], mask [R][K][T][F], Zs/Zn [R][K][T][F] (row order = concatenate_signals, tango.py:142-155).
+ * Rss, Rnn: disco_c32 [R][K][F][P][P]. */
+int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask,
+                     const disco_c32* Zs, const disco_c32* Zn, int mask_remote, int P,
+                     disco_c32* Rss, disco_c32* Rnn, disco_stream s);
+
+/* intern_filter(Rxx, Rnn, mu, type='gevd', rank=1) -- internal_formulas.py:56-73, batched:
+ * top generalized eigenpair of each Hermitian pencil (float64 Cholesky whitening + one-sided Jacobi),
+ * eigenvalue clamped to [eps, 1e6], w = q d/(d+mu) (Q^-1)[0,0], t1 = q (Q^-1)[0,0].
+ * Rss, Rnn: [n_prob][P][P]  ->  w, t1: [n_prob][P]  (t1 may be NULL).  1 <= P <= 16. */
+int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const disco_c32* Rnn, int64_t n_prob, int P,
+                      float mu, disco_c32* w, disco_c32* t1, disco_stream s);
+
+/* Filter-and-sum -- the np.inner loops tango.py:369-374 / 445-450:
+ *   out[t,f] = sum_p c(w[f,p]) * v[p,t,f],  v = [X_k ; Z_j (j<k) ; Z_j (j>k)],  c = conj if conj_w else identity.
+ * X [R][K][T][F][M]; Z [R][K][T][F] or NULL when P == M; w [R][K][F][P]; out [R][K][T][F]. */
+int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, int P,
+                int conj_w, disco_c32* out, disco_stream s);
+
+/* zn = Y[ref_mic] - z_y -- tango.py:376.  X [R][K][T][F][M], z/zn [R][K][T][F]. */
+int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const disco_c32* z, disco_c32* zn, disco_stream s);
+
+/* ---- whole path -------------------------------------------------------------------------------------- */
+
+/* offline_tango(y, ..., mask_for_z='local') restricted to the y branch ("enhanced" outputs), device resident:
+ *   y       float [R][K][M][L]       mixture
+ *   mask_z  float [R][K][T][F]       step-1 mask (oracle via disco_mask_oracle, or a DNN's output)
+ *   mask_w  float [R][K][T][F]       step-2 mask (may alias mask_z)
+ *   out     float [R][K][L]          iSTFT of the step-2 output yf            (tango.py:528)
+ *   z_y     disco_c32 [R][K][T][F]   compressed signals, or NULL to keep them in the workspace
+ *   yf      disco_c32 [R][K][T][F]   step-2 STFT-domain output, or NULL
+ * workspace: device buffer of at least disco_workspace_bytes(ctx), or NULL to let the context allocate
+ * (once, lazily) and keep it. */
+int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w,
+                        float* out, disco_c32* z_y, disco_c32* yf,
+                        void* workspace, size_t workspace_bytes, disco_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCO_HIP_H */

@@ -1,0 +1,175 @@
+// hipemu -- a tiny CPU *emulator* of the HIP execution model, for TESTS ONLY.
+//
+// Purpose: run the kernel sources of disco_amd/csrc/ unmodified on a machine without a GPU, so that
+// `pytest -m "not gpu"` can check kernel LOGIC (indexing, FFT passes, reductions, the Jacobi solver)
+// against the oracle at toy sizes.  It is NOT a product path and NOT a fallback: the shipped library
+// (disco_amd/lib/libdisco_hip.so) is built by hipcc for gfx950 only and the Python package refuses to run
+// without it.  Only tests/emu_build.py compiles against this header, into tests/_emu/.
+//
+// Model: one OS thread per GPU thread of a block; blocks run one after another; __syncthreads() is a
+// pthread barrier; a wave is 64 consecutive threads; shuffles go through a per-wave slot array;
+// `__shared__` becomes `static` (valid because blocks are serialised).  gcc, -pthread.
+#pragma once
+#include <pthread.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define HIPEMU 1
+
+struct uint3 { unsigned x, y, z; };
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+struct int2 { int x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+
+namespace hipemu {
+struct WaveState {
+    pthread_barrier_t bar;
+    uint64_t slot[64];
+    int n;
+};
+struct BlockState {
+    pthread_barrier_t bar;
+    std::vector<WaveState> waves;
+};
+inline thread_local uint3 t_threadIdx, t_blockIdx;
+inline thread_local dim3 t_blockDim, t_gridDim;
+inline thread_local BlockState* t_block = nullptr;
+inline thread_local WaveState* t_wave = nullptr;
+inline thread_local int t_lane = 0;
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
+    const unsigned nthreads = block.x * block.y * block.z;
+    BlockState bs;
+    pthread_barrier_init(&bs.bar, nullptr, nthreads);
+    const unsigned nwaves = (nthreads + 63) / 64;
+    bs.waves.resize(nwaves);
+    for (unsigned w = 0; w < nwaves; ++w) {
+        bs.waves[w].n = (int)std::min(64u, nthreads - 64 * w);
+        pthread_barrier_init(&bs.waves[w].bar, nullptr, bs.waves[w].n);
+    }
+    auto body = [&](unsigned tid) {
+        t_block = &bs;
+        t_wave = &bs.waves[tid / 64];
+        t_lane = (int)(tid % 64);
+        t_blockDim = block;
+        t_gridDim = grid;
+        t_threadIdx.x = tid % block.x;
+        t_threadIdx.y = (tid / block.x) % block.y;
+        t_threadIdx.z = tid / (block.x * block.y);
+        for (unsigned bz = 0; bz < grid.z; ++bz)
+            for (unsigned by = 0; by < grid.y; ++by)
+                for (unsigned bx = 0; bx < grid.x; ++bx) {
+                    t_blockIdx = uint3{bx, by, bz};
+                    fn();
+                    pthread_barrier_wait(&bs.bar);      // block boundary: `static` LDS is reused by the next block
+                }
+    };
+    std::vector<std::thread> th;
+    th.reserve(nthreads);
+    for (unsigned t = 0; t < nthreads; ++t) th.emplace_back(body, t);
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&bs.bar);
+    for (auto& w : bs.waves) pthread_barrier_destroy(&w.bar);
+}
+
+template <class T>
+inline T shfl_abs(T v, int src_abs) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    uint64_t bits = 0;
+    std::memcpy(&bits, &v, sizeof(T));
+    t_wave->slot[t_lane] = bits;
+    pthread_barrier_wait(&t_wave->bar);
+    uint64_t r = t_wave->slot[(src_abs >= 0 && src_abs < t_wave->n) ? src_abs : t_lane];
+    pthread_barrier_wait(&t_wave->bar);
+    T out;
+    std::memcpy(&out, &r, sizeof(T));
+    return out;
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::t_threadIdx)
+#define blockIdx (hipemu::t_blockIdx)
+#define blockDim (hipemu::t_blockDim)
+#define gridDim (hipemu::t_gridDim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { pthread_barrier_wait(&hipemu::t_block->bar); }
+
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+    int base = hipemu::t_lane & ~(width - 1);
+    return hipemu::shfl_abs(v, base + (src & (width - 1)));
+}
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int base = hipemu::t_lane & ~(width - 1);
+    return hipemu::shfl_abs(v, base + ((hipemu::t_lane ^ mask) & (width - 1)));
+}
+template <class T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int base = hipemu::t_lane & ~(width - 1);
+    int idx = (hipemu::t_lane & (width - 1)) + (int)delta;
+    return hipemu::shfl_abs(v, idx < width ? base + idx : hipemu::t_lane);
+}
+static inline unsigned long long __ballot(int pred) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        int p = hipemu::shfl_abs(pred, l);
+        if (l < hipemu::t_wave->n && p) m |= (1ull << l);
+    }
+    return m;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0ull; }
+static inline int __all(int pred) {
+    unsigned long long full = hipemu::t_wave->n == 64 ? ~0ull : ((1ull << hipemu::t_wave->n) - 1);
+    return (__ballot(pred) & full) == full;
+}
+
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+
+// ---- host runtime: "device" memory is host memory ----------------------------------------------------
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }

@@ -1,0 +1,212 @@
+"""Stage-by-stage and end-to-end comparisons of the HIP path (through the C ABI) with the CPU oracle.
+
+Shared by tests/test_gpu_parity.py (real MI355X, `-m gpu`) and tests/test_kernels_emulated.py (the same
+kernel sources under the hipemu CPU emulator, toy sizes, `-m "not gpu"`).  `make_engine(**cfg)` builds a
+disco_amd.engine.Engine bound to the library under test.
+"""
+import numpy as np
+
+from oracle import mwf_oracle as mo
+from oracle import stft_oracle as so
+from oracle import tango_oracle as to
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def maxrel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def check_stft(make_engine, n_sig=2, chans=3, L=3000, n_fft=512, pad_mode='reflect', seed=0, tol=2e-6):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n_sig, chans, L)).astype(np.float32)
+    eng = make_engine(rooms=n_sig, nodes=1, mics=chans, length=L, n_fft=n_fft, pad_mode=pad_mode)
+    X = eng.stft(x).numpy()                                              # (n_sig, T, F, chans)
+    ref = so.stft(x, n_fft, n_fft // 2, pad_mode, np.complex128)         # (n_sig, chans, F, T)
+    ref = np.transpose(ref, (0, 3, 2, 1))
+    assert X.shape == ref.shape
+    e = maxrel(X, ref)
+    assert e < tol, e
+    return e
+
+
+def check_istft(make_engine, n_sig=3, L=3000, n_fft=512, seed=1, tol=3e-6):
+    rng = np.random.default_rng(seed)
+    T, F = 1 + L // (n_fft // 2), n_fft // 2 + 1
+    Z = (rng.standard_normal((n_sig, T, F)) + 1j * rng.standard_normal((n_sig, T, F))).astype(np.complex64)
+    eng = make_engine(rooms=n_sig, nodes=1, mics=1, length=L, n_fft=n_fft)
+    y = eng.istft(Z).numpy()
+    ref = so.istft(np.transpose(Z, (0, 2, 1)), L, n_fft, n_fft // 2, work_dtype=np.float64)
+    e = maxrel(y, ref)
+    assert e < tol, e
+    # round trip on a real signal
+    x = rng.standard_normal((n_sig, 1, L)).astype(np.float32)
+    xr = eng.istft(eng.stft(x).reshape(n_sig, T, F)).numpy()
+    e2 = float(np.abs(xr - x[:, 0]).max())
+    assert e2 < 2e-5, e2
+    return e
+
+
+def check_masks(make_engine, L=3000, n_fft=512, seed=2):
+    rng = np.random.default_rng(seed)
+    n_sig = 2
+    s = rng.standard_normal((n_sig, L)).astype(np.float32)
+    n = rng.standard_normal((n_sig, L)).astype(np.float32)
+    s[:, :400] = 0
+    worst = 0.0
+    for mask in ('irm1', 'irm2', 'iam1', 'ibm1'):
+        eng = make_engine(rooms=n_sig, nodes=1, mics=1, length=L, n_fft=n_fft, mask=mask)
+        m = eng.mask_oracle(s, n).numpy()                                # (n_sig, T, F)
+        S = so.stft(s, n_fft, n_fft // 2, 'reflect', np.complex128)
+        Nn = so.stft(n, n_fft, n_fft // 2, 'reflect', np.complex128)
+        with np.errstate(all='ignore'):
+            ref = np.transpose(mo.tf_mask(S, Nn, type=mask), (0, 2, 1)).astype(np.float64)
+        if mask.startswith('ibm'):
+            assert np.mean(m != ref) < 1e-3                              # threshold flips at rounding level only
+        else:
+            ok = np.isfinite(ref)
+            err = np.abs(m[ok] - ref[ok]) / (1.0 + np.abs(ref[ok]))
+            # the mask is a ratio of STFT magnitudes: where a denominator (|N|, or |S+N| for 'iam') nearly cancels
+            # against the frame norm, fp32 STFT rounding is amplified -- bound the bulk tightly, the tail loosely
+            e = float(np.percentile(err, 99.9))
+            worst = max(worst, e)
+            assert e < 2e-5 and float(err.max()) < 5e-3, (mask, e, float(err.max()))
+        # elementwise entry point on given STFT planes
+        S32, N32 = S.astype(np.complex64), Nn.astype(np.complex64)
+        m2 = eng.tf_mask(S32, N32, type=mask).numpy()
+        with np.errstate(all='ignore'):
+            ref2 = mo.tf_mask(S32, N32, type=mask)
+        if mask.startswith('ibm'):
+            assert np.mean(m2 != ref2) < 1e-3
+        else:
+            ok = np.isfinite(ref2)
+            assert float((np.abs(m2[ok] - ref2[ok]) / (1.0 + np.abs(ref2[ok]))).max()) < 1e-5
+    return worst
+
+
+def _rand_stft_scene(rng, R, K, M, T, F):
+    """Spatially structured random STFTs (rank-1 target + full-rank noise per bin) and a mask in (0,1)."""
+    a = rng.standard_normal((R, K, 1, F, M)) + 1j * rng.standard_normal((R, K, 1, F, M))
+    src = rng.standard_normal((R, 1, T, F, 1)) + 1j * rng.standard_normal((R, 1, T, F, 1))
+    noise = rng.standard_normal((R, K, T, F, M)) + 1j * rng.standard_normal((R, K, T, F, M))
+    X = (a * src + 0.7 * noise).astype(np.complex64)
+    mask = rng.uniform(0.05, 0.95, (R, K, T, F)).astype(np.float32)
+    return X, mask
+
+
+def oracle_cov(X, mask, Zs=None, Zn=None, mask_remote=True):
+    """float64 restatement of tango.py:357-364 / 433-440 in the engine's layout."""
+    R, K, T, F, M = X.shape
+    X = X.astype(np.complex128)
+    m = mask.astype(np.float64)[..., None]
+    P = M + (K - 1 if Zs is not None else 0)
+    Rss = np.zeros((R, K, F, P, P), np.complex128)
+    Rnn = np.zeros_like(Rss)
+    for k in range(K):
+        vs = [m[:, k] * X[:, k]]
+        vn = [(1 - m[:, k]) * X[:, k]]
+        if Zs is not None:
+            others = [j for j in range(K) if j != k]
+            gs = m[:, k] if mask_remote else 1.0
+            gn = (1 - m[:, k]) if mask_remote else 1.0
+            vs.append(gs * np.stack([Zs[:, j].astype(np.complex128) for j in others], axis=-1))
+            vn.append(gn * np.stack([Zn[:, j].astype(np.complex128) for j in others], axis=-1))
+        vs = np.concatenate(vs, axis=-1)
+        vn = np.concatenate(vn, axis=-1)
+        Rss[:, k] = np.einsum('rtfp,rtfq->rfpq', vs, vs.conj()) / T
+        Rnn[:, k] = np.einsum('rtfp,rtfq->rfpq', vn, vn.conj()) / T
+    return Rss, Rnn
+
+
+def check_cov_solve_apply(make_engine, R=2, K=2, M=2, L=2560, n_fft=512, seed=3, same_z=True, mask_remote=True):
+    rng = np.random.default_rng(seed)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    T, F = eng.T, eng.F
+    X, mask = _rand_stft_scene(rng, R, K, M, T, F)
+    errs = {}
+    # step-1 shape (P = M)
+    Rss, Rnn = eng.cov_masked(X, mask)
+    rs, rn = oracle_cov(X, mask)
+    errs['cov1'] = max(relerr(Rss.numpy(), rs), relerr(Rnn.numpy(), rn))
+    assert errs['cov1'] < 5e-6, errs
+    w, t1 = eng.gevd_mwf_r1(Rss, Rnn)
+    w_ref, t1_ref, _ = mo.gevd_mwf_r1_hermitian(Rss.numpy(), Rnn.numpy(), 1.0)
+    errs['solve1'] = max(relerr(w.numpy(), w_ref), relerr(t1.numpy(), t1_ref))
+    assert errs['solve1'] < 5e-6, errs
+    z = eng.apply(X, w)
+    z_ref = np.einsum('rkfm,rktfm->rktf', w.numpy().conj().astype(np.complex128), X.astype(np.complex128))
+    errs['apply1'] = relerr(z.numpy(), z_ref)
+    assert errs['apply1'] < 5e-6, errs
+    zt = eng.apply(X, t1, conj=False).numpy()
+    errs['apply1_t'] = relerr(zt, np.einsum('rkfm,rktfm->rktf', t1.numpy().astype(np.complex128), X.astype(np.complex128)))
+    assert errs['apply1_t'] < 5e-6, errs
+    zn = eng.noise_residual(X, z).numpy()
+    assert relerr(zn, X[..., 0] - z.numpy()) < 1e-6
+    if K > 1:
+        zs = z.numpy()
+        zn_arr = zs if same_z else (zs * 0.5 + 0.1 * X[..., 0]).astype(np.complex64)
+        Rss2, Rnn2 = eng.cov_masked(X, mask, zs, zs if same_z else zn_arr, mask_remote=mask_remote)
+        rs2, rn2 = oracle_cov(X, mask, zs, zn_arr, mask_remote)
+        errs['cov2'] = max(relerr(Rss2.numpy(), rs2), relerr(Rnn2.numpy(), rn2))
+        assert errs['cov2'] < 5e-6, errs
+        w2, t12 = eng.gevd_mwf_r1(Rss2, Rnn2)
+        w2_ref, _, _ = mo.gevd_mwf_r1_hermitian(Rss2.numpy(), Rnn2.numpy(), 1.0)
+        errs['solve2'] = relerr(w2.numpy(), w2_ref)
+        assert errs['solve2'] < 5e-6, errs
+        yf = eng.apply(X, w2, Z=zs).numpy()
+        ext = []
+        for k in range(K):
+            others = [j for j in range(K) if j != k]
+            ext.append(np.concatenate([X[:, k].astype(np.complex128)] + [zs[:, j, :, :, None].astype(np.complex128) for j in others], axis=-1))
+        ext = np.stack(ext, axis=1)                                       # (R,K,T,F,P)
+        yf_ref = np.einsum('rkfp,rktfp->rktf', w2.numpy().conj().astype(np.complex128), ext)
+        errs['apply2'] = relerr(yf, yf_ref)
+        assert errs['apply2'] < 5e-6, errs
+    return errs
+
+
+def check_solver_vs_reference_golden(make_engine, golden_dir):
+    """HIP solver against intern_filter outputs of the REFERENCE'S OWN CODE (tests/golden/intern_filter_ref.npz)."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'intern_filter_ref.npz'))
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    worst = 0.0
+    for i in range(int(g['n_cases'])):
+        if str(g[f'c{i}_type']) != 'gevd':
+            continue
+        Rxx, Rnn = g[f'c{i}_Rxx'], g[f'c{i}_Rnn']
+        w, t1 = eng.gevd_mwf_r1(Rxx[None].astype(np.complex64), Rnn[None].astype(np.complex64))
+        # complex64 inputs: the reference itself solved in complex64 LAPACK -> 1e-4 class agreement;
+        # complex128 inputs are rounded to complex64 at the ABI, same class.
+        e = max(relerr(w.numpy()[0], g[f'c{i}_w']), relerr(t1.numpy()[0], g[f'c{i}_t1']))
+        worst = max(worst, e)
+        assert e < 2e-4, (i, e)
+    return worst
+
+
+def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-4, ref_tuple=None):
+    """Whole path through the C ABI vs the float64 oracle.  y, s, n: (R, K, M, L) float32.
+    Returns the per-output worst relative errors."""
+    R, K, M, L = y.shape
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask)
+    T, F = eng.T, eng.F
+    m_dev = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F)
+    out, z, yf = eng.tango_enhance(y, m_dev)
+    out, z, yf, m_gpu = out.numpy(), z.numpy(), yf.numpy(), m_dev.numpy()
+    errs = {'mask': 0.0, 'z_y': 0.0, 'yf': 0.0, 'out': 0.0}
+    for r in range(R):
+        o = to.offline_tango_vec(y[r], s[r], n[r], vads=[mask, mask], n_fft=n_fft, hop=n_fft // 2,
+                                 precision='f64', solver='eigh')
+        for k in range(K):
+            errs['mask'] = max(errs['mask'], float(np.abs(m_gpu[r, k].T - o['masks_z'][k]).max()))
+            errs['z_y'] = max(errs['z_y'], relerr(z[r, k].T, o['z_y'][k]))
+            errs['yf'] = max(errs['yf'], relerr(yf[r, k].T, o['yf'][k]))
+            t_ref = so.istft(o['yf'][k], L, n_fft, n_fft // 2, work_dtype=np.float64)
+            errs['out'] = max(errs['out'], relerr(out[r, k], t_ref))
+    assert errs['mask'] < 1e-4, errs
+    assert errs['z_y'] < tol and errs['yf'] < tol and errs['out'] < tol, errs
+    return errs

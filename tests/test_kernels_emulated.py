@@ -1,0 +1,49 @@
+"""Kernel LOGIC under the hipemu CPU emulator (no GPU): the unmodified sources of disco_amd/csrc are compiled by
+g++ against tests/hipemu and driven through the same C ABI / Engine as on the MI355X, at toy sizes, and
+compared with the oracle.  This is test tooling, not a product path (disco_amd itself has no CPU path); the
+real parity tests are tests/test_gpu_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+
+import emu_build
+import parity_checks as pc
+from disco_amd import synth
+from disco_amd.engine import Engine
+
+
+@pytest.fixture(scope='module')
+def make_engine():
+    lib = emu_build.load_emu()
+
+    def mk(**cfg):
+        return Engine(lib=lib, **cfg)
+    return mk
+
+
+@pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 2048, 2), (1024, 2600, 1)])
+@pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
+def test_emu_stft(make_engine, n_fft, L, chans, pad_mode):
+    print(pc.check_stft(make_engine, n_sig=2, chans=chans, L=L, n_fft=n_fft, pad_mode=pad_mode))
+
+
+@pytest.mark.parametrize('n_fft,L', [(512, 2048), (512, 2100), (1024, 4500)])
+def test_emu_istft(make_engine, n_fft, L):
+    print(pc.check_istft(make_engine, n_sig=2, L=L, n_fft=n_fft))
+
+
+def test_emu_masks(make_engine):
+    print(pc.check_masks(make_engine, L=1800))
+
+
+@pytest.mark.parametrize('K,M,same_z,mask_remote', [(2, 2, True, True), (3, 2, False, False), (1, 4, True, True), (4, 4, True, True)])
+def test_emu_cov_solve_apply(make_engine, K, M, same_z, mask_remote):
+    print(pc.check_cov_solve_apply(make_engine, R=1, K=K, M=M, L=2304, same_z=same_z, mask_remote=mask_remote))
+
+
+def test_emu_solver_vs_reference_golden(make_engine, golden_dir):
+    print(pc.check_solver_vs_reference_golden(make_engine, golden_dir))
+
+
+def test_emu_tango_end_to_end(make_engine):
+    y, s, n = synth.make_rooms_numpy(1, K=2, M=2, L=8192)
+    print(pc.check_tango_end_to_end(make_engine, y, s, n))
