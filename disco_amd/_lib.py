@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdisco_hip.so')
+LIB_PATH = os.environ.get('DISCO_HIP_LIB', os.path.join(_HERE, 'lib', 'libdisco_hip.so'))   # override: A/B of kernel builds
 
 E_ARG, E_UNSUPPORTED, E_HIP_BASE = -1, -2, -1000
 MASK_TYPES = {'irm': 0, 'ibm': 1, 'iam': 2}

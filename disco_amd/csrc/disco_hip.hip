@@ -160,24 +160,39 @@ extern "C" int disco_sync(disco_ctx* ctx, disco_stream s) {
 // ---------------------------------------------------------------------------------------------------------
 // STFT family
 // ---------------------------------------------------------------------------------------------------------
-static inline unsigned stft_grid(long long n_items) {
-    const long long per_block = (long long)STFT_WAVES * STFT_ITERS;
-    return (unsigned)((n_items + per_block - 1) / per_block);
+static inline int stft_runs(int T) { return (T + STFT_RUN - 1) / STFT_RUN; }
+static inline long long stft_blocks(long long n_witems) { return (n_witems + STFT_WAVES - 1) / STFT_WAVES; }
+
+template <int N>
+static bool launch_stft(int chp, dim3 grid, hipStream_t st, const float* x, c32* X, const float* win, const c32* tw, int chans,
+                        int L, int T, int pad_mode, int runs, long long n_items) {
+    const dim3 block(64 * STFT_WAVES);
+    switch (chp) {
+#define C_(P_)                                                                                                          \
+    case P_:                                                                                                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<N, P_>), grid, block, 0, st, x, X, win, tw, chans, L, T, pad_mode, runs, n_items); \
+        return true;
+        C_(1) C_(2) C_(3) C_(4)
+#undef C_
+    }
+    return false;
 }
 
 extern "C" int disco_stft(disco_ctx* ctx, const float* x, int64_t n_sig, int chans, disco_c32* X, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
     if (!x || !X || n_sig < 1 || chans < 1) return fail(ctx, DISCO_E_ARG, "disco_stft: bad argument");
-    const long long n_items = (long long)n_sig * ctx->T * ((chans + 1) / 2);
-    if (stft_grid(n_items) == 0 || n_items / (STFT_WAVES * STFT_ITERS) > 0x7fffffffLL)
+    if (chans > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft: more than 8 channels per signal group");
+    const int runs = stft_runs(ctx->T);
+    const long long n_items = (long long)n_sig * runs;
+    if (stft_blocks(n_items) > 0x7fffffffLL)
         return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft: batch too large for one launch");
     const disco_cfg& c = ctx->cfg;
-    if (c.n_fft == 512)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<512>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0, (hipStream_t)s, x,
-                           (c32*)X, ctx->d_win, ctx->d_tw, chans, c.length, ctx->T, c.pad_mode, n_items);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<1024>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0, (hipStream_t)s, x,
-                           (c32*)X, ctx->d_win, ctx->d_tw, chans, c.length, ctx->T, c.pad_mode, n_items);
+    const dim3 grid((unsigned)stft_blocks(n_items));
+    const int chp = (chans + 1) / 2;
+    const bool ok = c.n_fft == 512
+        ? launch_stft<512>(chp, grid, (hipStream_t)s, x, (c32*)X, ctx->d_win, ctx->d_tw, chans, c.length, ctx->T, c.pad_mode, runs, n_items)
+        : launch_stft<1024>(chp, grid, (hipStream_t)s, x, (c32*)X, ctx->d_win, ctx->d_tw, chans, c.length, ctx->T, c.pad_mode, runs, n_items);
+    if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft: unsupported channel count");
     return check_launch(ctx, "k_stft");
 }
 
@@ -188,16 +203,20 @@ extern "C" int disco_mask_oracle(disco_ctx* ctx, const float* s_ref, const float
     const disco_cfg& c = ctx->cfg;
     if (c.mask_type < DISCO_MASK_IRM || c.mask_type > DISCO_MASK_IAM)
         return fail(ctx, DISCO_E_ARG, "disco_mask_oracle: unknown mask type");
-    const long long n_items = (long long)n_sig * ctx->T;
+    const int runs = stft_runs(ctx->T);
+    const long long n_items = (long long)n_sig * runs;
+    if (stft_blocks(n_items) > 0x7fffffffLL)
+        return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mask_oracle: batch too large for one launch");
     const float thr = powf(10.f, c.mask_bin_thr_db / 10.f);                 // math_utils.py db2lin (power)
+    const dim3 grid((unsigned)stft_blocks(n_items));
     if (c.n_fft == 512)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_oracle<512>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_oracle<512>), grid, dim3(64 * STFT_WAVES), 0,
                            (hipStream_t)s, s_ref, n_ref, mask, ctx->d_win, ctx->d_tw, c.length, ctx->T, c.pad_mode,
-                           c.mask_type, c.mask_pow, thr, n_items);
+                           c.mask_type, c.mask_pow, thr, runs, n_items);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_oracle<1024>), dim3(stft_grid(n_items)), dim3(64 * STFT_WAVES), 0,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_oracle<1024>), grid, dim3(64 * STFT_WAVES), 0,
                            (hipStream_t)s, s_ref, n_ref, mask, ctx->d_win, ctx->d_tw, c.length, ctx->T, c.pad_mode,
-                           c.mask_type, c.mask_pow, thr, n_items);
+                           c.mask_type, c.mask_pow, thr, runs, n_items);
     return check_launch(ctx, "k_mask_oracle");
 }
 
@@ -296,10 +315,17 @@ extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float*
     bool launched = false;
 #define X_(M_, KR_)                                                                                                  \
     if (!launched && M == M_ && KR == KR_) {                                                                         \
-        if (KR_ == 0 || same)                                                                                        \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, true>), grid, block, 0, (hipStream_t)s, a);            \
-        else                                                                                                         \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, false>), grid, block, 0, (hipStream_t)s, a);           \
+        if (c.n_fft == 512) {                                                                                        \
+            if (KR_ == 0 || same)                                                                                    \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, true, 320>), grid, block, 0, (hipStream_t)s, a);   \
+            else                                                                                                     \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, false, 320>), grid, block, 0, (hipStream_t)s, a);  \
+        } else {                                                                                                     \
+            if (KR_ == 0 || same)                                                                                    \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, true, 576>), grid, block, 0, (hipStream_t)s, a);   \
+            else                                                                                                     \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, false, 576>), grid, block, 0, (hipStream_t)s, a);  \
+        }                                                                                                            \
         launched = true;                                                                                             \
     }
     DISCO_FOR_MKR(X_)

@@ -12,10 +12,17 @@
 
 namespace disco {
 
-// LDS exchange fences.  All lanes of a block execute the same pass sequence (idle waves transform zeros),
-// so a block barrier is always legal; the buffers are wave-private.
-#define DISCO_LDS_RAW() __syncthreads()
-#define DISCO_LDS_WAR() __syncthreads()
+// LDS exchange fences.  The exchange buffers are WAVE-PRIVATE, so no s_barrier is needed: a wave's DS
+// instructions execute in issue order, and all that has to be prevented is (a) the compiler moving a read
+// above the writes it depends on through another lane, (b) a read issuing before this wave's own writes have
+// been accepted.  RAW = `s_waitcnt lgkmcnt(0)` (0xC07F: vmcnt/expcnt untouched, so global prefetches stay in
+// flight) + a scheduling barrier; WAR = scheduling barrier only.
+#define DISCO_LDS_RAW()                       \
+    do {                                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   \
+        __builtin_amdgcn_wave_barrier();      \
+    } while (0)
+#define DISCO_LDS_WAR() __builtin_amdgcn_wave_barrier()
 
 template <int N>
 struct FftPlan;
@@ -92,11 +99,38 @@ __device__ __forceinline__ void dftR(c32* u) {
     else dft16(u);
 }
 
+// Per-lane twiddle factors of passes 2 and 3, gathered once per kernel from the N-entry table
+// tw[j] = exp(-2 pi i j / N): they depend on the lane only, so they live in registers for every transform
+// the wave performs (saves 14 LDS reads per 512-point transform and the LDS table itself).
+template <int N>
+struct WaveTw {
+    using Pl = FftPlan<N>;
+    static constexpr int E = Pl::E;
+    static constexpr int Q1 = E / Pl::R1, Q2 = E / Pl::R2;
+    c32 t1[Q1 * (Pl::R1 - 1)];
+    c32 t2[Q2 * (Pl::R2 - 1)];
+    __device__ __forceinline__ void init(const c32* __restrict__ tw, int lane) {
+        constexpr int P1 = Pl::R0, P2 = Pl::R0 * Pl::R1;
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) {
+            const int k = (lane + 64 * q) & (P1 - 1);
+#pragma unroll
+            for (int r = 1; r < Pl::R1; ++r) t1[q * (Pl::R1 - 1) + r - 1] = tw[k * r * (N / (P1 * Pl::R1))];
+        }
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) {
+            const int k = (lane + 64 * q) & (P2 - 1);
+#pragma unroll
+            for (int r = 1; r < Pl::R2; ++r) t2[q * (Pl::R2 - 1) + r - 1] = tw[k * r * (N / (P2 * Pl::R2))];
+        }
+    }
+};
+
 // One Stockham pass of radix R with P_ = product of the previous radices.
 //   butterfly i in [0, N/R): k = i mod P_; u[r] = x[i + r N/R] * W_{P_ R}^{k r}; U = DFT_R(u); y[(i-k) R + k + r P_] = U[r]
 // A lane owns the E/R butterflies i = lane + 64 q; v[q R + r] carries u[r] / U[r].
 template <int N, int R, int P_, bool FIRST, bool LAST>
-__device__ __forceinline__ void fft_pass(c32* v, const c32* __restrict__ tw, c32* buf, int lane) {
+__device__ __forceinline__ void fft_pass(c32* v, const c32* tw, c32* buf, int lane) {
     constexpr int E = FftPlan<N>::E, S = N / R, Q = E / R;
     if constexpr (!FIRST) {
         DISCO_LDS_RAW();
@@ -110,10 +144,9 @@ __device__ __forceinline__ void fft_pass(c32* v, const c32* __restrict__ tw, c32
     for (int q = 0; q < Q; ++q) {
         const int i = lane + 64 * q;
         const int k = i & (P_ - 1);
-        if constexpr (P_ > 1) {
-            constexpr int TWS = N / (P_ * R);      // table stride: W_{P_ R}^{k r} = tw[k r N/(P_ R)]
+        if constexpr (P_ > 1) {                    // tw = this pass' register twiddles W_{P_ R}^{k r}, r = 1..R-1
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[k * r * TWS]);
+            for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[q * (R - 1) + r - 1]);
         }
         dftR<R>(v + q * R);
         if constexpr (!LAST) {
@@ -135,18 +168,18 @@ __device__ __forceinline__ void fft_pass(c32* v, const c32* __restrict__ tw, c32
 }
 
 // Forward complex FFT of the wave's N points.  In: v[e] = x[lane + 64 e].  Out: v[e] = X[lane + 64 e].
-// `tw` = exp(-2 pi i j / N), j < N (LDS or global); `buf` = wave-private LDS of fft_buf_len<N>() c32.
+// `buf` = wave-private LDS of fft_buf_len<N>() c32.
 template <int N>
-__device__ __forceinline__ void fft_wave(c32* v, const c32* __restrict__ tw, c32* buf, int lane) {
+__device__ __forceinline__ void fft_wave(c32* v, const WaveTw<N>& tw, c32* buf, int lane) {
     using Pl = FftPlan<N>;
     DISCO_LDS_WAR();        // the previous user of `buf` (an earlier item's untangle reads) is done in every lane
-    fft_pass<N, Pl::R0, 1, true, false>(v, tw, buf, lane);
-    fft_pass<N, Pl::R1, Pl::R0, false, false>(v, tw, buf, lane);
-    fft_pass<N, Pl::R2, Pl::R0 * Pl::R1, false, true>(v, tw, buf, lane);
+    fft_pass<N, Pl::R0, 1, true, false>(v, nullptr, buf, lane);
+    fft_pass<N, Pl::R1, Pl::R0, false, false>(v, tw.t1, buf, lane);
+    fft_pass<N, Pl::R2, Pl::R0 * Pl::R1, false, true>(v, tw.t2, buf, lane);
 }
 
 // Spectra of two real sequences a, b from Z = FFT(a + i b):  A[f] = (Z[f] + conj Z[N-f]) / 2,
-// B[f] = (Z[f] - conj Z[N-f]) / (2i).  Lane receives f = lane + 64 j (j < E/2) through emit(f, A, B);
+// B[f] = (Z[f] - conj Z[N-f]) / (2i).  Lane receives f = lane + 64 j (j < E/2) through emit(j, f, A, B);
 // lane 0 additionally receives the Nyquist bin f = N/2.
 template <int N, class Emit>
 __device__ __forceinline__ void rfft_pair_untangle(c32* v, c32* buf, int lane, Emit emit) {
@@ -163,7 +196,7 @@ __device__ __forceinline__ void rfft_pair_untangle(c32* v, c32* buf, int lane, E
             const c32 zc = buf[fft_pad<N>((N - f) & (N - 1))];
             const c32 A = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
             const c32 B = make_float2(0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x));
-            emit(f, A, B);
+            emit(j, f, A, B);
         }
     }
 }

@@ -73,9 +73,11 @@ __device__ __forceinline__ void cov_walk(const CovArgs& a, long long g, int f, i
     }
 }
 
-// grid = R*K*chunks blocks of (F - 1) + 64 threads: threads [0, F-1) own bins, the last wave owns bin F-1.
-template <int M, int KR, bool SAMEZ>
-__global__ void k_cov(CovArgs a) {
+// grid = R*K*chunks blocks of NT = (F - 1) + 64 threads: threads [0, F-1) own bins, the last wave owns bin F-1.
+// __launch_bounds__(NT) matters: without it hipcc budgets registers for 1024-thread blocks and spills the
+// P(P+1) accumulators to scratch (measured: 64 VGPR + 280 B scratch, 32 ms instead of ~8 ms at C3).
+template <int M, int KR, bool SAMEZ, int NT>
+__global__ __launch_bounds__(NT) void k_cov(CovArgs a) {
     constexpr int P = M + KR, NP = P * (P + 1) / 2;
     const long long g = blockIdx.x / a.chunks;
     const int c = (int)(blockIdx.x % a.chunks);

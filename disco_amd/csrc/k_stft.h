@@ -1,40 +1,52 @@
 // STFT / oracle-mask / iSTFT kernels (librosa semantics, see oracle/stft_oracle.py for the restated
 // algorithm and the reference call sites: tango.py:335-342, 528-539; math_utils.py:134-152).
+//
+// A wave owns one frame of one signal group at a time and transforms its channels two per complex FFT
+// (fft.h).  Window and twiddle factors depend on the lane only and are held in registers; the only LDS is the
+// wave-private exchange buffer, so the four waves of a block never synchronise with each other in the
+// forward kernels.  All samples of a frame are requested before the first butterfly, and the spectra of all
+// channel pairs are written together: one contiguous 8*chans-byte vector per (frame, bin), i.e. 512*chans
+// contiguous bytes per wave store.
 #pragma once
 #include "fft.h"
 
 namespace disco {
 
-constexpr int STFT_WAVES = 4;     // waves (= frame/channel-pair items in flight) per block
-constexpr int STFT_ITERS = 4;     // items per wave per block (amortises the table loads)
+#ifndef DISCO_STFT_WAVES
+#define DISCO_STFT_WAVES 4
+#endif
+#ifndef DISCO_STFT_RUN
+#define DISCO_STFT_RUN 16
+#endif
+#ifndef DISCO_EXP
+#define DISCO_EXP 0            // kernel-ablation switch for tools/exp_*.py only; 0 in every shipped build
+#endif
+constexpr int STFT_WAVES = DISCO_STFT_WAVES;     // waves per block; each streams its own run of frames
+constexpr int STFT_RUN = DISCO_STFT_RUN;         // consecutive frames per wave
 
 template <int N>
 struct StftShared {
-    c32 tw[N];
-    float win[N];
     c32 buf[STFT_WAVES][fft_buf_len<N>()];
 };
 
 template <int N>
-__device__ __forceinline__ void load_tables(StftShared<N>& sh, const float* __restrict__ win, const c32* __restrict__ tw) {
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        sh.tw[i] = tw[i];
-        sh.win[i] = win[i];
-    }
-    __syncthreads();
+__device__ __forceinline__ void load_window(float* w, const float* __restrict__ win, int lane) {
+#pragma unroll
+    for (int e = 0; e < FftPlan<N>::E; ++e) w[e] = win[lane + 64 * e];
 }
 
-// windowed, centre-padded frame t of the channel pair (xa, xb) into FFT slots: v[e] = (a, b)[lane + 64 e]
-template <int N>
-__device__ __forceinline__ void load_frame_pair(c32* v, const float* __restrict__ xa, const float* __restrict__ xb,
-                                                int t, int L, int pad_mode, const float* win, int lane) {
-    constexpr int E = FftPlan<N>::E, H = N / 2;
+// Slots [E0, E1) of centre-padded frame t of the channel pair (xa, xb), un-windowed: v[e] = (a, b)[lane + 64 e].
+// With hop = N/2 the first half of frame t+1 is the second half of frame t, so a wave streaming consecutive
+// frames only ever fetches slots [E/2, E) after its first frame.
+template <int N, int E0, int E1>
+__device__ __forceinline__ void load_frame_slots(c32* v, const float* __restrict__ xa, const float* __restrict__ xb,
+                                                 int t, int L, int pad_mode, int lane) {
+    constexpr int H = N / 2;
     const int p0 = t * H - N / 2;
-    const bool interior = (p0 >= 0) && (p0 + N <= L);
+    const bool interior = (p0 + 64 * E0 >= 0) && (p0 + 64 * E1 <= L);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
+    for (int e = E0; e < E1; ++e) {
         const int n = lane + 64 * e;
-        const float w = win[n];
         float a, b = 0.f;
         if (interior) {
             a = xa[p0 + n];
@@ -43,45 +55,92 @@ __device__ __forceinline__ void load_frame_pair(c32* v, const float* __restrict_
             a = load_padded(xa, p0 + n, L, pad_mode);
             if (xb) b = load_padded(xb, p0 + n, L, pad_mode);
         }
-        v[e] = make_float2(a * w, b * w);
+        v[e - E0] = make_float2(a, b);
     }
 }
 
-// x: [n_sig][chans][L] -> X: [n_sig][T][F][chans].  One wave per (signal group, frame, channel pair).
-template <int N>
-__global__ __launch_bounds__(256) void k_stft(const float* __restrict__ x, c32* __restrict__ X,
-                                               const float* __restrict__ win, const c32* __restrict__ tw,
-                                               int chans, int L, int T, int pad_mode, long long n_items) {
-    constexpr int E = FftPlan<N>::E, F = N / 2 + 1;
+// x: [n_sig][chans][L] -> X: [n_sig][T][F][chans].  CHP = ceil(chans / 2) channel pairs per frame.
+// A wave streams STFT_RUN consecutive frames of one signal group: the next frame's new half-window is
+// requested before the current frame is transformed (the loads fly under the butterflies), the shared
+// half-window is recycled in registers.
+template <int N, int CHP>
+__global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restrict__ x, c32* __restrict__ X,
+                                                           const float* __restrict__ win, const c32* __restrict__ tw,
+                                                           int chans, int L, int T, int pad_mode, int runs_per_sig,
+                                                           long long n_witems) {
+    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, NJ = E / 2 + 1, EH = E / 2;
     __shared__ StftShared<N> sh;
-    load_tables<N>(sh, win, tw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int MP = (chans + 1) >> 1;
-    for (int it = 0; it < STFT_ITERS; ++it) {
-        const long long item = ((long long)blockIdx.x * STFT_ITERS + it) * STFT_WAVES + wave;
-        const bool active = item < n_items;
-        const int pair = (int)(item % MP);
-        const long long gt = item / MP;
-        const int t = (int)(gt % T);
-        const long long g = gt / T;
-        const int ca = 2 * pair, cb = 2 * pair + 1;
-        c32 v[E];
-        if (active) {
-            const float* xa = x + (g * chans + ca) * (long long)L;
-            const float* xb = (cb < chans) ? x + (g * chans + cb) * (long long)L : nullptr;
-            load_frame_pair<N>(v, xa, xb, t, L, pad_mode, sh.win, lane);
+    const long long item = (long long)blockIdx.x * STFT_WAVES + wave;          // (g, run)
+    if (item >= n_witems) return;                  // no block-level synchronisation anywhere below
+    const long long g = item / runs_per_sig;
+    const int t0 = (int)(item % runs_per_sig) * STFT_RUN;
+    const int t1 = min(T, t0 + STFT_RUN);
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
+    float w[E];
+    load_window<N>(w, win, lane);
+    const float* xa[CHP];
+    const float* xb[CHP];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) {
+        xa[p] = x + (g * chans + 2 * p) * (long long)L;
+        xb[p] = (2 * p + 1 < chans) ? x + (g * chans + 2 * p + 1) * (long long)L : nullptr;
+    }
+    c32 raw[CHP][E];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) load_frame_slots<N, 0, E>(raw[p], xa[p], xb[p], t0, L, pad_mode, lane);
+    for (int t = t0; t < t1; ++t) {
+        c32 nxt[CHP][EH];
+        if (t + 1 < t1 && !(DISCO_EXP & 2)) {
+#pragma unroll
+            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], t + 1, L, pad_mode, lane);
         } else {
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = make_float2(0.f, 0.f);
+            for (int p = 0; p < CHP; ++p)
+#pragma unroll
+                for (int e = 0; e < EH; ++e) nxt[p][e] = make_float2(0.f, 0.f);
         }
-        fft_wave<N>(v, sh.tw, sh.buf[wave], lane);
-        c32* Xo = X + ((g * T + t) * (long long)F) * chans;
-        rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int f, c32 A, c32 B) {
-            if (active) {
-                Xo[(long long)f * chans + ca] = A;
-                if (cb < chans) Xo[(long long)f * chans + cb] = B;
+        c32 A[CHP][NJ], B[CHP][NJ];
+#pragma unroll
+        for (int p = 0; p < CHP; ++p) {
+            c32 v[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = make_float2(raw[p][e].x * w[e], raw[p][e].y * w[e]);
+            fft_wave<N>(v, wtw, sh.buf[wave], lane);
+            rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int j, int, c32 a, c32 b) {
+                A[p][j] = a;
+                B[p][j] = b;
+            });
+        }
+        if (!(DISCO_EXP & 1) || A[0][0].x == 1.2345f) {
+            c32* Xo = X + ((g * T + t) * (long long)F) * chans;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j < NJ - 1 || lane == 0) {
+                    const int f = lane + 64 * j;
+                    c32* o = Xo + (long long)f * chans;
+                    if ((chans & 1) == 0) {
+                        float4* o4 = reinterpret_cast<float4*>(o);      // (f*chans + 2p) * 8 B is 16-B aligned
+#pragma unroll
+                        for (int p = 0; p < CHP; ++p) o4[p] = make_float4(A[p][j].x, A[p][j].y, B[p][j].x, B[p][j].y);
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < CHP; ++p) {
+                            o[2 * p] = A[p][j];
+                            if (2 * p + 1 < chans) o[2 * p + 1] = B[p][j];
+                        }
+                    }
+                }
             }
-        });
+        }
+#pragma unroll
+        for (int p = 0; p < CHP; ++p)
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                raw[p][e] = raw[p][e + EH];
+                raw[p][e + EH] = nxt[p][e];
+            }
     }
 }
 
@@ -103,33 +162,50 @@ __device__ __forceinline__ float tf_mask_value(c32 S, c32 Nn, int mask_type, int
     return xi / (1.f + xi);
 }
 
-// s_ref, n_ref: [n_sig][L] -> mask [n_sig][T][F]; the pair (s, n) shares one complex FFT.
+// s_ref, n_ref: [n_sig][L] -> mask [n_sig][T][F]; the pair (s, n) shares one complex FFT.  Streams like k_stft.
 template <int N>
-__global__ __launch_bounds__(256) void k_mask_oracle(const float* __restrict__ s_ref, const float* __restrict__ n_ref,
-                                                      float* __restrict__ mask, const float* __restrict__ win,
-                                                      const c32* __restrict__ tw, int L, int T, int pad_mode,
-                                                      int mask_type, int mask_pow, float thr_lin, long long n_items) {
-    constexpr int E = FftPlan<N>::E, F = N / 2 + 1;
+__global__ __launch_bounds__(64 * STFT_WAVES) void k_mask_oracle(const float* __restrict__ s_ref, const float* __restrict__ n_ref,
+                                                                  float* __restrict__ mask, const float* __restrict__ win,
+                                                                  const c32* __restrict__ tw, int L, int T, int pad_mode,
+                                                                  int mask_type, int mask_pow, float thr_lin, int runs_per_sig,
+                                                                  long long n_witems) {
+    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2;
     __shared__ StftShared<N> sh;
-    load_tables<N>(sh, win, tw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int it = 0; it < STFT_ITERS; ++it) {
-        const long long item = ((long long)blockIdx.x * STFT_ITERS + it) * STFT_WAVES + wave;
-        const bool active = item < n_items;
-        const int t = (int)(item % T);
-        const long long g = item / T;
-        c32 v[E];
-        if (active) {
-            load_frame_pair<N>(v, s_ref + g * (long long)L, n_ref + g * (long long)L, t, L, pad_mode, sh.win, lane);
+    const long long item = (long long)blockIdx.x * STFT_WAVES + wave;
+    if (item >= n_witems) return;
+    const long long g = item / runs_per_sig;
+    const int t0 = (int)(item % runs_per_sig) * STFT_RUN;
+    const int t1 = min(T, t0 + STFT_RUN);
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
+    float w[E];
+    load_window<N>(w, win, lane);
+    const float* xs = s_ref + g * (long long)L;
+    const float* xn = n_ref + g * (long long)L;
+    c32 raw[E];
+    load_frame_slots<N, 0, E>(raw, xs, xn, t0, L, pad_mode, lane);
+    for (int t = t0; t < t1; ++t) {
+        c32 nxt[EH];
+        if (t + 1 < t1) {
+            load_frame_slots<N, EH, E>(nxt, xs, xn, t + 1, L, pad_mode, lane);
         } else {
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = make_float2(0.f, 0.f);
+            for (int e = 0; e < EH; ++e) nxt[e] = make_float2(0.f, 0.f);
         }
-        fft_wave<N>(v, sh.tw, sh.buf[wave], lane);
+        c32 v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = make_float2(raw[e].x * w[e], raw[e].y * w[e]);
+        fft_wave<N>(v, wtw, sh.buf[wave], lane);
         float* mo = mask + (g * T + t) * (long long)F;
-        rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int f, c32 A, c32 B) {
-            if (active) mo[f] = tf_mask_value(A, B, mask_type, mask_pow, thr_lin);
+        rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
+            mo[f] = tf_mask_value(a, b, mask_type, mask_pow, thr_lin);
         });
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {
+            raw[e] = raw[e + EH];
+            raw[e + EH] = nxt[e];
+        }
     }
 }
 
@@ -148,7 +224,6 @@ constexpr int ISTFT_SEGS = ISTFT_FRAMES - 1;
 
 template <int N>
 struct IstftShared {
-    c32 tw[N];
     float win[N];
     c32 buf[STFT_WAVES][fft_buf_len<N>()];     // after the transform each wave parks its two time frames here
 };
@@ -158,17 +233,15 @@ __device__ __forceinline__ float* istft_frame(IstftShared<N>& sh, int j) {
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void k_istft(const c32* __restrict__ Z, float* __restrict__ out,
-                                                const float* __restrict__ win, const c32* __restrict__ tw,
-                                                int L, int T, int blocks_per_sig) {
+__global__ __launch_bounds__(64 * STFT_WAVES) void k_istft(const c32* __restrict__ Z, float* __restrict__ out,
+                                                            const float* __restrict__ win, const c32* __restrict__ tw,
+                                                            int L, int T, int blocks_per_sig) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2;
     __shared__ IstftShared<N> sh;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        sh.tw[i] = tw[i];
-        sh.win[i] = win[i];
-    }
-    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) sh.win[i] = win[i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
     const long long g = blockIdx.x / blocks_per_sig;
     const int seg0 = (int)(blockIdx.x % blocks_per_sig) * ISTFT_SEGS;       // first output segment == first frame
     const int ta = seg0 + 2 * wave, tb = ta + 1;
@@ -195,9 +268,9 @@ __global__ __launch_bounds__(256) void k_istft(const c32* __restrict__ Z, float*
         const c32 V = make_float2(a.x - b.y, a.y + b.x);
         v[e] = cconj(V);
     }
-    fft_wave<N>(v, sh.tw, sh.buf[wave], lane);
+    fft_wave<N>(v, wtw, sh.buf[wave], lane);
     const float inv = 1.0f / N;
-    DISCO_LDS_WAR();                                   // every lane is past its last read of buf[wave]
+    __syncthreads();                                   // sh.win is loaded; every lane is past its last read of buf[wave]
     float* fa = istft_frame<N>(sh, 2 * wave);
     float* fb = istft_frame<N>(sh, 2 * wave + 1);
 #pragma unroll

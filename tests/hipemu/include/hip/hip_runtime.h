@@ -157,6 +157,12 @@ static inline int __all(int pred) {
     return (__ballot(pred) & full) == full;
 }
 
+// wave-level fences used by the kernels: the scheduling barrier becomes a real 64-thread rendezvous here
+static inline void __builtin_amdgcn_wave_barrier() { pthread_barrier_wait(&hipemu::t_wave->bar); }
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 

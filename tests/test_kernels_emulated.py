@@ -20,7 +20,7 @@ def make_engine():
     return mk
 
 
-@pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 2048, 2), (1024, 2600, 1)])
+@pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 2048, 2), (1024, 2600, 1), (512, 9000, 4)])
 @pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
 def test_emu_stft(make_engine, n_fft, L, chans, pad_mode):
     print(pc.check_stft(make_engine, n_sig=2, chans=chans, L=L, n_fft=n_fft, pad_mode=pad_mode))
@@ -33,6 +33,7 @@ def test_emu_istft(make_engine, n_fft, L):
 
 def test_emu_masks(make_engine):
     print(pc.check_masks(make_engine, L=1800))
+    print(pc.check_masks(make_engine, L=5000))
 
 
 @pytest.mark.parametrize('K,M,same_z,mask_remote', [(2, 2, True, True), (3, 2, False, False), (1, 4, True, True), (4, 4, True, True)])
