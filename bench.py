@@ -41,6 +41,8 @@ def kernel_alg_bytes(M, K, F, H):
         'apply1': M * F * 8 + F * 8,                          # X in, z out
         'cov2': M * F * 8 + F * 4 + (K - 1) * F * 8,          # X + mask + remote z in
         'apply2': M * F * 8 + (K - 1) * F * 8 + F * 8,        # X + remote z in, yf out
+        'step2_cov': M * F * 8 + F * 4,                       # X + mask in (z stays on chip)
+        'step2_apply': M * F * 8 + F * 8,                     # X in, yf out
         'istft': F * 8 + H * 4,                               # yf in, hop samples out
     }
 
@@ -157,10 +159,11 @@ def main():
             ('apply1', lambda: lib.disco_apply(eng.ctx, p(X), None, p(w), M, 1, p(z), None)),
         ]
         if K > 1:
-            calls += [
-                ('cov2', lambda: lib.disco_cov_masked(eng.ctx, p(X), p(mask), p(z), p(z), 1, P2, p(Rss), p(Rnn), None)),
-                ('solve2', lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, P2, 1.0, p(w), None, None)),
-                ('apply2', lambda: lib.disco_apply(eng.ctx, p(X), p(z), p(w), P2, 1, p(yf), None)),
+            w2 = torch.empty_like(w)
+            calls = calls[:-1] + [          # step 2 on the on-chip z exchange replaces apply1 / cov2 / apply2
+                ('step2_cov', lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), None, p(Rss), p(Rnn), None)),
+                ('solve2', lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, P2, 1.0, p(w2), None, None)),
+                ('step2_apply', lambda: lib.disco_step2_apply_fused(eng.ctx, p(X), p(w), p(w2), None, p(yf), None)),
                 ('istft', lambda: lib.disco_istft(eng.ctx, p(yf), G, p(out), None)),
             ]
         else:

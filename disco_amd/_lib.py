@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('DISCO_HIP_LIB', os.path.join(_HERE, 'lib', 'libdisco_
 E_ARG, E_UNSUPPORTED, E_HIP_BASE = -1, -2, -1000
 MASK_TYPES = {'irm': 0, 'ibm': 1, 'iam': 2}
 PAD_MODES = {'reflect': 0, 'constant': 1}
+FLAG_STAGED_STEP2 = 1
 
 
 class DiscoCfg(C.Structure):
@@ -20,7 +21,7 @@ class DiscoCfg(C.Structure):
     _fields_ = [('rooms', C.c_int32), ('nodes', C.c_int32), ('mics', C.c_int32), ('length', C.c_int32),
                 ('n_fft', C.c_int32), ('hop', C.c_int32), ('ref_mic', C.c_int32), ('mask_type', C.c_int32),
                 ('mask_pow', C.c_int32), ('mask_bin_thr_db', C.c_float), ('mu', C.c_float),
-                ('pad_mode', C.c_int32), ('device', C.c_int32), ('reserved', C.c_int32 * 3)]
+                ('pad_mode', C.c_int32), ('device', C.c_int32), ('flags', C.c_int32), ('reserved', C.c_int32 * 2)]
 
 
 # name -> (restype, argtypes); every symbol the header declares
@@ -46,6 +47,8 @@ PROTOTYPES = {
     'disco_gevd_mwf_r1': (_int, [_vp, _vp, _vp, _i64, _int, _f, _vp, _vp, _vp]),
     'disco_apply': (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     'disco_noise_residual': (_int, [_vp, _vp, _vp, _vp, _vp]),
+    'disco_step2_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'disco_step2_apply_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_tango_enhance': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

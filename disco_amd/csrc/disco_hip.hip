@@ -10,6 +10,7 @@
 #include "../../include/disco_hip.h"
 #include "k_apply.h"
 #include "k_cov.h"
+#include "k_fused.h"
 #include "k_solve.h"
 #include "k_stft.h"
 
@@ -283,13 +284,20 @@ static int ensure_scratch(disco_ctx* ctx, size_t bytes) {
     return 0;
 }
 
-extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs,
-                                const disco_c32* Zn, int mask_remote, int P, disco_c32* Rss, disco_c32* Rnn,
-                                disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+static int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
+    const long long n_gf = (long long)ctx->cfg.rooms * ctx->cfg.nodes * ctx->F;
+    hipLaunchKernelGGL(k_cov_finalize, dim3((unsigned)std::min<long long>((n_gf + 127) / 128, 65535)), dim3(128), 0,
+                       (hipStream_t)s, (const float4*)ctx->scratch, (c32*)Rss, (c32*)Rnn, n_gf, ctx->F, chunks, P,
+                       1.0f / (float)ctx->T);
+    return check_launch(ctx, "k_cov_finalize");
+}
+
+// chunk partials of the masked covariances into ctx->scratch ([R*K][chunks][F][NP] float4)
+static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs, const disco_c32* Zn,
+                        int mask_remote, int P, int* chunks_out, disco_stream s) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, KR = P - M;
-    if (!X || !mask || !Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
+    if (!X || !mask) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
     if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: P must be M or M + K - 1");
     if (KR > 0 && (!Zs || !Zn)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Zs/Zn required when P > M");
     if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: P > 8 not supported yet");
@@ -331,38 +339,58 @@ extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float*
     DISCO_FOR_MKR(X_)
 #undef X_
     if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: unsupported (M, K) combination");
-    rc = check_launch(ctx, "k_cov");
+    *chunks_out = chunks;
+    return check_launch(ctx, "k_cov");
+}
+
+extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs,
+                                const disco_c32* Zn, int mask_remote, int P, disco_c32* Rss, disco_c32* Rnn,
+                                disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
+    int chunks = 1;
+    int rc = cov_partials(ctx, X, mask, Zs, Zn, mask_remote, P, &chunks, s);
     if (rc) return rc;
-    const long long n_gf = G * ctx->F;
-    hipLaunchKernelGGL(k_cov_finalize, dim3((unsigned)std::min<long long>((n_gf + 127) / 128, 65535)), dim3(128), 0,
-                       (hipStream_t)s, (const float4*)ctx->scratch, (c32*)Rss, (c32*)Rnn, n_gf, ctx->F, chunks, P,
-                       1.0f / (float)ctx->T);
-    return check_launch(ctx, "k_cov_finalize");
+    return cov_finalize(ctx, chunks, P, Rss, Rnn, s);
 }
 
 template <int P>
-static void launch_solve(const c32* Rss, const c32* Rnn, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s) {
+static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s) {
     const int probs = SolveGeom<P>::PROBS;
     const long long grid = (n_prob + probs - 1) / probs;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1<P>), dim3((unsigned)grid), dim3(SolveGeom<P>::THREADS), 0, s, Rss, Rnn,
-                       n_prob, mu, w, t1);
+    if (src.part)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1<P, true>), dim3((unsigned)grid), dim3(SolveGeom<P>::THREADS), 0, s, src,
+                           n_prob, mu, w, t1);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1<P, false>), dim3((unsigned)grid), dim3(SolveGeom<P>::THREADS), 0, s, src,
+                           n_prob, mu, w, t1);
+}
+
+static int solve_dispatch(disco_ctx* ctx, const SolveSrc& src, int64_t n_prob, int P, float mu, disco_c32* w, disco_c32* t1,
+                          disco_stream s) {
+    if (P < 1 || P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: P must be in 1..16");
+    if (n_prob / 4 > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: batch too large");
+    hipStream_t st = (hipStream_t)s;
+    switch (P) {
+#define C_(P_) case P_: launch_solve<P_>(src, n_prob, (double)mu, (c32*)w, (c32*)t1, st); break;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+#undef C_
+    }
+    return check_launch(ctx, "k_gevd_mwf_r1");
 }
 
 extern "C" int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const disco_c32* Rnn, int64_t n_prob, int P,
                                  float mu, disco_c32* w, disco_c32* t1, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
     if (!Rss || !Rnn || !w || n_prob < 1) return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1: bad argument");
-    if (P < 1 || P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: P must be in 1..16");
-    if (n_prob / 4 > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: batch too large");
-    const c32* A = (const c32*)Rss;
-    const c32* B = (const c32*)Rnn;
-    hipStream_t st = (hipStream_t)s;
-    switch (P) {
-#define C_(P_) case P_: launch_solve<P_>(A, B, n_prob, (double)mu, (c32*)w, (c32*)t1, st); break;
-        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
-#undef C_
-    }
-    return check_launch(ctx, "k_gevd_mwf_r1");
+    SolveSrc src;
+    src.Rss = (const c32*)Rss;
+    src.Rnn = (const c32*)Rnn;
+    src.part = nullptr;
+    src.F = 1;
+    src.chunks = 1;
+    src.inv_T = 1.f;
+    return solve_dispatch(ctx, src, n_prob, P, mu, w, t1, s);
 }
 
 extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, int P, int conj_w,
@@ -403,11 +431,108 @@ extern "C" int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const di
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// step 2 with the in-register z exchange
+// ---------------------------------------------------------------------------------------------------------
+static int step2_chunks(const disco_ctx* ctx, int tiles_plus_1) {
+    const long long base = (long long)ctx->cfg.rooms * tiles_plus_1;
+    long long c = (4096 + base - 1) / base;
+    if (c > 8) c = 8;
+    if (c > ctx->T) c = ctx->T;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
+                              disco_c32* z_out, int* chunks_out, disco_stream s) {
+    if (!X || !mask_w || !w_loc) return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused: null argument");
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes, P = M + K - 1;
+    if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_cov_fused: M + K - 1 > 8 not supported yet");
+    const int tiles = (ctx->F - 1) / 64;
+    const int chunks = step2_chunks(ctx, tiles + 1);
+    const long long G = (long long)c.rooms * K;
+    const int NP = P * (P + 1) / 2;
+    int rc = ensure_scratch(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
+    if (rc) return rc;
+    Step2Args a;
+    a.X = (const c32*)X;
+    a.mask = mask_w;
+    a.w_loc = (const c32*)w_loc;
+    a.w_glo = nullptr;
+    a.z_out = (c32*)z_out;
+    a.yf = nullptr;
+    a.part = (float4*)ctx->scratch;
+    a.K = K;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    a.chunks = chunks;
+    const long long nblk = (long long)c.rooms * (tiles + 1) * chunks;
+    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_cov_fused: batch too large");
+    bool launched = false;
+#define X_(M_, KR_)                                                                                                  \
+    if (!launched && M == M_ && K == KR_ + 1) {                                                                      \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_cov_fused<M_, KR_ + 1>), dim3((unsigned)nblk), dim3(64 * (KR_ + 1)), 0, \
+                           (hipStream_t)s, a);                                                                       \
+        launched = true;                                                                                             \
+    }
+    DISCO_FOR_MKR(X_)
+#undef X_
+    if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_cov_fused: unsupported (M, K) combination");
+    *chunks_out = chunks;
+    return check_launch(ctx, "k_step2_cov_fused");
+}
+
+extern "C" int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
+                                     disco_c32* z_out, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused: null argument");
+    int chunks = 1;
+    int rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_out, &chunks, s);
+    if (rc) return rc;
+    return cov_finalize(ctx, chunks, ctx->cfg.mics + ctx->cfg.nodes - 1, Rss, Rnn, s);
+}
+
+extern "C" int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc, const disco_c32* w_glo,
+                                       disco_c32* z_out, disco_c32* yf, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!X || !w_loc || !w_glo || !yf) return fail(ctx, DISCO_E_ARG, "disco_step2_apply_fused: null argument");
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes, P = M + K - 1;
+    if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_fused: M + K - 1 > 8 not supported yet");
+    Step2Args a;
+    a.X = (const c32*)X;
+    a.mask = nullptr;
+    a.w_loc = (const c32*)w_loc;
+    a.w_glo = (const c32*)w_glo;
+    a.z_out = (c32*)z_out;
+    a.yf = (c32*)yf;
+    a.part = nullptr;
+    a.K = K;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    const int tiles = (ctx->F - 1) / 64;
+    a.chunks = step2_chunks(ctx, tiles + 1);
+    const long long nblk = (long long)c.rooms * (tiles + 1) * a.chunks;
+    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_fused: batch too large");
+    bool launched = false;
+#define X_(M_, KR_)                                                                                                  \
+    if (!launched && M == M_ && K == KR_ + 1) {                                                                      \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_apply_fused<M_, KR_ + 1>), dim3((unsigned)nblk), dim3(64 * (KR_ + 1)), \
+                           0, (hipStream_t)s, a);                                                                    \
+        launched = true;                                                                                             \
+    }
+    DISCO_FOR_MKR(X_)
+#undef X_
+    if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_fused: unsupported (M, K) combination");
+    return check_launch(ctx, "k_step2_apply_fused");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // whole path
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 struct WsLayout {
-    size_t X, z, yf, Rss, Rnn, w, total;
+    size_t X, z, yf, Rss, Rnn, w, w2, total;
 };
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 WsLayout ws_layout(const disco_ctx* ctx) {
@@ -422,12 +547,27 @@ WsLayout ws_layout(const disco_ctx* ctx) {
     l.Rss = o; o = align_up(o + G * ctx->F * Pmax * Pmax * sizeof(c32));
     l.Rnn = o; o = align_up(o + G * ctx->F * Pmax * Pmax * sizeof(c32));
     l.w = o;   o = align_up(o + G * ctx->F * Pmax * sizeof(c32));
+    l.w2 = o;  o = align_up(o + G * ctx->F * Pmax * sizeof(c32));
     l.total = o;
     return l;
 }
 }  // namespace
 
 extern "C" size_t disco_workspace_bytes(const disco_ctx* ctx) { return ctx ? ws_layout(ctx).total : 0; }
+
+static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
+                               disco_c32* z_y, disco_c32* yf, char* ws, const WsLayout& l, disco_stream s);
+
+static int solve_from_partials(disco_ctx* ctx, int chunks, int P, disco_c32* w, disco_stream s) {
+    SolveSrc src;
+    src.Rss = nullptr;
+    src.Rnn = nullptr;
+    src.part = (const float4*)ctx->scratch;
+    src.F = ctx->F;
+    src.chunks = chunks;
+    src.inv_T = 1.0f / (float)ctx->T;
+    return solve_dispatch(ctx, src, (int64_t)ctx->cfg.rooms * ctx->cfg.nodes * ctx->F, P, ctx->cfg.mu, w, nullptr, s);
+}
 
 extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
                                    disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
@@ -450,6 +590,8 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
         }
         ws = (char*)ctx->own_ws;
     }
+    if (c.nodes > 1 && c.mics + c.nodes - 1 <= 8 && !(c.flags & DISCO_FLAG_STAGED_STEP2))
+        return tango_enhance_fused(ctx, y, mask_z, mask_w, out, z_y, yf, ws, l, s);
     disco_c32* X = (disco_c32*)(ws + l.X);
     disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
     disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
@@ -474,5 +616,26 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     if ((rc = disco_cov_masked(ctx, X, mask_w, z, z, 1, P2, Rss, Rnn, s))) return rc;
     if ((rc = disco_gevd_mwf_r1(ctx, Rss, Rnn, G * ctx->F, P2, c.mu, w, nullptr, s))) return rc;
     if ((rc = disco_apply(ctx, X, z, w, P2, 1, yo, s))) return rc;
+    return disco_istft(ctx, yo, G, out, s);
+}
+
+// The same path with step 2 on the in-register z exchange (default whenever all nodes of a room share the GPU).
+static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
+                               disco_c32* z_y, disco_c32* yf, char* ws, const WsLayout& l, disco_stream s) {
+    const disco_cfg& c = ctx->cfg;
+    disco_c32* X = (disco_c32*)(ws + l.X);
+    disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
+    disco_c32* w_loc = (disco_c32*)(ws + l.w);
+    disco_c32* w_glo = (disco_c32*)(ws + l.w2);
+    const int64_t G = (int64_t)c.rooms * c.nodes;
+    const int M = c.mics, P2 = c.mics + c.nodes - 1;
+    int rc;
+    int chunks = 1;
+    if ((rc = disco_stft(ctx, y, G, M, X, s))) return rc;
+    if ((rc = cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, &chunks, s))) return rc;
+    if ((rc = solve_from_partials(ctx, chunks, M, w_loc, s))) return rc;
+    if ((rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s))) return rc;
+    if ((rc = solve_from_partials(ctx, chunks, P2, w_glo, s))) return rc;
+    if ((rc = disco_step2_apply_fused(ctx, X, w_loc, w_glo, nullptr, yo, s))) return rc;
     return disco_istft(ctx, yo, G, out, s);
 }

@@ -1,0 +1,225 @@
+// Step-2 kernels with the cross-node z exchange kept ON CHIP (mask_for_z = 'local', tango.py:378-450).
+//
+// DISCO's algorithm has every node k send one compressed channel z_k = w_loc,k^H y_k to all the others
+// (tango.py:369, 382).  When all K nodes of a room live on one GPU that exchange never needs to touch HBM:
+// a workgroup has one WAVE per node; wave k streams node k's STFT for a tile of 64 bins (one contiguous
+// 512*M-byte span per wave-load), filters it with its local filter held in registers, drops its z into a
+// double-buffered LDS tile, and after one workgroup barrier per U frames picks up the K-1 remote z's.
+//   k_step2_cov_fused   : z (optionally written out) + the (M+K-1)x(M+K-1) masked covariances of every node
+//                         -- replaces disco_apply + disco_cov_masked(Zs=Zn=z): two passes over X and four over z less
+//   k_step2_apply_fused : z again (recomputed, 4 FMAs per channel) + yf_k = w_glo,k^H [y_k ; z_-k]
+// The Nyquist bin (F = 64 n + 1) is served by one extra workgroup per (room, chunk) whose lanes stride over
+// frames instead of bins; the exchange is identical (same lane <-> same frame in every wave).
+#pragma once
+#include "k_cov.h"
+
+namespace disco {
+
+struct Step2Args {
+    const c32* X;        // [R][K][T][F][M]
+    const float* mask;   // [R][K][T][F]         (cov kernel)
+    const c32* w_loc;    // [R][K][F][M]
+    const c32* w_glo;    // [R][K][F][M+K-1]     (apply kernel)
+    c32* z_out;          // [R][K][T][F] or null
+    c32* yf;             // [R][K][T][F]         (apply kernel)
+    float4* part;        // [R*K][chunks][F][NP] (cov kernel)
+    int K, T, F, chunks;
+};
+
+// (room, bin tile | Nyquist, frame chunk) of a block and the (bin, first frame, frame stride) of a lane
+struct Step2Geom {
+    long long r;
+    int c, t0, t1, f, t_lane, t_stride;
+    bool nyq;
+};
+
+__device__ __forceinline__ Step2Geom step2_geom(const Step2Args& a, int lane) {
+    Step2Geom g;
+    const int nbin = a.F - 1, tiles = nbin / 64;
+    int bid = blockIdx.x;
+    g.c = bid % a.chunks;
+    bid /= a.chunks;
+    const int tile = bid % (tiles + 1);
+    g.r = bid / (tiles + 1);
+    g.t0 = (int)(((long long)a.T * g.c) / a.chunks);
+    g.t1 = (int)(((long long)a.T * (g.c + 1)) / a.chunks);
+    g.nyq = tile == tiles;
+    g.f = g.nyq ? nbin : tile * 64 + lane;
+    g.t_lane = g.nyq ? lane : 0;
+    g.t_stride = g.nyq ? 64 : 1;
+    return g;
+}
+
+template <int M>
+__device__ __forceinline__ c32 filt_conj(const c32* w, const c32* x) {      // sum_i conj(w_i) x_i
+    float zr = 0.f, zi = 0.f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        zr = fmaf(w[i].x, x[i].x, fmaf(w[i].y, x[i].y, zr));
+        zi = fmaf(w[i].x, x[i].y, fmaf(-w[i].y, x[i].x, zi));
+    }
+    return make_float2(zr, zi);
+}
+
+#ifndef DISCO_S2_U_COV
+#define DISCO_S2_U_COV 1
+#endif
+#ifndef DISCO_S2_U_APPLY
+#define DISCO_S2_U_APPLY 4
+#endif
+constexpr int S2_U_COV = DISCO_S2_U_COV;        // frames per barrier in the covariance kernel (register budget)
+constexpr int S2_U_APPLY = DISCO_S2_U_APPLY;    // frames per barrier in the apply kernel
+
+// grid = R * (F/64 + 1) * chunks blocks of 64*K threads
+template <int M, int K>
+__global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
+    constexpr int P = M + K - 1, NP = P * (P + 1) / 2, U = S2_U_COV;
+    __shared__ c32 zbuf[2][U][K][64];
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Step2Geom gm = step2_geom(a, lane);
+    const int T = a.T, F = a.F, f = gm.f;
+    const long long g = gm.r * a.K + k;
+    const c32* Xg = a.X + (g * T * (long long)F) * M;
+    const float* mg = a.mask + g * T * (long long)F;
+    c32* zg = a.z_out ? a.z_out + g * T * (long long)F : nullptr;
+    c32 wl[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) wl[i] = a.w_loc[(g * F + f) * M + i];
+    c32 acc_s[NP], acc_n[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
+    // software pipeline: the next U frames are requested before the current ones are reduced, so every wave
+    // keeps 2*U*(8M+4) bytes per lane in flight while it computes
+    auto fetch = [&](int tu, c32 (*xx)[M], float* mm) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tu + u * gm.t_stride + gm.t_lane;
+            const bool live = t < gm.t1;
+            const long long tf = (long long)(live ? t : gm.t0) * F + f;
+#pragma unroll
+            for (int i = 0; i < M; ++i) xx[u][i] = live ? Xg[tf * M + i] : make_float2(0.f, 0.f);
+            mm[u] = live ? mg[tf] : 0.f;
+        }
+    };
+    c32 x[U][M], xn[U][M];
+    float m[U], mn[U];
+    fetch(gm.t0, x, m);
+    int buf = 0;
+    for (int tu = gm.t0; tu < gm.t1; tu += U * gm.t_stride, buf ^= 1) {
+        fetch(tu + U * gm.t_stride, xn, mn);           // frames >= t1 come back as zeros (predicated off)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tu + u * gm.t_stride + gm.t_lane;
+            const c32 z = filt_conj<M>(wl, x[u]);
+            zbuf[buf][u][k][lane] = z;
+            if (t < gm.t1 && zg) zg[(long long)t * F + f] = z;
+        }
+        __syncthreads();             // one barrier per U frames; zbuf is double buffered, so none is needed after the reads
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float ms = m[u], mc = 1.f - m[u];
+            c32 vs[P], vn[P];
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                vs[i] = make_float2(ms * x[u][i].x, ms * x[u][i].y);
+                vn[i] = make_float2(mc * x[u][i].x, mc * x[u][i].y);
+            }
+#pragma unroll
+            for (int jj = 0; jj < K - 1; ++jj) {       // concatenate_signals order; 'local': remote rows carry this node's mask
+                const int j = jj < k ? jj : jj + 1;
+                const c32 z = zbuf[buf][u][j][lane];
+                vs[M + jj] = make_float2(ms * z.x, ms * z.y);
+                vn[M + jj] = make_float2(mc * z.x, mc * z.y);
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+#pragma unroll
+                for (int j = i; j < P; ++j) {
+                    const int q = tri_index<P>(i, j);
+                    acc_s[q].x = fmaf(vs[i].x, vs[j].x, fmaf(vs[i].y, vs[j].y, acc_s[q].x));
+                    acc_n[q].x = fmaf(vn[i].x, vn[j].x, fmaf(vn[i].y, vn[j].y, acc_n[q].x));
+                    if (j != i) {
+                        acc_s[q].y = fmaf(vs[i].y, vs[j].x, fmaf(-vs[i].x, vs[j].y, acc_s[q].y));
+                        acc_n[q].y = fmaf(vn[i].y, vn[j].x, fmaf(-vn[i].x, vn[j].y, acc_n[q].y));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) x[u][i] = xn[u][i];
+            m[u] = mn[u];
+        }
+    }
+    if (gm.nyq) {                    // lanes of a wave hold partial sums over disjoint frames of the same (node, bin)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                acc_s[q].x += __shfl_xor(acc_s[q].x, off);
+                acc_s[q].y += __shfl_xor(acc_s[q].y, off);
+                acc_n[q].x += __shfl_xor(acc_n[q].x, off);
+                acc_n[q].y += __shfl_xor(acc_n[q].y, off);
+            }
+        }
+    }
+    if (!gm.nyq || lane == 0) {
+        float4* o = a.part + (((g * a.chunks + gm.c) * F) + f) * (long long)NP;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) o[q] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+    }
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(64 * K) void k_step2_apply_fused(Step2Args a) {
+    constexpr int P = M + K - 1, U = S2_U_APPLY;
+    __shared__ c32 zbuf[2][U][K][64];
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Step2Geom gm = step2_geom(a, lane);
+    const int T = a.T, F = a.F, f = gm.f;
+    const long long g = gm.r * a.K + k;
+    const c32* Xg = a.X + (g * T * (long long)F) * M;
+    c32* zg = a.z_out ? a.z_out + g * T * (long long)F : nullptr;
+    c32* yg = a.yf + g * T * (long long)F;
+    c32 wl[M], wg[P];
+#pragma unroll
+    for (int i = 0; i < M; ++i) wl[i] = a.w_loc[(g * F + f) * M + i];
+#pragma unroll
+    for (int i = 0; i < P; ++i) wg[i] = a.w_glo[(g * F + f) * P + i];
+    int buf = 0;
+    for (int tu = gm.t0; tu < gm.t1; tu += U * gm.t_stride, buf ^= 1) {
+        c32 x[U][M];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tu + u * gm.t_stride + gm.t_lane;
+            const bool live = t < gm.t1;
+            const long long tf = (long long)(live ? t : gm.t0) * F + f;
+#pragma unroll
+            for (int i = 0; i < M; ++i) x[u][i] = live ? Xg[tf * M + i] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tu + u * gm.t_stride + gm.t_lane;
+            const c32 z = filt_conj<M>(wl, x[u]);
+            zbuf[buf][u][k][lane] = z;
+            if (t < gm.t1 && zg) zg[(long long)t * F + f] = z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tu + u * gm.t_stride + gm.t_lane;
+            c32 y = filt_conj<M>(wg, x[u]);
+#pragma unroll
+            for (int jj = 0; jj < K - 1; ++jj) {
+                const int j = jj < k ? jj : jj + 1;
+                const c32 z = zbuf[buf][u][j][lane];
+                y.x = fmaf(wg[M + jj].x, z.x, fmaf(wg[M + jj].y, z.y, y.x));
+                y.y = fmaf(wg[M + jj].x, z.y, fmaf(-wg[M + jj].y, z.x, y.y));
+            }
+            if (t < gm.t1) yg[(long long)t * F + f] = y;
+        }
+    }
+}
+
+}  // namespace disco

@@ -15,6 +15,7 @@
 // column.  On convergence the columns are d_j v_j; the longest one gives (d0, v0).
 #pragma once
 #include "common.h"
+#include "k_cov.h"
 
 namespace disco {
 
@@ -28,10 +29,52 @@ struct SolveGeom {
     static constexpr int PROBS = THREADS / G;
 };
 
-template <int P>
-__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(const c32* __restrict__ Rss, const c32* __restrict__ Rnn,
-                                                                long long n_prob, double mu,
-                                                                c32* __restrict__ w_out, c32* __restrict__ t1_out) {
+// Where the pencils come from: either full row-major matrices (the disco_gevd_mwf_r1 ABI) or, inside the fused
+// path, straight from the covariance kernels' chunk partials (upper triangle, (Rss, Rnn) interleaved per entry:
+// part[g][chunk][f][q]), which saves materialising and re-reading the P x P matrices.
+struct SolveSrc {
+    const c32* Rss;
+    const c32* Rnn;
+    const float4* part;
+    int F, chunks;
+    float inv_T;
+};
+
+// row j of both Hermitian matrices of problem pid: rs[c] = Rss[j][c], rn[c] = Rnn[j][c]
+template <int P, bool FROM_PART>
+__device__ __forceinline__ void solve_load_row(const SolveSrc& src, long long pid, int j, c32* rs, c32* rn) {
+    if constexpr (!FROM_PART) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            rs[c] = src.Rss[pid * P * P + j * P + c];
+            rn[c] = src.Rnn[pid * P * P + j * P + c];
+        }
+    } else {
+        constexpr int NP = P * (P + 1) / 2;
+        const long long g = pid / src.F;
+        const int f = (int)(pid % src.F);
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            const bool up = c >= j;
+            const int q = up ? (j * P - (j * (j - 1)) / 2 + (c - j)) : (c * P - (c * (c - 1)) / 2 + (j - c));
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ch = 0; ch < src.chunks; ++ch) {
+                const float4 v = src.part[(((g * src.chunks + ch) * src.F) + f) * (long long)NP + q];
+                s.x += v.x;
+                s.y += v.y;
+                s.z += v.z;
+                s.w += v.w;
+            }
+            const float sg = up ? src.inv_T : -src.inv_T;           // lower triangle = conj(upper)
+            rs[c] = make_float2(s.x * src.inv_T, c == j ? 0.f : s.y * sg);
+            rn[c] = make_float2(s.z * src.inv_T, c == j ? 0.f : s.w * sg);
+        }
+    }
+}
+
+template <int P, bool FROM_PART>
+__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
+                                                                        c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
     __shared__ c64 s_L[PROBS][P][P + 1];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]
     __shared__ c64 s_Y[PROBS][P][P + 1];
@@ -42,20 +85,21 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(const c32
     const bool col = live && j < P;
     c64 (*Lm)[P + 1] = s_L[slot];
     c64 (*Ym)[P + 1] = s_Y[slot];
-    const c32* A = Rss + pid * P * P;
-    const c32* B = Rnn + pid * P * P;
 
-    // ---- stage Rnn (lower triangle) in LDS as float64
-    if (j < P) {
+    // ---- row j of both matrices; stage Rnn in LDS as float64
+    c32 rowA[P], rowB[P];
+    if (col) {
+        solve_load_row<P, FROM_PART>(src, pid, j, rowA, rowB);
+    } else {
 #pragma unroll
         for (int c = 0; c < P; ++c) {
-            c64 b = make_double2(c == j ? 1.0 : 0.0, 0.0);
-            if (live) {
-                const c32 t = B[j * P + c];
-                b = make_double2((double)t.x, (double)t.y);
-            }
-            Lm[j][c] = b;
+            rowA[c] = make_float2(0.f, 0.f);
+            rowB[c] = make_float2(c == j ? 1.f : 0.f, 0.f);
         }
+    }
+    if (j < P) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) Lm[j][c] = make_double2((double)rowB[c].x, (double)rowB[c].y);
     }
     __syncthreads();
 
@@ -81,11 +125,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(const c32
     c64 y[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        c64 a = make_double2(0.0, 0.0);
-        if (col) {
-            const c32 t = A[j * P + i];
-            a = make_double2((double)t.x, -(double)t.y);
-        }
+        c64 a = make_double2((double)rowA[i].x, -(double)rowA[i].y);
 #pragma unroll
         for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[i][k], y[k]));
         y[i] = zscale(a, 1.0 / dd[i]);

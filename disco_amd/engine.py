@@ -63,13 +63,14 @@ def parse_mask_type(mask):
 
 class Engine:
     def __init__(self, rooms, nodes, mics, length, n_fft=512, hop=None, ref_mic=0, mask='irm1', bin_thr=0.0,
-                 mu=1.0, pad_mode='reflect', device=0, lib=None):
+                 mu=1.0, pad_mode='reflect', device=0, lib=None, staged_step2=False):
         self.lib = lib if lib is not None else L.load()
         mt, mp = parse_mask_type(mask)
         hop = n_fft // 2 if hop is None else hop
         self.cfg = L.DiscoCfg(rooms=rooms, nodes=nodes, mics=mics, length=length, n_fft=n_fft, hop=hop,
                               ref_mic=ref_mic, mask_type=mt, mask_pow=mp, mask_bin_thr_db=bin_thr, mu=mu,
-                              pad_mode=L.PAD_MODES[pad_mode], device=device)
+                              pad_mode=L.PAD_MODES[pad_mode], device=device,
+                              flags=L.FLAG_STAGED_STEP2 if staged_step2 else 0)
         ctx = C.c_void_p()
         rc = self.lib.disco_create(C.byref(ctx), C.byref(self.cfg))
         self.ctx = ctx.value if rc == 0 else None
@@ -200,6 +201,27 @@ class Engine:
         zn = self.empty((self.R, self.K, self.T, self.F), np.complex64)
         self._chk(self.lib.disco_noise_residual(self.ctx, px, pz, zn.ptr, self.stream))
         return zn
+
+    def step2_cov_fused(self, X, mask_w, w_loc, want_z=True):
+        """Fused apply-1 + in-register z exchange + step-2 covariance -> Rss, Rnn (R,K,F,P,P)[, z (R,K,T,F)]."""
+        P = self.M + self.K - 1
+        px, kx = self.to_device(X, np.complex64)
+        pm, km = self.to_device(mask_w, np.float32)
+        pw, kw = self.to_device(w_loc, np.complex64)
+        z = self.empty((self.R, self.K, self.T, self.F), np.complex64) if want_z else None
+        Rss = self.empty((self.R, self.K, self.F, P, P), np.complex64)
+        Rnn = self.empty((self.R, self.K, self.F, P, P), np.complex64)
+        self._chk(self.lib.disco_step2_cov_fused(self.ctx, px, pm, pw, z.ptr if z else None, Rss.ptr, Rnn.ptr, self.stream))
+        return Rss, Rnn, z
+
+    def step2_apply_fused(self, X, w_loc, w_glo, want_z=False):
+        px, kx = self.to_device(X, np.complex64)
+        pl, kl = self.to_device(w_loc, np.complex64)
+        pg, kg = self.to_device(w_glo, np.complex64)
+        z = self.empty((self.R, self.K, self.T, self.F), np.complex64) if want_z else None
+        yf = self.empty((self.R, self.K, self.T, self.F), np.complex64)
+        self._chk(self.lib.disco_step2_apply_fused(self.ctx, px, pl, pg, z.ptr if z else None, yf.ptr, self.stream))
+        return yf, z
 
     # ---- whole path
     def workspace_bytes(self):

@@ -45,6 +45,10 @@ extern "C" {
 #define DISCO_MASK_IBM 1
 #define DISCO_MASK_IAM 2
 
+/* disco_cfg.flags: run step 2 of disco_tango_enhance through the staged kernels (z materialised in HBM, the form a
+ * node-sharded multi-GPU run needs) instead of the default in-register exchange. */
+#define DISCO_FLAG_STAGED_STEP2 1
+
 #define DISCO_PAD_REFLECT  0   /* librosa < 0.10 (the reference's era)  */
 #define DISCO_PAD_CONSTANT 1   /* librosa >= 0.10                        */
 
@@ -68,7 +72,8 @@ typedef struct disco_cfg {
     float   mu;             /* speech-distortion constant of intern_filter (1 at every call site)   */
     int32_t pad_mode;       /* DISCO_PAD_*                                                          */
     int32_t device;         /* HIP device ordinal                                                   */
-    int32_t reserved[3];
+    int32_t flags;          /* DISCO_FLAG_*                                                         */
+    int32_t reserved[2];
 } disco_cfg;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
@@ -134,6 +139,22 @@ int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const di
 
 /* zn = Y[ref_mic] - z_y -- tango.py:376.  X [R][K][T][F][M], z/zn [R][K][T][F]. */
 int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const disco_c32* z, disco_c32* zn, disco_stream s);
+
+/* ---- step 2 with the z exchange in registers (all K nodes of a room on this GPU, mask_for_z = 'local') ------ */
+
+/* tango.py:369 + 382-386 + 433-440 in one pass over X: every node's z_k = w_loc,k^H y_k is formed on the fly,
+ * swapped between the K node-lanes of a bin with lane shuffles, and the (M+K-1)^2 masked covariances of every
+ * node are accumulated.  Equivalent to disco_apply(X, w_loc) -> z ; disco_cov_masked(X, mask_w, z, z, 1, M+K-1).
+ * X [R][K][T][F][M], mask_w [R][K][T][F], w_loc [R][K][F][M]; z_out [R][K][T][F] or NULL;
+ * Rss, Rnn [R][K][F][P][P], P = M + K - 1 <= 8. */
+int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
+                          disco_c32* z_out, disco_c32* Rss, disco_c32* Rnn, disco_stream s);
+
+/* tango.py:369 + 382 + 445 in one pass over X: yf_k = w_glo,k^H [y_k ; z_j (j<k) ; z_j (j>k)] with z recomputed
+ * from w_loc.  Equivalent to disco_apply(X, w_loc) -> z ; disco_apply(X, z, w_glo, M+K-1).
+ * w_glo [R][K][F][P]; yf [R][K][T][F]; z_out [R][K][T][F] or NULL. */
+int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc, const disco_c32* w_glo,
+                            disco_c32* z_out, disco_c32* yf, disco_stream s);
 
 /* ---- whole path -------------------------------------------------------------------------------------- */
 

@@ -109,7 +109,7 @@ def oracle_cov(X, mask, Zs=None, Zn=None, mask_remote=True):
     for k in range(K):
         vs = [m[:, k] * X[:, k]]
         vn = [(1 - m[:, k]) * X[:, k]]
-        if Zs is not None:
+        if Zs is not None and K > 1:
             others = [j for j in range(K) if j != k]
             gs = m[:, k] if mask_remote else 1.0
             gn = (1 - m[:, k]) if mask_remote else 1.0
@@ -169,6 +169,41 @@ def check_cov_solve_apply(make_engine, R=2, K=2, M=2, L=2560, n_fft=512, seed=3,
     return errs
 
 
+def check_step2_fused(make_engine, R=2, K=4, M=4, L=4096, n_fft=512, seed=5):
+    """The in-register z exchange kernels against the staged kernels they replace (same inputs -> same sums up to
+    accumulation order) and against the float64 restatement."""
+    rng = np.random.default_rng(seed)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    T, F = eng.T, eng.F
+    X, mask = _rand_stft_scene(rng, R, K, M, T, F)
+    P = M + K - 1
+    w_loc = (rng.standard_normal((R, K, F, M)) + 1j * rng.standard_normal((R, K, F, M))).astype(np.complex64) * 0.3
+    w_glo = (rng.standard_normal((R, K, F, P)) + 1j * rng.standard_normal((R, K, F, P))).astype(np.complex64) * 0.3
+    z_ref = np.einsum('rkfm,rktfm->rktf', w_loc.conj().astype(np.complex128), X.astype(np.complex128))
+    Rss, Rnn, z = eng.step2_cov_fused(X, mask, w_loc, want_z=True)
+    errs = {'z': relerr(z.numpy(), z_ref)}
+    assert errs['z'] < 2e-6, errs
+    rs, rn = oracle_cov(X, mask, z_ref, z_ref, True)
+    errs['cov2'] = max(relerr(Rss.numpy(), rs), relerr(Rnn.numpy(), rn))
+    assert errs['cov2'] < 5e-6, errs
+    if K > 1:
+        zs = eng.apply(X, w_loc)
+        Rss_s, Rnn_s = eng.cov_masked(X, mask, zs, zs, mask_remote=True)
+        errs['cov2_vs_staged'] = max(relerr(Rss.numpy(), Rss_s.numpy()), relerr(Rnn.numpy(), Rnn_s.numpy()))
+        assert errs['cov2_vs_staged'] < 5e-6, errs
+    yf, z2 = eng.step2_apply_fused(X, w_loc, w_glo, want_z=True)
+    ext = []
+    for k in range(K):
+        others = [j for j in range(K) if j != k]
+        ext.append(np.concatenate([X[:, k].astype(np.complex128)] + [z_ref[:, j, :, :, None] for j in others], axis=-1))
+    ext = np.stack(ext, axis=1)
+    yf_ref = np.einsum('rkfp,rktfp->rktf', w_glo.conj().astype(np.complex128), ext)
+    errs['yf'] = relerr(yf.numpy(), yf_ref)
+    errs['z2'] = relerr(z2.numpy(), z_ref)
+    assert errs['yf'] < 2e-6 and errs['z2'] < 2e-6, errs
+    return errs
+
+
 def check_solver_vs_reference_golden(make_engine, golden_dir):
     """HIP solver against intern_filter outputs of the REFERENCE'S OWN CODE (tests/golden/intern_filter_ref.npz)."""
     import os
@@ -188,11 +223,11 @@ def check_solver_vs_reference_golden(make_engine, golden_dir):
     return worst
 
 
-def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-4, ref_tuple=None):
+def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-4, staged_step2=False):
     """Whole path through the C ABI vs the float64 oracle.  y, s, n: (R, K, M, L) float32.
     Returns the per-output worst relative errors."""
     R, K, M, L = y.shape
-    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask, staged_step2=staged_step2)
     T, F = eng.T, eng.F
     m_dev = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F)
     out, z, yf = eng.tango_enhance(y, m_dev)

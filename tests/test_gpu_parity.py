@@ -52,6 +52,11 @@ def test_cov_solve_apply(make_engine, R, K, M, same_z, mask_remote):
     pc.check_cov_solve_apply(make_engine, R=R, K=K, M=M, L=16000, same_z=same_z, mask_remote=mask_remote)
 
 
+@pytest.mark.parametrize('R,K,M', [(3, 4, 4), (2, 2, 2), (2, 3, 2), (2, 1, 3), (1, 5, 4), (2, 8, 1), (2, 2, 7)])
+def test_step2_fused(make_engine, R, K, M):
+    pc.check_step2_fused(make_engine, R=R, K=K, M=M, L=16000)
+
+
 def test_solver_vs_reference_golden(make_engine, golden_dir):
     pc.check_solver_vs_reference_golden(make_engine, golden_dir)
 
@@ -85,12 +90,14 @@ def test_solver_degenerate_inputs(make_engine):
     assert np.all(np.isfinite(w.numpy().view(np.float32))) and np.abs(w.numpy()).max() < 1e-12
 
 
-@pytest.mark.parametrize('K,M,L,n_fft', [(4, 4, 160000, 512), (1, 4, 160000, 512), (2, 3, 20000, 512), (2, 2, 40000, 1024)])
-def test_tango_end_to_end_vs_oracle(make_engine, K, M, L, n_fft):
-    """Full path on synthetic rooms (SURVEY 8d generator) vs the float64 oracle; bar: 1e-4 relative."""
+@pytest.mark.parametrize('K,M,L,n_fft,staged', [(4, 4, 160000, 512, False), (4, 4, 160000, 512, True), (1, 4, 160000, 512, False),
+                                                (2, 3, 20000, 512, False), (2, 2, 40000, 1024, False), (3, 2, 30000, 512, True)])
+def test_tango_end_to_end_vs_oracle(make_engine, K, M, L, n_fft, staged):
+    """Full path on synthetic rooms (SURVEY 8d generator) vs the float64 oracle; bar: 1e-4 relative.
+    staged=False: step 2 on the in-register z exchange (default); True: z materialised, staged kernels."""
     y, s, n = synth.make_rooms_numpy(2, K=K, M=M, L=L)
-    errs = pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4)
-    print(K, M, L, n_fft, errs)
+    errs = pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, staged_step2=staged)
+    print(K, M, L, n_fft, staged, errs)
 
 
 @pytest.mark.parametrize('scene', ['k2m2', 'k4m4'])

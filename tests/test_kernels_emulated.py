@@ -41,10 +41,16 @@ def test_emu_cov_solve_apply(make_engine, K, M, same_z, mask_remote):
     print(pc.check_cov_solve_apply(make_engine, R=1, K=K, M=M, L=2304, same_z=same_z, mask_remote=mask_remote))
 
 
+@pytest.mark.parametrize('K,M', [(4, 4), (2, 2), (3, 2), (1, 3)])
+def test_emu_step2_fused(make_engine, K, M):
+    print(pc.check_step2_fused(make_engine, R=1, K=K, M=M, L=2304))
+
+
 def test_emu_solver_vs_reference_golden(make_engine, golden_dir):
     print(pc.check_solver_vs_reference_golden(make_engine, golden_dir))
 
 
-def test_emu_tango_end_to_end(make_engine):
+@pytest.mark.parametrize('staged', [False, True])
+def test_emu_tango_end_to_end(make_engine, staged):
     y, s, n = synth.make_rooms_numpy(1, K=2, M=2, L=8192)
-    print(pc.check_tango_end_to_end(make_engine, y, s, n))
+    print(pc.check_tango_end_to_end(make_engine, y, s, n, staged_step2=staged))
