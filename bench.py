@@ -37,6 +37,7 @@ def kernel_alg_bytes(M, K, F, H):
     return {
         'mask_oracle': 2 * H * 4 + F * 4,                     # s_ref, n_ref hop samples in, mask out
         'stft': M * H * 4 + M * F * 8,                        # hop samples of M mics in, M*F bins out
+        'stft_cov1': M * H * 4 + M * F * 8 + F * 4,           # samples + mask in, X out (covariances amortised over T)
         'cov1': M * F * 8 + F * 4,                            # X + mask in (covariances: amortised over T)
         'apply1': M * F * 8 + F * 8,                          # X in, z out
         'cov2': M * F * 8 + F * 4 + (K - 1) * F * 8,          # X + mask + remote z in
@@ -153,8 +154,7 @@ def main():
         p = lambda t: t.data_ptr()
         calls = [
             ('mask_oracle', lambda: lib.disco_mask_oracle(eng.ctx, p(s_ref), p(n_ref), G, p(mask), None)),
-            ('stft', lambda: lib.disco_stft(eng.ctx, p(y), G, M, p(X), None)),
-            ('cov1', lambda: lib.disco_cov_masked(eng.ctx, p(X), p(mask), None, None, 0, M, p(Rss), p(Rnn), None)),
+            ('stft_cov1', lambda: lib.disco_stft_cov_fused(eng.ctx, p(y), p(mask), p(X), p(Rss), p(Rnn), None)),
             ('solve1', lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, M, 1.0, p(w), None, None)),
             ('apply1', lambda: lib.disco_apply(eng.ctx, p(X), None, p(w), M, 1, p(z), None)),
         ]

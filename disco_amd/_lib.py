@@ -47,6 +47,7 @@ PROTOTYPES = {
     'disco_gevd_mwf_r1': (_int, [_vp, _vp, _vp, _i64, _int, _f, _vp, _vp, _vp]),
     'disco_apply': (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     'disco_noise_residual': (_int, [_vp, _vp, _vp, _vp, _vp]),
+    'disco_stft_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_apply_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_tango_enhance': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

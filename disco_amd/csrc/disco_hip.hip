@@ -431,6 +431,76 @@ extern "C" int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const di
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// STFT + step-1 covariance in one pass
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, const float* mask, c32* X, float4* part,
+                            const float* win, const c32* tw, int L, int T, int pad_mode, int chunks) {
+    const dim3 block(64 * STFT_WAVES);
+    switch (M) {
+#define C_(M_)                                                                                                          \
+    case M_:                                                                                                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
+                           chunks);                                                                                     \
+        return true;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6)
+#undef C_
+    }
+    if constexpr (N == 512) {          // the 1024-point spectrum tile of 7-8 mics does not fit the 160 KiB LDS
+        switch (M) {
+#define C_(M_)                                                                                                          \
+    case M_:                                                                                                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
+                           chunks);                                                                                     \
+        return true;
+            C_(7) C_(8)
+#undef C_
+        }
+    }
+    return false;
+}
+
+static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs, const disco_c32* Zn,
+                        int mask_remote, int P, int* chunks_out, disco_stream s);
+
+static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s) {
+    if (!y || !mask_z || !X) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics;
+    if (M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: more than 8 mics per node");
+    if (c.n_fft == 1024 && M > 6) {        // staged form of the same two operations
+        int rc0 = disco_stft(ctx, y, (int64_t)c.rooms * c.nodes, M, X, s);
+        if (rc0) return rc0;
+        return cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s);
+    }
+    const int chunks = (ctx->T + STFT_WAVES * SC_RUNW - 1) / (STFT_WAVES * SC_RUNW);
+    const long long G = (long long)c.rooms * c.nodes;
+    const int NP = M * (M + 1) / 2;
+    int rc = ensure_scratch(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
+    if (rc) return rc;
+    if (G * chunks > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: batch too large");
+    const dim3 grid((unsigned)(G * chunks));
+    const bool ok = c.n_fft == 512
+        ? launch_stft_cov<512>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
+                               ctx->T, c.pad_mode, chunks)
+        : launch_stft_cov<1024>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
+                                ctx->T, c.pad_mode, chunks);
+    if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: unsupported mic count");
+    *chunks_out = chunks;
+    return check_launch(ctx, "k_stft_cov");
+}
+
+extern "C" int disco_stft_cov_fused(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, disco_c32* Rss,
+                                    disco_c32* Rnn, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
+    int chunks = 1;
+    int rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s);
+    if (rc) return rc;
+    return cov_finalize(ctx, chunks, ctx->cfg.mics, Rss, Rnn, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // step 2 with the in-register z exchange
 // ---------------------------------------------------------------------------------------------------------
 static int step2_chunks(const disco_ctx* ctx, int tiles_plus_1) {
@@ -631,8 +701,7 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
     const int M = c.mics, P2 = c.mics + c.nodes - 1;
     int rc;
     int chunks = 1;
-    if ((rc = disco_stft(ctx, y, G, M, X, s))) return rc;
-    if ((rc = cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, &chunks, s))) return rc;
+    if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
     if ((rc = solve_from_partials(ctx, chunks, M, w_loc, s))) return rc;
     if ((rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s))) return rc;
     if ((rc = solve_from_partials(ctx, chunks, P2, w_glo, s))) return rc;

@@ -9,6 +9,7 @@
 // contiguous bytes per wave store.
 #pragma once
 #include "fft.h"
+#include "k_cov.h"
 
 namespace disco {
 
@@ -294,6 +295,192 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_istft(const c32* __restrict
             if (wss > 1.17549435e-38f) val /= wss;
             o[pos] = val;
         }
+    }
+}
+
+}  // namespace disco
+
+namespace disco {
+
+// ---- STFT + step-1 covariance in one pass over the samples ---------------------------------------------------
+// tango.py:335 + 357-364: the spectra are needed twice right away (stored for step 2, and reduced into the local
+// covariances), so the 4 waves of a workgroup stream 4 interleaved runs of frames of one node, park each
+// frame's M-channel spectrum in an LDS tile, and after a barrier the workgroup switches to one-thread-per-bin:
+// every thread copies its bin's M-vector to X (coalesced 8*M*64-byte wave stores) and folds it into the
+// P(P+1)/2 covariance accumulators it keeps in registers for the whole run.  Saves the separate covariance
+// pass over X (8*M*F bytes per node-frame).
+constexpr int SC_RUNW = 20;              // frames per wave per workgroup (a workgroup covers 4 * SC_RUNW frames)
+
+template <int N, int CHP>
+struct alignas(16) StftCovShared {
+    c32 buf[STFT_WAVES][fft_buf_len<N>()];
+    c32 tile[STFT_WAVES][N / 2 + 1][2 * CHP];
+};
+
+template <int N, int M>
+__global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
+                                                               c32* __restrict__ X, float4* __restrict__ part,
+                                                               const float* __restrict__ win, const c32* __restrict__ tw,
+                                                               int L, int T, int pad_mode, int chunks) {
+    static_assert(STFT_WAVES == 4, "one bin per thread needs 4 waves for 256 bins");
+    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, CHP = (M + 1) / 2, MP = 2 * CHP;
+    constexpr int NP = M * (M + 1) / 2;
+    constexpr int BPT = (F - 1) / 256;             // bins per thread: 1 (N = 512) or 2 (N = 1024)
+    __shared__ StftCovShared<N, CHP> sh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long g = blockIdx.x / chunks;
+    const int c = (int)(blockIdx.x % chunks);
+    const int tb = c * STFT_WAVES * SC_RUNW;
+    const int ts = tb + wave * SC_RUNW;
+    const int te = min(T, ts + SC_RUNW);
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
+    float w[E];
+    load_window<N>(w, win, lane);
+    const float* xa[CHP];
+    const float* xb[CHP];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) {
+        xa[p] = x + (g * M + 2 * p) * (long long)L;
+        xb[p] = (2 * p + 1 < M) ? x + (g * M + 2 * p + 1) * (long long)L : nullptr;
+    }
+    c32 raw[CHP][E];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) {
+        if (ts < te) load_frame_slots<N, 0, E>(raw[p], xa[p], xb[p], ts, L, pad_mode, lane);
+        else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) raw[p][e] = make_float2(0.f, 0.f);
+        }
+    }
+    c32 acc_s[BPT][NP], acc_n[BPT][NP];
+#pragma unroll
+    for (int b = 0; b < BPT; ++b)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) acc_s[b][q] = acc_n[b][q] = make_float2(0.f, 0.f);
+    // Nyquist bin: thread (q, which) with tid < 2*NP owns one complex entry of Rss (which = 0) or Rnn (1)
+    c32 acc_ny = make_float2(0.f, 0.f);
+    int ny_i = 0, ny_j = 0;
+    {
+        int q = tid >> 1, i = 0;
+        while (i < M - 1 && q >= M - i) {
+            q -= M - i;
+            ++i;
+        }
+        ny_i = i;
+        ny_j = i + q;
+    }
+    const float* mg = mask + g * T * (long long)F;
+    for (int it = 0; it < SC_RUNW; ++it) {
+        const int t = ts + it;
+        const bool valid = t < te;
+        // masks of the 4 frames this thread will reduce after the barrier (requested early)
+        float mv[STFT_WAVES][BPT], mny[STFT_WAVES];
+#pragma unroll
+        for (int ww = 0; ww < STFT_WAVES; ++ww) {
+            const int t2 = tb + ww * SC_RUNW + it;
+            const bool ok = t2 < min(T, tb + (ww + 1) * SC_RUNW);
+#pragma unroll
+            for (int b = 0; b < BPT; ++b) mv[ww][b] = ok ? mg[(long long)t2 * F + tid + 256 * b] : 0.f;
+            mny[ww] = (ok && tid < 2 * NP) ? mg[(long long)t2 * F + F - 1] : 0.f;
+        }
+        c32 nxt[CHP][EH];
+#pragma unroll
+        for (int p = 0; p < CHP; ++p) {
+            if (t + 1 < te) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], t + 1, L, pad_mode, lane);
+            else {
+#pragma unroll
+                for (int e = 0; e < EH; ++e) nxt[p][e] = make_float2(0.f, 0.f);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int p = 0; p < CHP; ++p) {
+                c32 v[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = make_float2(raw[p][e].x * w[e], raw[p][e].y * w[e]);
+                fft_wave<N>(v, wtw, sh.buf[wave], lane);
+                rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
+                    *reinterpret_cast<float4*>(&sh.tile[wave][f][2 * p]) = make_float4(a.x, a.y, b.x, b.y);
+                });
+            }
+        }
+        __syncthreads();
+        // ---- one thread per bin: copy out + reduce the (up to) 4 frames of this iteration
+#pragma unroll
+        for (int ww = 0; ww < STFT_WAVES; ++ww) {
+            const int t2 = tb + ww * SC_RUNW + it;
+            if (t2 < min(T, tb + (ww + 1) * SC_RUNW)) {          // workgroup-uniform
+                c32* Xo = X + ((g * T + t2) * (long long)F) * M;
+#pragma unroll
+                for (int b = 0; b < BPT; ++b) {
+                    const int f = tid + 256 * b;
+                    c32 xv[MP];
+#pragma unroll
+                    for (int p = 0; p < CHP; ++p) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(&sh.tile[ww][f][2 * p]);
+                        xv[2 * p] = make_float2(q4.x, q4.y);
+                        xv[2 * p + 1] = make_float2(q4.z, q4.w);
+                    }
+                    if ((M & 1) == 0) {
+#pragma unroll
+                        for (int p = 0; p < CHP; ++p)
+                            reinterpret_cast<float4*>(Xo + (long long)f * M)[p] =
+                                make_float4(xv[2 * p].x, xv[2 * p].y, xv[2 * p + 1].x, xv[2 * p + 1].y);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < M; ++i) Xo[(long long)f * M + i] = xv[i];
+                    }
+                    const float m = mv[ww][b], mc = 1.f - m;
+                    c32 vs[M], vn[M];
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        vs[i] = make_float2(m * xv[i].x, m * xv[i].y);
+                        vn[i] = make_float2(mc * xv[i].x, mc * xv[i].y);
+                    }
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+#pragma unroll
+                        for (int j = i; j < M; ++j) {
+                            const int q = tri_index<M>(i, j);
+                            acc_s[b][q].x = fmaf(vs[i].x, vs[j].x, fmaf(vs[i].y, vs[j].y, acc_s[b][q].x));
+                            acc_n[b][q].x = fmaf(vn[i].x, vn[j].x, fmaf(vn[i].y, vn[j].y, acc_n[b][q].x));
+                            if (j != i) {
+                                acc_s[b][q].y = fmaf(vs[i].y, vs[j].x, fmaf(-vs[i].x, vs[j].y, acc_s[b][q].y));
+                                acc_n[b][q].y = fmaf(vn[i].y, vn[j].x, fmaf(-vn[i].x, vn[j].y, acc_n[b][q].y));
+                            }
+                        }
+                    }
+                }
+                // Nyquist bin
+                if (tid < M) Xo[(long long)(F - 1) * M + tid] = sh.tile[ww][F - 1][tid];
+                if (tid < 2 * NP) {
+                    const float m = (tid & 1) ? 1.f - mny[ww] : mny[ww];
+                    const c32 a = sh.tile[ww][F - 1][ny_i], b2 = sh.tile[ww][F - 1][ny_j];
+                    const float m2 = m * m;
+                    acc_ny.x = fmaf(m2, a.x * b2.x + a.y * b2.y, acc_ny.x);
+                    if (ny_i != ny_j) acc_ny.y = fmaf(m2, a.y * b2.x - a.x * b2.y, acc_ny.y);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < CHP; ++p)
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                raw[p][e] = raw[p][e + EH];
+                raw[p][e + EH] = nxt[p][e];
+            }
+    }
+    float4* o = part + ((g * chunks + c) * F) * (long long)NP;
+#pragma unroll
+    for (int b = 0; b < BPT; ++b)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            o[(long long)(tid + 256 * b) * NP + q] = make_float4(acc_s[b][q].x, acc_s[b][q].y, acc_n[b][q].x, acc_n[b][q].y);
+    if (tid < 2 * NP) {
+        float2* o2 = reinterpret_cast<float2*>(o + (long long)(F - 1) * NP + (tid >> 1));
+        o2[tid & 1] = acc_ny;
     }
 }
 

@@ -202,6 +202,16 @@ class Engine:
         self._chk(self.lib.disco_noise_residual(self.ctx, px, pz, zn.ptr, self.stream))
         return zn
 
+    def stft_cov_fused(self, y, mask_z):
+        """y (R,K,M,L), mask_z (R,K,T,F) -> X (R,K,T,F,M), Rss, Rnn (R,K,F,M,M) in one pass over the samples."""
+        py, ky = self.to_device(y, np.float32)
+        pm, km = self.to_device(mask_z, np.float32)
+        X = self.empty((self.R, self.K, self.T, self.F, self.M), np.complex64)
+        Rss = self.empty((self.R, self.K, self.F, self.M, self.M), np.complex64)
+        Rnn = self.empty((self.R, self.K, self.F, self.M, self.M), np.complex64)
+        self._chk(self.lib.disco_stft_cov_fused(self.ctx, py, pm, X.ptr, Rss.ptr, Rnn.ptr, self.stream))
+        return X, Rss, Rnn
+
     def step2_cov_fused(self, X, mask_w, w_loc, want_z=True):
         """Fused apply-1 + in-register z exchange + step-2 covariance -> Rss, Rnn (R,K,F,P,P)[, z (R,K,T,F)]."""
         P = self.M + self.K - 1

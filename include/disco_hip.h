@@ -140,6 +140,12 @@ int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const di
 /* zn = Y[ref_mic] - z_y -- tango.py:376.  X [R][K][T][F][M], z/zn [R][K][T][F]. */
 int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const disco_c32* z, disco_c32* zn, disco_stream s);
 
+/* STFT and step-1 covariance in one pass over the samples (tango.py:335 + 357-364): equivalent to
+ * disco_stft(y, R*K, M) -> X ; disco_cov_masked(X, mask_z, NULL, NULL, 0, M) without re-reading X.
+ * y [R][K][M][L], mask_z [R][K][T][F] -> X [R][K][T][F][M], Rss, Rnn [R][K][F][M][M]. */
+int disco_stft_cov_fused(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X,
+                         disco_c32* Rss, disco_c32* Rnn, disco_stream s);
+
 /* ---- step 2 with the z exchange in registers (all K nodes of a room on this GPU, mask_for_z = 'local') ------ */
 
 /* tango.py:369 + 382-386 + 433-440 in one pass over X: every node's z_k = w_loc,k^H y_k is formed on the fly,

@@ -169,6 +169,25 @@ def check_cov_solve_apply(make_engine, R=2, K=2, M=2, L=2560, n_fft=512, seed=3,
     return errs
 
 
+def check_stft_cov_fused(make_engine, R=2, K=2, M=4, L=30000, n_fft=512, seed=6):
+    """STFT + step-1 covariance in one pass vs the two staged kernels it replaces."""
+    rng = np.random.default_rng(seed)
+    y = rng.standard_normal((R, K, M, L)).astype(np.float32)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    mask = rng.uniform(0.05, 0.95, (R, K, eng.T, eng.F)).astype(np.float32)
+    X, Rss, Rnn = eng.stft_cov_fused(y, mask)
+    Xs = eng.stft(y.reshape(R * K, M, L)).reshape(R, K, eng.T, eng.F, M)
+    # same algorithm; hipcc may contract mul+add into fma differently in the two kernels, so not bit-for-bit
+    assert maxrel(X.numpy(), Xs.numpy()) < 1e-6
+    rs, rn = oracle_cov(Xs.numpy(), mask)
+    e = max(relerr(Rss.numpy(), rs), relerr(Rnn.numpy(), rn))
+    assert e < 5e-6, e
+    Rss_s, Rnn_s = eng.cov_masked(Xs, mask)
+    e2 = max(relerr(Rss.numpy(), Rss_s.numpy()), relerr(Rnn.numpy(), Rnn_s.numpy()))
+    assert e2 < 5e-6, e2
+    return e, e2
+
+
 def check_step2_fused(make_engine, R=2, K=4, M=4, L=4096, n_fft=512, seed=5):
     """The in-register z exchange kernels against the staged kernels they replace (same inputs -> same sums up to
     accumulation order) and against the float64 restatement."""

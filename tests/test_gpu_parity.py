@@ -52,6 +52,12 @@ def test_cov_solve_apply(make_engine, R, K, M, same_z, mask_remote):
     pc.check_cov_solve_apply(make_engine, R=R, K=K, M=M, L=16000, same_z=same_z, mask_remote=mask_remote)
 
 
+@pytest.mark.parametrize('R,K,M,L,n_fft', [(3, 4, 4, 160000, 512), (2, 2, 3, 30000, 512), (2, 1, 8, 20000, 512), (2, 2, 2, 50000, 1024),
+                                          (1, 1, 1, 5000, 512)])
+def test_stft_cov_fused(make_engine, R, K, M, L, n_fft):
+    pc.check_stft_cov_fused(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft)
+
+
 @pytest.mark.parametrize('R,K,M', [(3, 4, 4), (2, 2, 2), (2, 3, 2), (2, 1, 3), (1, 5, 4), (2, 8, 1), (2, 2, 7)])
 def test_step2_fused(make_engine, R, K, M):
     pc.check_step2_fused(make_engine, R=R, K=K, M=M, L=16000)

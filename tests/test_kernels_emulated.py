@@ -41,6 +41,11 @@ def test_emu_cov_solve_apply(make_engine, K, M, same_z, mask_remote):
     print(pc.check_cov_solve_apply(make_engine, R=1, K=K, M=M, L=2304, same_z=same_z, mask_remote=mask_remote))
 
 
+@pytest.mark.parametrize('K,M,L,n_fft', [(1, 4, 23000, 512), (2, 3, 6000, 512), (1, 2, 9000, 1024)])
+def test_emu_stft_cov_fused(make_engine, K, M, L, n_fft):
+    print(pc.check_stft_cov_fused(make_engine, R=1, K=K, M=M, L=L, n_fft=n_fft))
+
+
 @pytest.mark.parametrize('K,M', [(4, 4), (2, 2), (3, 2), (1, 3)])
 def test_emu_step2_fused(make_engine, K, M):
     print(pc.check_step2_fused(make_engine, R=1, K=K, M=M, L=2304))

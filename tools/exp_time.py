@@ -42,6 +42,7 @@ calls = {
  'solve2': lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, P2, 1.0, p(w), None, None),
  'apply2': lambda: lib.disco_apply(eng.ctx, p(X), p(z), p(w), P2, 1, p(yf), None),
  'istft': lambda: lib.disco_istft(eng.ctx, p(yf), G, p(out), None),
+ 'stftcov': lambda: lib.disco_stft_cov_fused(eng.ctx, p(y), p(mask), p(X), p(Rss), p(Rnn), None),
  's2cov': lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), None, p(Rss), p(Rnn), None),
  's2cov_z': lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), p(z), p(Rss), p(Rnn), None),
  's2apply': lambda: lib.disco_step2_apply_fused(eng.ctx, p(X), p(w), p(w), None, p(yf), None),
