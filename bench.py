@@ -78,6 +78,7 @@ def main():
     ap.add_argument('--n-fft', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
+    ap.add_argument('--pmc-calibrate', action='store_true', help='also run a 4 GiB device copy (known bytes) for PMC calibration')
     args = ap.parse_args()
 
     import numpy as np
@@ -85,9 +86,8 @@ def main():
     from disco_amd import _lib, synth
     from disco_amd.engine import Engine
 
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    from disco_amd import dist as dd
+    rank, world, local_rank = dd.env_rank_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE {world}')
     if not torch.cuda.is_available():
@@ -95,9 +95,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        dist = dd.init('nccl', rank, world, device=dev)          # RCCL; used for the timing contract only
 
     R, K, M, Ls, N = args.rooms, args.nodes, args.mics, args.length, args.n_fft
     H, F = N // 2, N // 2 + 1
@@ -107,7 +105,8 @@ def main():
     assert torch.cuda.current_stream().cuda_stream == 0, 'bench times the null stream the library launches on'
 
     # synthetic rooms, generated on the GPU (SURVEY 8d recipe); rank r owns rooms [r*R, (r+1)*R)
-    y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, Ls, first_room=rank * R, device=dev, ref_only_sn=True)
+    first_room, _ = dd.room_range(rank, world, R)
+    y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, Ls, first_room=first_room, device=dev, ref_only_sn=True)
     mask = torch.empty((R, K, T, F), dtype=torch.float32, device=dev)
     out = torch.empty((R, K, Ls), dtype=torch.float32, device=dev)
     ws = torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
@@ -123,6 +122,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_calibrate:
+        src = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)                      # 4 GiB read + 4 GiB written by one elementwise copy kernel
+        torch.cuda.synchronize()
+        del src, dst
     for _ in range(args.warmup):
         step()
     barrier()
@@ -131,14 +136,9 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    value, dt = dd.whole_job_throughput(R * K * T * args.steps, dt, world, device=dev)
     assert bool(torch.isfinite(out).all())
     ms_per_step = 1e3 * dt / args.steps
-    node_frames = world * R * K * T
-    value = node_frames / (dt / args.steps)
     x_rt = (Ls / 16000.0) / (dt / args.steps)
 
     # ---- per-stage timing with HIP events on the launch stream (rank 0, N=1), for the roofline object
@@ -152,22 +152,25 @@ def main():
         Rnn = torch.empty_like(Rss)
         w = torch.empty((R, K, F, P2), dtype=torch.complex64, device=dev)
         p = lambda t: t.data_ptr()
+        w2 = torch.empty_like(w)
+        NUL = None
+        # exactly the launches disco_tango_enhance makes, one stage per call (covariances stay as partial sums in
+        # the context and feed the solver directly, as in the fused path)
         calls = [
             ('mask_oracle', lambda: lib.disco_mask_oracle(eng.ctx, p(s_ref), p(n_ref), G, p(mask), None)),
-            ('stft_cov1', lambda: lib.disco_stft_cov_fused(eng.ctx, p(y), p(mask), p(X), p(Rss), p(Rnn), None)),
-            ('solve1', lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, M, 1.0, p(w), None, None)),
-            ('apply1', lambda: lib.disco_apply(eng.ctx, p(X), None, p(w), M, 1, p(z), None)),
+            ('stft_cov1', lambda: lib.disco_stft_cov_fused(eng.ctx, p(y), p(mask), p(X), NUL, NUL, None)),
+            ('solve1', lambda: lib.disco_gevd_mwf_r1_pending(eng.ctx, 1.0, p(w), NUL, None)),
         ]
         if K > 1:
-            w2 = torch.empty_like(w)
-            calls = calls[:-1] + [          # step 2 on the on-chip z exchange replaces apply1 / cov2 / apply2
-                ('step2_cov', lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), None, p(Rss), p(Rnn), None)),
-                ('solve2', lambda: lib.disco_gevd_mwf_r1(eng.ctx, p(Rss), p(Rnn), G * F, P2, 1.0, p(w2), None, None)),
-                ('step2_apply', lambda: lib.disco_step2_apply_fused(eng.ctx, p(X), p(w), p(w2), None, p(yf), None)),
+            calls += [
+                ('step2_cov', lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), NUL, NUL, NUL, None)),
+                ('solve2', lambda: lib.disco_gevd_mwf_r1_pending(eng.ctx, 1.0, p(w2), NUL, None)),
+                ('step2_apply', lambda: lib.disco_step2_apply_fused(eng.ctx, p(X), p(w), p(w2), NUL, p(yf), None)),
                 ('istft', lambda: lib.disco_istft(eng.ctx, p(yf), G, p(out), None)),
             ]
         else:
-            calls += [('istft', lambda: lib.disco_istft(eng.ctx, p(z), G, p(out), None))]
+            calls += [('apply1', lambda: lib.disco_apply(eng.ctx, p(X), NUL, p(w), M, 1, p(z), None)),
+                      ('istft', lambda: lib.disco_istft(eng.ctx, p(z), G, p(out), None))]
         reps = max(2, min(args.steps, 5))
         acc = {name: 0.0 for name, _ in calls}
         for rep in range(reps + 1):

@@ -45,6 +45,7 @@ PROTOTYPES = {
     'disco_mask_oracle': (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     'disco_cov_masked': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     'disco_gevd_mwf_r1': (_int, [_vp, _vp, _vp, _i64, _int, _f, _vp, _vp, _vp]),
+    'disco_gevd_mwf_r1_pending': (_int, [_vp, _f, _vp, _vp, _vp]),
     'disco_apply': (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     'disco_noise_residual': (_int, [_vp, _vp, _vp, _vp, _vp]),
     'disco_stft_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

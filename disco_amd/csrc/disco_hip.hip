@@ -25,6 +25,7 @@ struct disco_ctx {
     size_t own_ws_bytes;
     void* scratch;            // covariance chunk partials (grown on demand)
     size_t scratch_bytes;
+    int pending_chunks, pending_P;   // geometry of the partials currently in `scratch` (0 = none)
     char err[512];
 };
 
@@ -96,6 +97,8 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->own_ws_bytes = 0;
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
+    ctx->pending_chunks = 0;
+    ctx->pending_P = 0;
     ctx->err[0] = 0;
     const int N = cfg->n_fft;
     std::vector<float> win(N);
@@ -340,6 +343,8 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
 #undef X_
     if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: unsupported (M, K) combination");
     *chunks_out = chunks;
+    ctx->pending_chunks = chunks;
+    ctx->pending_P = P;
     return check_launch(ctx, "k_cov");
 }
 
@@ -347,10 +352,10 @@ extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float*
                                 const disco_c32* Zn, int mask_remote, int P, disco_c32* Rss, disco_c32* Rnn,
                                 disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
-    if (!Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
+    if ((Rss == nullptr) != (Rnn == nullptr)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Rss and Rnn must both be given or both be NULL");
     int chunks = 1;
     int rc = cov_partials(ctx, X, mask, Zs, Zn, mask_remote, P, &chunks, s);
-    if (rc) return rc;
+    if (rc || !Rss) return rc;
     return cov_finalize(ctx, chunks, P, Rss, Rnn, s);
 }
 
@@ -391,6 +396,21 @@ extern "C" int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const dis
     src.chunks = 1;
     src.inv_T = 1.f;
     return solve_dispatch(ctx, src, n_prob, P, mu, w, t1, s);
+}
+
+extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w, disco_c32* t1, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!w) return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1_pending: null argument");
+    if (ctx->pending_chunks < 1 || !ctx->scratch)
+        return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1_pending: no covariance call has left partial sums in this context");
+    SolveSrc src;
+    src.Rss = nullptr;
+    src.Rnn = nullptr;
+    src.part = (const float4*)ctx->scratch;
+    src.F = ctx->F;
+    src.chunks = ctx->pending_chunks;
+    src.inv_T = 1.0f / (float)ctx->T;
+    return solve_dispatch(ctx, src, (int64_t)ctx->cfg.rooms * ctx->cfg.nodes * ctx->F, ctx->pending_P, mu, w, t1, s);
 }
 
 extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, int P, int conj_w,
@@ -487,16 +507,18 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
                                 ctx->T, c.pad_mode, chunks);
     if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: unsupported mic count");
     *chunks_out = chunks;
+    ctx->pending_chunks = chunks;
+    ctx->pending_P = M;
     return check_launch(ctx, "k_stft_cov");
 }
 
 extern "C" int disco_stft_cov_fused(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, disco_c32* Rss,
                                     disco_c32* Rnn, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
-    if (!Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
+    if ((Rss == nullptr) != (Rnn == nullptr)) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: Rss and Rnn must both be given or both be NULL");
     int chunks = 1;
     int rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s);
-    if (rc) return rc;
+    if (rc || !Rss) return rc;
     return cov_finalize(ctx, chunks, ctx->cfg.mics, Rss, Rnn, s);
 }
 
@@ -549,16 +571,18 @@ static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* m
 #undef X_
     if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_cov_fused: unsupported (M, K) combination");
     *chunks_out = chunks;
+    ctx->pending_chunks = chunks;
+    ctx->pending_P = P;
     return check_launch(ctx, "k_step2_cov_fused");
 }
 
 extern "C" int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
                                      disco_c32* z_out, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
-    if (!Rss || !Rnn) return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused: null argument");
+    if ((Rss == nullptr) != (Rnn == nullptr)) return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused: Rss and Rnn must both be given or both be NULL");
     int chunks = 1;
     int rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_out, &chunks, s);
-    if (rc) return rc;
+    if (rc || !Rss) return rc;
     return cov_finalize(ctx, chunks, ctx->cfg.mics + ctx->cfg.nodes - 1, Rss, Rnn, s);
 }
 

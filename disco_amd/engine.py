@@ -185,6 +185,14 @@ class Engine:
                                              t1.ptr if want_t1 else None, self.stream))
         return w, t1
 
+    def gevd_mwf_r1_pending(self, P, mu=None, want_t1=False):
+        """Solve straight from the partial sums the last covariance call left in the context."""
+        w = self.empty((self.R, self.K, self.F, P), np.complex64)
+        t1 = self.empty((self.R, self.K, self.F, P), np.complex64) if want_t1 else None
+        self._chk(self.lib.disco_gevd_mwf_r1_pending(self.ctx, self.cfg.mu if mu is None else mu, w.ptr,
+                                                     t1.ptr if want_t1 else None, self.stream))
+        return w, t1
+
     def apply(self, X, w, Z=None, conj=True):
         """out = w^H [X ; Z_-k] (conj=True) or w^T [...]   [tango.py:369-374, 445-450]"""
         P = self.M + (self.K - 1 if Z is not None else 0)

@@ -131,6 +131,12 @@ int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask,
 int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const disco_c32* Rnn, int64_t n_prob, int P,
                       float mu, disco_c32* w, disco_c32* t1, disco_stream s);
 
+/* The same solve, fed straight from the partial sums the LAST covariance call of this context left in its scratch
+ * (any of disco_cov_masked / disco_stft_cov_fused / disco_step2_cov_fused; those accept Rss == Rnn == NULL when the
+ * matrices themselves are not wanted).  Saves writing and re-reading the [R][K][F][P][P] matrices.
+ * w, t1: [R][K][F][P] with the P of that covariance call. */
+int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w, disco_c32* t1, disco_stream s);
+
 /* Filter-and-sum -- the np.inner loops tango.py:369-374 / 445-450:
  *   out[t,f] = sum_p c(w[f,p]) * v[p,t,f],  v = [X_k ; Z_j (j<k) ; Z_j (j>k)],  c = conj if conj_w else identity.
  * X [R][K][T][F][M]; Z [R][K][T][F] or NULL when P == M; w [R][K][F][P]; out [R][K][T][F]. */

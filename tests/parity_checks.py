@@ -133,10 +133,12 @@ def check_cov_solve_apply(make_engine, R=2, K=2, M=2, L=2560, n_fft=512, seed=3,
     rs, rn = oracle_cov(X, mask)
     errs['cov1'] = max(relerr(Rss.numpy(), rs), relerr(Rnn.numpy(), rn))
     assert errs['cov1'] < 5e-6, errs
+    wp, t1p = eng.gevd_mwf_r1_pending(M, want_t1=True)      # straight from the partial sums of the call above
     w, t1 = eng.gevd_mwf_r1(Rss, Rnn)
     w_ref, t1_ref, _ = mo.gevd_mwf_r1_hermitian(Rss.numpy(), Rnn.numpy(), 1.0)
     errs['solve1'] = max(relerr(w.numpy(), w_ref), relerr(t1.numpy(), t1_ref))
-    assert errs['solve1'] < 5e-6, errs
+    errs['solve1_pending'] = max(relerr(wp.numpy(), w_ref), relerr(t1p.numpy(), t1_ref))
+    assert errs['solve1'] < 5e-6 and errs['solve1_pending'] < 5e-6, errs
     z = eng.apply(X, w)
     z_ref = np.einsum('rkfm,rktfm->rktf', w.numpy().conj().astype(np.complex128), X.astype(np.complex128))
     errs['apply1'] = relerr(z.numpy(), z_ref)

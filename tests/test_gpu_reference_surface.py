@@ -1,0 +1,120 @@
+"""The reference's Python call surface re-implemented on the HIP engine: offline_tango, intern_filter,
+tf_mask, my_stft / my_istft -- checked against the reference's OWN outputs (tests/golden) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mwf_oracle as mo
+from oracle import stft_oracle as so
+from oracle import tango_oracle as to
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def test_offline_tango_signature_and_oracle_parity():
+    from disco_amd import synth
+    from disco_amd.speech_enhancement.tango import offline_tango
+    y, s, n, _ = synth.make_room_numpy(5, K=3, M=2, L=24000)
+    res = offline_tango(list(y), list(s), list(n), vads=['irm1', 'irm1'], mods=[None, None])
+    assert len(res) == 9 and all(len(r) == 3 for r in res)
+    o = to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+    ref = to.as_reference_tuple(o)
+    names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
+    for nm, got, want in zip(names, res, ref):
+        for k in range(3):
+            assert got[k].shape == want[k].shape == (257, 94)
+            tol = 2e-5 if 'mask' in nm else 1e-4
+            assert relerr(got[k], want[k]) < tol, (nm, k, relerr(got[k], want[k]))
+
+
+def test_offline_tango_mask_for_z_none():
+    from disco_amd import synth
+    from disco_amd.speech_enhancement.tango import offline_tango
+    y, s, n, _ = synth.make_room_numpy(6, K=2, M=2, L=20000)
+    res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mask_for_z=None)
+    o = to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], mask_for_z=None, precision='f64', solver='eigh')
+    for k in range(2):
+        assert relerr(res[0][k], o['yf'][k]) < 1e-4
+
+
+def test_get_z_signals_variant():
+    from disco_amd import synth
+    from disco_amd.speech_enhancement.get_z_signals import offline_tango
+    y, s, n, _ = synth.make_room_numpy(7, K=2, M=2, L=12000)
+    z_y, z_s, z_n, zn, masks_z = offline_tango(y, s, n, vads=['irm1', 'irm1'])
+    o = to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+    assert relerr(z_y[1], o['z_y'][1]) < 1e-4 and relerr(zn[0], o['zn'][0]) < 1e-4
+
+
+def test_offline_tango_vs_reference_golden(golden_dir):
+    """Against the reference's own offline_tango output (badly conditioned toy scene: see test_gpu_parity)."""
+    from disco_amd.speech_enhancement.tango import offline_tango
+    g = np.load(os.path.join(golden_dir, 'tango_ref_k2m2.npz'))
+    y = [g['y0'], g['y1']]
+    s = [g['s0'], g['s1']]
+    n = [g['n0'], g['n1']]
+    res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mods=[None, None])
+    for i, nm in enumerate(['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn']):
+        for k in range(2):
+            assert relerr(res[i][k], g[f'{nm}{k}']) < 1e-2, (nm, k)
+    for k in range(2):
+        assert np.abs(res[7][k] - g[f'masks_z{k}']).max() < 1e-3
+
+
+def test_offline_tango_errors():
+    from disco_amd.speech_enhancement.tango import offline_tango
+    y = np.zeros((2, 2, 4096), np.float32)
+    with pytest.raises(ValueError):
+        offline_tango(y, y, y, vads=['xyz1', 'irm1'])
+    with pytest.raises(NotImplementedError):
+        offline_tango([np.zeros((3, 4096)), np.zeros((2, 4096))], y, y, vads=['irm1', 'irm1'])
+
+
+def test_intern_filter_vs_reference_golden(golden_dir):
+    from disco_amd.se_utils.internal_formulas import intern_filter
+    g = np.load(os.path.join(golden_dir, 'intern_filter_ref.npz'))
+    for i in range(int(g['n_cases'])):
+        if str(g[f'c{i}_type']) != 'gevd':
+            continue
+        w, (t1, si) = intern_filter(g[f'c{i}_Rxx'], g[f'c{i}_Rnn'], mu=1, type='gevd', rank=1)
+        assert w.dtype == np.complex128 and si is None
+        assert relerr(w, g[f'c{i}_w']) < 2e-4 and relerr(t1, g[f'c{i}_t1']) < 2e-4
+    R = np.eye(3, dtype=np.complex64)
+    with pytest.raises(AttributeError):
+        intern_filter(R, R, type='nope')
+    with pytest.raises(TypeError):
+        intern_filter(R, R + 0.1, type='gevd')
+
+
+def test_tf_mask_vs_reference_golden(golden_dir):
+    from disco_amd.dnn.utils import tf_mask
+    g = np.load(os.path.join(golden_dir, 'tf_mask_ref.npz'))
+    for typ in ('irm1', 'irm2', 'iam1', 'iam2', 'ibm1'):
+        m = tf_mask(g['S'], g['N'], type=typ)
+        ref = g[typ]
+        ok = np.isfinite(ref)
+        if typ.startswith('ibm'):
+            assert m.dtype == bool and np.mean(m != ref) < 1e-2
+        else:
+            assert np.abs(m[ok] - ref[ok]).max() < 1e-5 * (1 + np.abs(ref[ok]).max())
+    with pytest.raises(ValueError):
+        tf_mask(g['S'], g['N'], type='xyz1')
+    with pytest.raises(AssertionError):
+        tf_mask(g['S'], g['N'][:-1], type='irm1')
+
+
+def test_my_stft_istft():
+    from disco_amd.math_utils import my_istft, my_stft
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(16000).astype(np.float32)
+    X = my_stft(x)
+    ref = so.stft(x, out_dtype=np.complex128)
+    assert X.shape == ref.shape == (257, 63) and X.dtype == np.complex64
+    assert np.abs(X - ref).max() / np.abs(ref).max() < 2e-6
+    xr = my_istft(X, 16000)
+    assert xr.shape == (16000,) and np.abs(xr - x).max() < 2e-5

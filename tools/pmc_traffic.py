@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc_raw.json (tools/pmc_extract.py) -> profiles/pmc_traffic.json: HBM bytes per launch of each
+disco kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+  * FETCH_SIZE and WRITE_SIZE come from SEPARATE rocprofv3 --pmc passes (TCC slots) and are in KiB;
+  * on gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read -> x2;
+  * WRITE_SIZE is taken x1.
+Both corrections were re-calibrated in the same runs on kernels whose traffic is known exactly:
+  torch abs() over a 1.28 GB tensor (FETCH x2 = bytes read, WRITE x1 = bytes written), and this repo's k_istft
+  (reads every spectrum once plus the 8/7 frame overlap; writes exactly R*K*L*4 bytes).
+Usage: tools/pmc_traffic.py gpurun_out/pmc_raw.json profiles/pmc_traffic.json"""
+import json
+import sys
+
+STAGE_OF = {'k_stft_cov<': 'stft_cov1', 'k_stft<': 'stft', 'k_mask_oracle<': 'mask_oracle', 'k_istft<': 'istft',
+            'k_step2_cov_fused<': 'step2_cov', 'k_step2_apply_fused<': 'step2_apply', 'k_cov<': 'cov', 'k_apply<': 'apply',
+            'k_gevd_mwf_r1<': 'solve'}
+
+raw = json.load(open(sys.argv[1]))
+out = {'_method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) on '
+                  '`bench.py --steps 1 --warmup 0 --no-stage-timing`; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024',
+       '_calibration': {}}
+for k, v in raw.items():
+    if k.startswith('_'):
+        continue
+    if 'AbsFunctor' in k:
+        out['_calibration']['torch_abs_1.28GB'] = {c: x['per_dispatch'] * 1024 for c, x in v.items()}
+    if 'disco::' not in k:
+        continue
+    name = k.replace('void disco::', '')
+    f = v.get('FETCH_SIZE', {}).get('per_dispatch')
+    w = v.get('WRITE_SIZE', {}).get('per_dispatch')
+    ent = {'kernel': name, 'fetch_size_KiB_raw': f, 'write_size_KiB_raw': w,
+           'hbm_read_bytes_per_launch': None if f is None else 2 * f * 1024,
+           'hbm_write_bytes_per_launch': None if w is None else w * 1024}
+    if f is not None and w is not None:
+        ent['hbm_bytes_per_launch'] = 2 * f * 1024 + w * 1024
+    stage = next((s for p, s in STAGE_OF.items() if name.startswith(p)), name)
+    if stage == 'solve':
+        stage = 'solve1' if '<4,' in name else 'solve2'
+    out[stage] = ent
+json.dump(out, open(sys.argv[2], 'w'), indent=1)
+print(json.dumps({k: (round(v['hbm_bytes_per_launch'] / 1e9, 2) if isinstance(v, dict) and 'hbm_bytes_per_launch' in v else None)
+                  for k, v in out.items() if not k.startswith('_')}))
