@@ -28,18 +28,25 @@ __device__ __forceinline__ c64 zadd(c64 a, c64 b) { return make_double2(a.x + b.
 __device__ __forceinline__ c64 zsub(c64 a, c64 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ c64 zscale(c64 a, double s) { return make_double2(a.x * s, a.y * s); }
 
-// reflect / zero padded sample fetch: p is the index into the un-padded signal of length L
+// Pin the point where a prefetched value must have landed: an empty asm that "modifies" the register makes hipcc
+// place the s_waitcnt for its load HERE instead of wherever register coalescing leaves the first real use
+// (typically the loop back-edge, i.e. after -- and therefore behind -- the iteration's stores).
+#ifndef DISCO_CONSUME
+#define DISCO_CONSUME(x) asm volatile("" : "+v"(x))
+#endif
+
+// The wave index as a PROVABLY wave-uniform value: anything derived from threadIdx is divergent to hipcc, which
+// then wraps every access guarded by a per-wave condition in exec-mask branches (one per load).
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// reflect / zero padded sample fetch, branch-free: p is the index into the un-padded signal of length L.
+// The load is unconditional (clamped index); out-of-range samples of constant padding are zeroed by a select.
 __device__ __forceinline__ float load_padded(const float* __restrict__ x, int p, int L, int pad_mode) {
-    if (p < 0) {
-        if (pad_mode != DISCO_PAD_REFLECT) return 0.f;
-        p = -p;
-    } else if (p >= L) {
-        if (pad_mode != DISCO_PAD_REFLECT) return 0.f;
-        p = 2 * (L - 1) - p;
-    }
-    // np.pad(reflect) needs L > n_fft/2; clamp keeps short inputs in bounds instead of faulting
-    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
-    return x[p];
+    const bool outside = (p < 0) || (p >= L);
+    int q = p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p);      // np.pad(mode='reflect')
+    q = q < 0 ? 0 : (q >= L ? L - 1 : q);                      // keeps inputs shorter than the window in bounds
+    const float v = x[q];
+    return (outside && pad_mode != DISCO_PAD_REFLECT) ? 0.f : v;
 }
 
 }  // namespace disco

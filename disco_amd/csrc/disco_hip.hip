@@ -303,7 +303,7 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     if (!X || !mask) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
     if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: P must be M or M + K - 1");
     if (KR > 0 && (!Zs || !Zn)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Zs/Zn required when P > M");
-    if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: P > 8 not supported yet");
+    if (P > CB_PMAX || M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: P > 16 or M > 8");
     const int chunks = cov_chunks(ctx);
     const long long G = (long long)c.rooms * c.nodes;
     const int NP = P * (P + 1) / 2;
@@ -341,7 +341,15 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     }
     DISCO_FOR_MKR(X_)
 #undef X_
-    if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: unsupported (M, K) combination");
+    if (!launched) {            // 9 <= P <= 16: pairs split over the waves of a workgroup
+        const int tiles = (ctx->F - 1 + 63) / 64;
+        const long long nblk = G * (tiles + 1) * chunks;
+        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
+        if (KR == 0 || same)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_big<true>), dim3((unsigned)nblk), dim3(64 * CB_S), 0, (hipStream_t)s, a, M, KR);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_big<false>), dim3((unsigned)nblk), dim3(64 * CB_S), 0, (hipStream_t)s, a, M, KR);
+    }
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
     ctx->pending_P = P;
@@ -421,7 +429,7 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     if (!X || !w || !out) return fail(ctx, DISCO_E_ARG, "disco_apply: null argument");
     if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_apply: P must be M or M + K - 1");
     if (KR > 0 && !Z) return fail(ctx, DISCO_E_ARG, "disco_apply: Z required when P > M");
-    if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_apply: P > 8 not supported yet");
+    if (P > CB_PMAX) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_apply: P > 16 not supported");
     const long long G = (long long)c.rooms * c.nodes;
     const long long TF = (long long)ctx->T * ctx->F;
     int bpn = (int)std::min<long long>((TF + 255) / 256, 64);
@@ -436,7 +444,9 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     }
     DISCO_FOR_MKR(X_)
 #undef X_
-    if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_apply: unsupported (M, K) combination");
+    if (!launched)
+        hipLaunchKernelGGL(k_apply_generic, grid, block, 0, (hipStream_t)s, (const c32*)X, (const c32*)Z, (const c32*)w,
+                           (c32*)out, M, KR, c.nodes, ctx->T, ctx->F, conj_w, bpn);
     return check_launch(ctx, "k_apply");
 }
 

@@ -42,6 +42,41 @@ __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const 
     }
 }
 
+// Run-time (M, K) form for the shapes outside the template table (P > 8): no register arrays, the filter is
+// re-read from L1 per element.
+__global__ __launch_bounds__(256) void k_apply_generic(const c32* __restrict__ X, const c32* __restrict__ Z,
+                                                        const c32* __restrict__ w, c32* __restrict__ out, int M, int KR,
+                                                        int K, int T, int F, int conj_w, int blocks_per_node) {
+    const int P = M + KR;
+    const long long g = blockIdx.x / blocks_per_node;
+    const int b = (int)(blockIdx.x % blocks_per_node);
+    const long long r = g / K;
+    const int k = (int)(g % K);
+    const long long TF = (long long)T * F;
+    const float sgn = conj_w ? -1.f : 1.f;
+    const c32* wg = w + g * F * (long long)P;
+    for (long long tf = (long long)b * blockDim.x + threadIdx.x; tf < TF; tf += (long long)blocks_per_node * blockDim.x) {
+        const int f = (int)(tf % F);
+        const c32* wf = wg + f * P;
+        const c32* xp = X + (g * TF + tf) * M;
+        float ar = 0.f, ai = 0.f;
+        for (int i = 0; i < M; ++i) {
+            const c32 x = xp[i];
+            const c32 ww = make_float2(wf[i].x, sgn * wf[i].y);
+            ar = fmaf(ww.x, x.x, fmaf(-ww.y, x.y, ar));
+            ai = fmaf(ww.x, x.y, fmaf(ww.y, x.x, ai));
+        }
+        for (int jj = 0; jj < KR; ++jj) {
+            const int j = jj < k ? jj : jj + 1;
+            const c32 x = Z[(r * K + j) * TF + tf];
+            const c32 ww = make_float2(wf[M + jj].x, sgn * wf[M + jj].y);
+            ar = fmaf(ww.x, x.x, fmaf(-ww.y, x.y, ar));
+            ai = fmaf(ww.x, x.y, fmaf(ww.y, x.x, ai));
+        }
+        out[g * TF + tf] = make_float2(ar, ai);
+    }
+}
+
 // zn = Y[ref] - z  (tango.py:376)
 __global__ void k_noise_residual(const c32* __restrict__ X, const c32* __restrict__ z, c32* __restrict__ zn,
                                  long long n, int M, int ref) {

@@ -113,6 +113,129 @@ __global__ __launch_bounds__(NT) void k_cov(CovArgs a) {
     }
 }
 
+// ---- 9 <= P <= 16 (e.g. 8 nodes x 8 mics: P = 15) ------------------------------------------------------------
+// The 2 * P(P+1)/2 accumulators no longer fit one thread, so a workgroup of CB_S waves shares a 64-bin tile: every
+// wave loads the same P-vector of its bin (the re-loads hit L1) and owns the pairs q with q % CB_S == wave.
+// M, KR are run-time values; all register arrays are indexed statically (loops unrolled to the maximum, guarded).
+constexpr int CB_S = 4;
+constexpr int CB_PMAX = 16;
+
+template <int SI, bool SAMEZ>
+__device__ __forceinline__ void cov_big_walk(const CovArgs& a, int M, int KR, long long g, int f, bool live, int t0, int t1,
+                                             int t_step, int t_off, c32* acc_s, c32* acc_n) {
+    const int K = a.K, T = a.T, F = a.F, P = M + KR;
+    const long long r = g / K;
+    const int k = (int)(g % K);
+    const c32* Xg = a.X + (g * T * (long long)F) * M;
+    const float* mg = a.mask + g * T * (long long)F;
+    for (int tu = t0; tu < t1; tu += t_step) {
+        const int t = tu + t_off;
+        const bool ok = live && t < t1;
+        const long long tf = (long long)(ok ? t : t0) * F + f;
+        const float m = ok ? mg[tf] : 0.f, mc = ok ? 1.f - m : 0.f;
+        const float gs = a.mask_remote ? m : (ok ? 1.f : 0.f), gn = a.mask_remote ? mc : (ok ? 1.f : 0.f);
+        c32 vs[CB_PMAX], vn[CB_PMAX];
+#pragma unroll
+        for (int i = 0; i < CB_PMAX; ++i) {
+            c32 xs = make_float2(0.f, 0.f), xn = make_float2(0.f, 0.f);
+            float ws = 0.f, wn = 0.f;
+            if (i < M) {
+                xs = xn = Xg[tf * M + i];
+                ws = m;
+                wn = mc;
+            } else if (i < P) {
+                const int jj = i - M;
+                const int j = jj < k ? jj : jj + 1;
+                const long long zo = ((r * K + j) * T) * (long long)F + tf;
+                xs = a.Zs[zo];
+                xn = SAMEZ ? xs : a.Zn[zo];
+                ws = gs;
+                wn = gn;
+            }
+            vs[i] = make_float2(ws * xs.x, ws * xs.y);
+            vn[i] = make_float2(wn * xn.x, wn * xn.y);
+        }
+        int q = 0, slot = 0;
+#pragma unroll
+        for (int i = 0; i < CB_PMAX; ++i) {
+#pragma unroll
+            for (int j = i; j < CB_PMAX; ++j, ++q) {
+                if (q % CB_S == SI) {                       // compile-time: this wave's share of the 136 (i, j) pairs
+                    if (j < P) {                            // run-time, wave-uniform
+                        acc_s[slot].x = fmaf(vs[i].x, vs[j].x, fmaf(vs[i].y, vs[j].y, acc_s[slot].x));
+                        acc_n[slot].x = fmaf(vn[i].x, vn[j].x, fmaf(vn[i].y, vn[j].y, acc_n[slot].x));
+                        if (j != i) {
+                            acc_s[slot].y = fmaf(vs[i].y, vs[j].x, fmaf(-vs[i].x, vs[j].y, acc_s[slot].y));
+                            acc_n[slot].y = fmaf(vn[i].y, vn[j].x, fmaf(-vn[i].x, vn[j].y, acc_n[slot].y));
+                        }
+                    }
+                    ++slot;
+                }
+            }
+        }
+    }
+}
+
+template <int SI, bool SAMEZ>
+__device__ __forceinline__ void cov_big_wave(const CovArgs& a, int M, int KR, long long g, int c, int tile, int lane) {
+    constexpr int NSLOT = (CB_PMAX * (CB_PMAX + 1) / 2 + CB_S - 1) / CB_S;
+    const int P = M + KR, NP = P * (P + 1) / 2;
+    const int nbin = a.F - 1, tiles = (nbin + 63) / 64;
+    const int t0 = (int)(((long long)a.T * c) / a.chunks), t1 = (int)(((long long)a.T * (c + 1)) / a.chunks);
+    c32 acc_s[NSLOT], acc_n[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) acc_s[s] = acc_n[s] = make_float2(0.f, 0.f);
+    const bool nyq = tile == tiles;
+    int f = nyq ? nbin : tile * 64 + lane;
+    const bool live = nyq || f < nbin;
+    if (f > nbin) f = nbin;
+    cov_big_walk<SI, SAMEZ>(a, M, KR, g, f, live, t0, t1, nyq ? 64 : 1, nyq ? lane : 0, acc_s, acc_n);
+    if (nyq) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                acc_s[s].x += __shfl_xor(acc_s[s].x, off);
+                acc_s[s].y += __shfl_xor(acc_s[s].y, off);
+                acc_n[s].x += __shfl_xor(acc_n[s].x, off);
+                acc_n[s].y += __shfl_xor(acc_n[s].y, off);
+            }
+    }
+    if (live && (!nyq || lane == 0)) {
+        // scatter this wave's slots to their packed upper-triangle positions of the RUN-TIME P
+        float4* o = a.part + (((g * a.chunks + c) * a.F) + f) * (long long)NP;
+        int q = 0, slot = 0;
+#pragma unroll
+        for (int i = 0; i < CB_PMAX; ++i) {
+#pragma unroll
+            for (int j = i; j < CB_PMAX; ++j, ++q) {
+                if (q % CB_S == SI) {
+                    if (j < P) o[i * P - (i * (i - 1)) / 2 + (j - i)] = make_float4(acc_s[slot].x, acc_s[slot].y, acc_n[slot].x, acc_n[slot].y);
+                    ++slot;
+                }
+            }
+        }
+    }
+}
+
+// grid = R*K * (tiles + 1) * chunks blocks of 64 * CB_S threads
+template <bool SAMEZ>
+__global__ __launch_bounds__(64 * CB_S) void k_cov_big(CovArgs a, int M, int KR) {
+    const int nbin = a.F - 1, tiles = (nbin + 63) / 64;
+    int bid = blockIdx.x;
+    const int c = bid % a.chunks;
+    bid /= a.chunks;
+    const int tile = bid % (tiles + 1);
+    const long long g = bid / (tiles + 1);
+    const int lane = threadIdx.x & 63;
+    switch (wave_id()) {
+        case 0: cov_big_wave<0, SAMEZ>(a, M, KR, g, c, tile, lane); break;
+        case 1: cov_big_wave<1, SAMEZ>(a, M, KR, g, c, tile, lane); break;
+        case 2: cov_big_wave<2, SAMEZ>(a, M, KR, g, c, tile, lane); break;
+        default: cov_big_wave<3, SAMEZ>(a, M, KR, g, c, tile, lane); break;
+    }
+}
+
 // part [n_gf/F][chunks][F][NP] -> Rss, Rnn [n_gf][P][P], mean over T, Hermitian mirror.
 __global__ void k_cov_finalize(const float4* __restrict__ part, c32* __restrict__ Rss, c32* __restrict__ Rnn,
                                long long n_gf, int F, int chunks, int P, float inv_T) {

@@ -75,7 +75,7 @@ template <int M, int K>
 __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
     constexpr int P = M + K - 1, NP = P * (P + 1) / 2, U = S2_U_COV;
     __shared__ c32 zbuf[2][U][K][64];
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = wave_id(), lane = threadIdx.x & 63;
     const Step2Geom gm = step2_geom(a, lane);
     const int T = a.T, F = a.F, f = gm.f;
     const long long g = gm.r * a.K + k;
@@ -95,10 +95,10 @@ __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
         for (int u = 0; u < U; ++u) {
             const int t = tu + u * gm.t_stride + gm.t_lane;
             const bool live = t < gm.t1;
-            const long long tf = (long long)(live ? t : gm.t0) * F + f;
+            const long long tf = (long long)(live ? t : gm.t1 - 1) * F + f;      // always a valid frame: loads stay unconditional
 #pragma unroll
-            for (int i = 0; i < M; ++i) xx[u][i] = live ? Xg[tf * M + i] : make_float2(0.f, 0.f);
-            mm[u] = live ? mg[tf] : 0.f;
+            for (int i = 0; i < M; ++i) xx[u][i] = Xg[tf * M + i];      // raw: consumed (and zeroed if !live) after the barrier
+            mm[u] = mg[tf];
         }
     };
     c32 x[U][M], xn[U][M];
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
         __syncthreads();             // one barrier per U frames; zbuf is double buffered, so none is needed after the reads
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float ms = m[u], mc = 1.f - m[u];
+            const bool live = tu + u * gm.t_stride + gm.t_lane < gm.t1;       // frames past the chunk were loaded clamped: weigh them 0
+            const float ms = live ? m[u] : 0.f, mc = live ? 1.f - m[u] : 0.f;
             c32 vs[P], vn[P];
 #pragma unroll
             for (int i = 0; i < M; ++i) {
@@ -175,7 +176,7 @@ template <int M, int K>
 __global__ __launch_bounds__(64 * K) void k_step2_apply_fused(Step2Args a) {
     constexpr int P = M + K - 1, U = S2_U_APPLY;
     __shared__ c32 zbuf[2][U][K][64];
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = wave_id(), lane = threadIdx.x & 63;
     const Step2Geom gm = step2_geom(a, lane);
     const int T = a.T, F = a.F, f = gm.f;
     const long long g = gm.r * a.K + k;
@@ -194,9 +195,12 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_fused(Step2Args a) {
         for (int u = 0; u < U; ++u) {
             const int t = tu + u * gm.t_stride + gm.t_lane;
             const bool live = t < gm.t1;
-            const long long tf = (long long)(live ? t : gm.t0) * F + f;
+            const long long tf = (long long)(live ? t : gm.t1 - 1) * F + f;      // always a valid frame: loads stay unconditional
 #pragma unroll
-            for (int i = 0; i < M; ++i) x[u][i] = live ? Xg[tf * M + i] : make_float2(0.f, 0.f);
+            for (int i = 0; i < M; ++i) {
+                const c32 v = Xg[tf * M + i];
+                x[u][i] = live ? v : make_float2(0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

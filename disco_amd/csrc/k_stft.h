@@ -35,6 +35,13 @@ __device__ __forceinline__ void load_window(float* w, const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < FftPlan<N>::E; ++e) w[e] = win[lane + 64 * e];
 }
+// (a, b) * (w, w) for a full channel pair, (a, b) * (w, 0) when the pair's second channel does not exist
+template <int N>
+__device__ __forceinline__ void apply_window(c32* v, const c32* raw, const float* w, bool has_b) {
+    const float sb = has_b ? 1.f : 0.f;
+#pragma unroll
+    for (int e = 0; e < FftPlan<N>::E; ++e) v[e] = make_float2(raw[e].x * w[e], raw[e].y * (w[e] * sb));
+}
 
 // Slots [E0, E1) of centre-padded frame t of the channel pair (xa, xb), un-windowed: v[e] = (a, b)[lane + 64 e].
 // With hop = N/2 the first half of frame t+1 is the second half of frame t, so a wave streaming consecutive
@@ -44,19 +51,22 @@ __device__ __forceinline__ void load_frame_slots(c32* v, const float* __restrict
                                                  int t, int L, int pad_mode, int lane) {
     constexpr int H = N / 2;
     const int p0 = t * H - N / 2;
-    const bool interior = (p0 + 64 * E0 >= 0) && (p0 + 64 * E1 <= L);
+    const bool interior = (p0 + 64 * E0 >= 0) && (p0 + 64 * E1 <= L);      // wave-uniform (t is)
+    // xb == xa for an odd channel count: the caller zeroes that half through the window (wb), so the loaded
+    // values are never touched here -- a prefetched half-window must stay un-consumed until after the stores of the
+    // current frame are issued (vmcnt is in-order: consuming a load early also waits for every older store).
+    if (interior) {
 #pragma unroll
-    for (int e = E0; e < E1; ++e) {
-        const int n = lane + 64 * e;
-        float a, b = 0.f;
-        if (interior) {
-            a = xa[p0 + n];
-            if (xb) b = xb[p0 + n];
-        } else {
-            a = load_padded(xa, p0 + n, L, pad_mode);
-            if (xb) b = load_padded(xb, p0 + n, L, pad_mode);
+        for (int e = E0; e < E1; ++e) {
+            const int n = lane + 64 * e;
+            v[e - E0] = make_float2(xa[p0 + n], xb[p0 + n]);
         }
-        v[e - E0] = make_float2(a, b);
+    } else {                                                               // first / last frames only
+#pragma unroll
+        for (int e = E0; e < E1; ++e) {
+            const int n = lane + 64 * e;
+            v[e - E0] = make_float2(load_padded(xa, p0 + n, L, pad_mode), load_padded(xb, p0 + n, L, pad_mode));
+        }
     }
 }
 
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restric
                                                            long long n_witems) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, NJ = E / 2 + 1, EH = E / 2;
     __shared__ StftShared<N> sh;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * STFT_WAVES + wave;          // (g, run)
     if (item >= n_witems) return;                  // no block-level synchronisation anywhere below
     const long long g = item / runs_per_sig;
@@ -86,34 +96,41 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restric
 #pragma unroll
     for (int p = 0; p < CHP; ++p) {
         xa[p] = x + (g * chans + 2 * p) * (long long)L;
-        xb[p] = (2 * p + 1 < chans) ? x + (g * chans + 2 * p + 1) * (long long)L : nullptr;
+        xb[p] = (2 * p + 1 < chans) ? x + (g * chans + 2 * p + 1) * (long long)L : xa[p];
     }
     c32 raw[CHP][E];
 #pragma unroll
     for (int p = 0; p < CHP; ++p) load_frame_slots<N, 0, E>(raw[p], xa[p], xb[p], t0, L, pad_mode, lane);
     for (int t = t0; t < t1; ++t) {
         c32 nxt[CHP][EH];
-        if (t + 1 < t1 && !(DISCO_EXP & 2)) {
+        {
+            const int tn = min(t + 1, T - 1);              // clamped: harmless reload at the end of a run
 #pragma unroll
-            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], t + 1, L, pad_mode, lane);
-        } else {
-#pragma unroll
-            for (int p = 0; p < CHP; ++p)
-#pragma unroll
-                for (int e = 0; e < EH; ++e) nxt[p][e] = make_float2(0.f, 0.f);
+            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], tn, L, pad_mode, lane);
         }
         c32 A[CHP][NJ], B[CHP][NJ];
 #pragma unroll
         for (int p = 0; p < CHP; ++p) {
             c32 v[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = make_float2(raw[p][e].x * w[e], raw[p][e].y * w[e]);
+            apply_window<N>(v, raw[p], w, 2 * p + 1 < chans);
             fft_wave<N>(v, wtw, sh.buf[wave], lane);
             rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int j, int, c32 a, c32 b) {
                 A[p][j] = a;
                 B[p][j] = b;
             });
         }
+        // Consume the prefetched half-window BEFORE this frame's stores are issued: vmcnt retires in order, so a wait
+        // placed after the stores would also wait for them; placed here it only covers loads (and stores of the
+        // previous frame, a whole transform old).
+#pragma unroll
+        for (int p = 0; p < CHP; ++p)
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                DISCO_CONSUME(nxt[p][e].x);
+                DISCO_CONSUME(nxt[p][e].y);
+                raw[p][e] = raw[p][e + EH];
+                raw[p][e + EH] = nxt[p][e];
+            }
         if (!(DISCO_EXP & 1) || A[0][0].x == 1.2345f) {
             c32* Xo = X + ((g * T + t) * (long long)F) * chans;
 #pragma unroll
@@ -135,32 +152,27 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restric
                 }
             }
         }
-#pragma unroll
-        for (int p = 0; p < CHP; ++p)
-#pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                raw[p][e] = raw[p][e + EH];
-                raw[p][e + EH] = nxt[p][e];
-            }
     }
 }
 
+// tf_mask (dnn/utils.py:57-67) on one bin.  v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE div/sqrt expansions:
+// ~12 instructions instead of ~60 per bin, error 2-3 ulp on a mask that is compared at 1e-5.
+__device__ __forceinline__ float ipow(float r, int p) {
+    float m = r;
+    for (int i = 1; i < p; ++i) m *= r;
+    return p == 0 ? 1.f : m;
+}
 __device__ __forceinline__ float tf_mask_value(c32 S, c32 Nn, int mask_type, int mask_pow, float thr_lin) {
-    const float as = sqrtf(S.x * S.x + S.y * S.y);
+    const float as = __builtin_amdgcn_sqrtf(S.x * S.x + S.y * S.y);
     if (mask_type == DISCO_MASK_IAM) {
         const c32 y = cadd(S, Nn);
-        float r = as / sqrtf(y.x * y.x + y.y * y.y);
-        float m = r;
-        for (int i = 1; i < mask_pow; ++i) m *= r;
-        return mask_pow == 0 ? 1.f : m;
+        return ipow(as * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(y.x * y.x + y.y * y.y)), mask_pow);
     }
-    const float an = fmaxf(sqrtf(Nn.x * Nn.x + Nn.y * Nn.y), 2.220446049250313e-16f);
-    const float r = as / an;
-    float xi = r;
-    for (int i = 1; i < mask_pow; ++i) xi *= r;
-    if (mask_pow == 0) xi = 1.f;
+    const float an = fmaxf(__builtin_amdgcn_sqrtf(Nn.x * Nn.x + Nn.y * Nn.y), 2.220446049250313e-16f);
+    const float xi = ipow(as * __builtin_amdgcn_rcpf(an), mask_pow);
     if (mask_type == DISCO_MASK_IBM) return xi >= thr_lin ? 1.f : 0.f;
-    return xi / (1.f + xi);
+    // xi / (1 + xi); an overflowing xi gives NaN exactly like the reference's inf / inf
+    return xi * __builtin_amdgcn_rcpf(1.f + xi);
 }
 
 // s_ref, n_ref: [n_sig][L] -> mask [n_sig][T][F]; the pair (s, n) shares one complex FFT.  Streams like k_stft.
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_mask_oracle(const float* __
                                                                   long long n_witems) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2;
     __shared__ StftShared<N> sh;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * STFT_WAVES + wave;
     if (item >= n_witems) return;
     const long long g = item / runs_per_sig;
@@ -188,25 +200,25 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_mask_oracle(const float* __
     load_frame_slots<N, 0, E>(raw, xs, xn, t0, L, pad_mode, lane);
     for (int t = t0; t < t1; ++t) {
         c32 nxt[EH];
-        if (t + 1 < t1) {
-            load_frame_slots<N, EH, E>(nxt, xs, xn, t + 1, L, pad_mode, lane);
-        } else {
-#pragma unroll
-            for (int e = 0; e < EH; ++e) nxt[e] = make_float2(0.f, 0.f);
-        }
+        load_frame_slots<N, EH, E>(nxt, xs, xn, min(t + 1, T - 1), L, pad_mode, lane);
         c32 v[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = make_float2(raw[e].x * w[e], raw[e].y * w[e]);
+        apply_window<N>(v, raw, w, true);
         fft_wave<N>(v, wtw, sh.buf[wave], lane);
-        float* mo = mask + (g * T + t) * (long long)F;
-        rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
-            mo[f] = tf_mask_value(a, b, mask_type, mask_pow, thr_lin);
+        float mval[EH + 1];
+        rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int j, int, c32 a, c32 b) {
+            mval[j] = tf_mask_value(a, b, mask_type, mask_pow, thr_lin);
         });
 #pragma unroll
-        for (int e = 0; e < EH; ++e) {
+        for (int e = 0; e < EH; ++e) {                 // consume the prefetch before the stores (see k_stft)
+            DISCO_CONSUME(nxt[e].x);
+            DISCO_CONSUME(nxt[e].y);
             raw[e] = raw[e + EH];
             raw[e + EH] = nxt[e];
         }
+        float* mo = mask + (g * T + t) * (long long)F;
+#pragma unroll
+        for (int j = 0; j <= EH; ++j)
+            if (j < EH || lane == 0) mo[lane + 64 * j] = mval[j];
     }
 }
 
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_istft(const c32* __restrict
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2;
     __shared__ IstftShared<N> sh;
     for (int i = threadIdx.x; i < N; i += blockDim.x) sh.win[i] = win[i];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     const long long g = blockIdx.x / blocks_per_sig;
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
     constexpr int NP = M * (M + 1) / 2;
     constexpr int BPT = (F - 1) / 256;             // bins per thread: 1 (N = 512) or 2 (N = 1024)
     __shared__ StftCovShared<N, CHP> sh;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63;
     const long long g = blockIdx.x / chunks;
     const int c = (int)(blockIdx.x % chunks);
     const int tb = c * STFT_WAVES * SC_RUNW;
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
 #pragma unroll
     for (int p = 0; p < CHP; ++p) {
         xa[p] = x + (g * M + 2 * p) * (long long)L;
-        xb[p] = (2 * p + 1 < M) ? x + (g * M + 2 * p + 1) * (long long)L : nullptr;
+        xb[p] = (2 * p + 1 < M) ? x + (g * M + 2 * p + 1) * (long long)L : xa[p];
     }
     c32 raw[CHP][E];
 #pragma unroll
@@ -378,33 +390,37 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
         float mv[STFT_WAVES][BPT], mny[STFT_WAVES];
 #pragma unroll
         for (int ww = 0; ww < STFT_WAVES; ++ww) {
-            const int t2 = tb + ww * SC_RUNW + it;
-            const bool ok = t2 < min(T, tb + (ww + 1) * SC_RUNW);
+            const int t2 = min(tb + ww * SC_RUNW + it, T - 1);          // clamped: unconditional loads, used only when valid
 #pragma unroll
-            for (int b = 0; b < BPT; ++b) mv[ww][b] = ok ? mg[(long long)t2 * F + tid + 256 * b] : 0.f;
-            mny[ww] = (ok && tid < 2 * NP) ? mg[(long long)t2 * F + F - 1] : 0.f;
+            for (int b = 0; b < BPT; ++b) mv[ww][b] = mg[(long long)t2 * F + tid + 256 * b];
+            mny[ww] = mg[(long long)t2 * F + F - 1];
         }
         c32 nxt[CHP][EH];
+        {
+            const int tn = min(t + 1, T - 1);              // clamped: harmless reload at the end of a run
 #pragma unroll
-        for (int p = 0; p < CHP; ++p) {
-            if (t + 1 < te) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], t + 1, L, pad_mode, lane);
-            else {
-#pragma unroll
-                for (int e = 0; e < EH; ++e) nxt[p][e] = make_float2(0.f, 0.f);
-            }
+            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], tn, L, pad_mode, lane);
         }
         if (valid) {
 #pragma unroll
             for (int p = 0; p < CHP; ++p) {
                 c32 v[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) v[e] = make_float2(raw[p][e].x * w[e], raw[p][e].y * w[e]);
+                apply_window<N>(v, raw[p], w, 2 * p + 1 < M);
                 fft_wave<N>(v, wtw, sh.buf[wave], lane);
                 rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
                     *reinterpret_cast<float4*>(&sh.tile[wave][f][2 * p]) = make_float4(a.x, a.y, b.x, b.y);
                 });
             }
         }
+#pragma unroll
+        for (int p = 0; p < CHP; ++p)                   // consume the prefetch before the X stores below (see k_stft)
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                DISCO_CONSUME(nxt[p][e].x);
+                DISCO_CONSUME(nxt[p][e].y);
+                raw[p][e] = raw[p][e + EH];
+                raw[p][e + EH] = nxt[p][e];
+            }
         __syncthreads();
         // ---- one thread per bin: copy out + reduce the (up to) 4 frames of this iteration
 #pragma unroll
@@ -412,6 +428,13 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
             const int t2 = tb + ww * SC_RUNW + it;
             if (t2 < min(T, tb + (ww + 1) * SC_RUNW)) {          // workgroup-uniform
                 c32* Xo = X + ((g * T + t2) * (long long)F) * M;
+                if ((M & 1) == 0) {
+                    // even M: the tile row IS the X row (F*M complex, contiguous) -> straight 16-B-per-lane copy, every
+                    // wave store covers 1 KiB of consecutive bytes (a per-bin store would touch each 128-B line twice)
+                    const float4* src = reinterpret_cast<const float4*>(&sh.tile[ww][0][0]);
+                    float4* dst = reinterpret_cast<float4*>(Xo);
+                    for (int i = tid; i < F * M / 2; i += 64 * STFT_WAVES) dst[i] = src[i];
+                }
 #pragma unroll
                 for (int b = 0; b < BPT; ++b) {
                     const int f = tid + 256 * b;
@@ -422,12 +445,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
                         xv[2 * p] = make_float2(q4.x, q4.y);
                         xv[2 * p + 1] = make_float2(q4.z, q4.w);
                     }
-                    if ((M & 1) == 0) {
-#pragma unroll
-                        for (int p = 0; p < CHP; ++p)
-                            reinterpret_cast<float4*>(Xo + (long long)f * M)[p] =
-                                make_float4(xv[2 * p].x, xv[2 * p].y, xv[2 * p + 1].x, xv[2 * p + 1].y);
-                    } else {
+                    if ((M & 1) != 0) {
 #pragma unroll
                         for (int i = 0; i < M; ++i) Xo[(long long)f * M + i] = xv[i];
                     }
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
                     }
                 }
                 // Nyquist bin
-                if (tid < M) Xo[(long long)(F - 1) * M + tid] = sh.tile[ww][F - 1][tid];
+                if ((M & 1) != 0 && tid < M) Xo[(long long)(F - 1) * M + tid] = sh.tile[ww][F - 1][tid];
                 if (tid < 2 * NP) {
                     const float m = (tid & 1) ? 1.f - mny[ww] : mny[ww];
                     const c32 a = sh.tile[ww][F - 1][ny_i], b2 = sh.tile[ww][F - 1][ny_j];
@@ -464,13 +482,6 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < CHP; ++p)
-#pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                raw[p][e] = raw[p][e + EH];
-                raw[p][e + EH] = nxt[p][e];
-            }
     }
     float4* o = part + ((g * chunks + c) * F) * (long long)NP;
 #pragma unroll

@@ -30,6 +30,7 @@
 #define __restrict__ __restrict
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define HIPEMU 1
+#define DISCO_CONSUME(x) ((void)(x))      // register-level scheduling pin of the GPU build: nothing to emulate
 
 struct uint3 { unsigned x, y, z; };
 struct dim3 {
@@ -160,9 +161,12 @@ static inline int __all(int pred) {
 // wave-level fences used by the kernels: the scheduling barrier becomes a real 64-thread rendezvous here
 static inline void __builtin_amdgcn_wave_barrier() { pthread_barrier_wait(&hipemu::t_wave->bar); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 

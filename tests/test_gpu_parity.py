@@ -47,7 +47,7 @@ def test_masks(make_engine):
 
 @pytest.mark.parametrize('R,K,M,same_z,mask_remote', [(2, 2, 2, True, True), (3, 3, 2, False, False), (5, 1, 4, True, True),
                                                      (4, 4, 4, True, True), (2, 2, 5, True, True), (1, 1, 8, True, True),
-                                                     (2, 5, 3, False, True)])
+                                                     (2, 5, 3, False, True), (2, 8, 8, True, True), (1, 3, 7, False, False), (2, 6, 5, True, True)])
 def test_cov_solve_apply(make_engine, R, K, M, same_z, mask_remote):
     pc.check_cov_solve_apply(make_engine, R=R, K=K, M=M, L=16000, same_z=same_z, mask_remote=mask_remote)
 
@@ -97,7 +97,8 @@ def test_solver_degenerate_inputs(make_engine):
 
 
 @pytest.mark.parametrize('K,M,L,n_fft,staged', [(4, 4, 160000, 512, False), (4, 4, 160000, 512, True), (1, 4, 160000, 512, False),
-                                                (2, 3, 20000, 512, False), (2, 2, 40000, 1024, False), (3, 2, 30000, 512, True)])
+                                                (2, 3, 20000, 512, False), (2, 2, 40000, 1024, False), (3, 2, 30000, 512, True),
+                                                (8, 8, 40000, 1024, False)])
 def test_tango_end_to_end_vs_oracle(make_engine, K, M, L, n_fft, staged):
     """Full path on synthetic rooms (SURVEY 8d generator) vs the float64 oracle; bar: 1e-4 relative.
     staged=False: step 2 on the in-register z exchange (default); True: z materialised, staged kernels."""
