@@ -705,10 +705,10 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     const int64_t G = (int64_t)c.rooms * c.nodes;
     const int M = c.mics, P2 = c.mics + c.nodes - 1;
     int rc;
-    // step 1 (tango.py:326-376)
-    if ((rc = disco_stft(ctx, y, G, M, X, s))) return rc;
-    if ((rc = disco_cov_masked(ctx, X, mask_z, nullptr, nullptr, 0, M, Rss, Rnn, s))) return rc;
-    if ((rc = disco_gevd_mwf_r1(ctx, Rss, Rnn, G * ctx->F, M, c.mu, w, nullptr, s))) return rc;
+    // step 1 (tango.py:326-376): STFT + covariance in one pass, solve straight from the partial sums
+    int chunks1 = 1;
+    if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks1, s))) return rc;
+    if ((rc = solve_from_partials(ctx, chunks1, M, w, s))) return rc;
     if ((rc = disco_apply(ctx, X, nullptr, w, M, 1, z, s))) return rc;
     if (c.nodes == 1 && mask_w == mask_z) {
         // single node, same mask: step 2 would rebuild the very same statistics from the very same inputs

@@ -156,7 +156,7 @@ class Engine:
         self._chk(self.lib.disco_mask_oracle(self.ctx, ps, pn, n_sig, m.ptr, self.stream))
         return m
 
-    def cov_masked(self, X, mask, Zs=None, Zn=None, mask_remote=True):
+    def cov_masked(self, X, mask, Zs=None, Zn=None, mask_remote=True, Rss_out=True):
         """X (R,K,T,F,M), mask (R,K,T,F)[, Zs, Zn (R,K,T,F)] -> Rss, Rnn (R,K,F,P,P)   [tango.py:357-364, 433-440]"""
         P = self.M + (self.K - 1 if Zs is not None else 0)
         px, kx = self.to_device(X, np.complex64)
@@ -166,6 +166,9 @@ class Engine:
             pzn, kzn = pzs, kzs
         else:
             pzn, kzn = self.to_device(Zn, np.complex64)
+        if not Rss_out:          # leave the partial sums in the context for gevd_mwf_r1_pending
+            self._chk(self.lib.disco_cov_masked(self.ctx, px, pm, pzs, pzn, int(bool(mask_remote)), P, None, None, self.stream))
+            return None, None
         Rss = self.empty((self.R, self.K, self.F, P, P), np.complex64)
         Rnn = self.empty((self.R, self.K, self.F, P, P), np.complex64)
         self._chk(self.lib.disco_cov_masked(self.ctx, px, pm, pzs, pzn, int(bool(mask_remote)), P, Rss.ptr, Rnn.ptr,
@@ -240,6 +243,28 @@ class Engine:
         yf = self.empty((self.R, self.K, self.T, self.F), np.complex64)
         self._chk(self.lib.disco_step2_apply_fused(self.ctx, px, pl, pg, z.ptr if z else None, yf.ptr, self.stream))
         return yf, z
+
+    def tango_enhance_iterated(self, y, mask_z, mask_w=None, iters=2):
+        """DANSE-style continuation of the two-step scheme (BASELINE.json configs[4]; not in the reference): step 2 is
+        run `iters` times, each time with z_k <- w_glo,k[:M]^H y_k.  iters=1 is exactly offline_tango's y branch.
+        Staged kernels (z materialised).  Returns (out (R,K,L), yf (R,K,T,F))."""
+        mask_w = mask_z if mask_w is None else mask_w
+        R, K, M = self.R, self.K, self.M
+        X = self.stft(y.reshape(R * K, M, self.Lsamp) if hasattr(y, 'reshape') else y).reshape(R, K, self.T, self.F, M)
+        self.cov_masked(X, mask_z, Rss_out=False)
+        w, _ = self.gevd_mwf_r1_pending(M)
+        z = self.apply(X, w)
+        yf = z
+        for it in range(iters):
+            if K > 1:
+                self.cov_masked(X, mask_w, z, z, mask_remote=True, Rss_out=False)
+            else:
+                self.cov_masked(X, mask_w, Rss_out=False)
+            w_glo, _ = self.gevd_mwf_r1_pending(M + K - 1)
+            yf = self.apply(X, w_glo, Z=z if K > 1 else None)
+            if it + 1 < iters:
+                z = self.apply(X, np.ascontiguousarray(w_glo.numpy()[..., :M]))
+        return self.istft(yf.reshape(R * K, self.T, self.F)).reshape(R, K, self.Lsamp), yf
 
     # ---- whole path
     def workspace_bytes(self):

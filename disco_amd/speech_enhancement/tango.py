@@ -42,8 +42,10 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
     """y, s, n: (R, K, M, L) float32.  Returns a dict of device-computed arrays with a leading room axis, in the
     engine's frame-major layout (R, K, T, F): yf, sf, nf, z_y, z_s, z_n, zn, masks_z, mask_w."""
     vads = _mask_names(vads)
-    if mask_for_z not in ('local', None):
-        raise NotImplementedError("mask_for_z: 'local' (the reference default) and None are implemented")
+    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs')
+    if mask_for_z not in MODES:
+        raise NotImplementedError(f'mask_for_z must be one of {MODES}')       # 'use_oracle_sigs' is broken in the reference
+    oracle_sigs = isinstance(mask_for_z, str) and 'use_oracle_' in mask_for_z
     y = np.ascontiguousarray(y, dtype=np.float32)
     s = np.ascontiguousarray(s, dtype=np.float32)
     n = np.ascontiguousarray(n, dtype=np.float32)
@@ -63,16 +65,33 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
     mz = masks_z.numpy().astype(np.float32)
     mw = mz if same else mask_w.numpy().astype(np.float32)
     # step 1 (tango.py:357-376)
-    Rss, Rnn = eng.cov_masked(Y, mz)
-    w_loc, _ = eng.gevd_mwf_r1_pending(M)
+    if oracle_sigs:                                                            # statistics from the oracle images (tango.py:343-345)
+        Rss, _ = eng.cov_masked(S, np.ones_like(mz))
+        _, Rnn = eng.cov_masked(N, np.zeros_like(mz))
+        w_loc, _ = eng.gevd_mwf_r1(Rss, Rnn, want_t1=False)
+    else:
+        eng.cov_masked(Y, mz)
+        w_loc, _ = eng.gevd_mwf_r1_pending(M)
     z_y, z_s, z_n = eng.apply(Y, w_loc), eng.apply(S, w_loc), eng.apply(N, w_loc)
     zn = eng.noise_residual(Y, z_y)
     out = dict(masks_z=mz, mask_w=mw, z_y=z_y.numpy(), z_s=z_s.numpy(), z_n=z_n.numpy(), zn=zn.numpy())
     # exchange + step 2 (tango.py:378-450)
     if mask_for_z == 'local':
         eng.cov_masked(Y, mw, z_y, z_y, mask_remote=True)
-    else:                                                                      # None: unmasked z / zn rows (tango.py:419-422)
+    elif mask_for_z is None:                                                   # unmasked z / zn rows (tango.py:419-422)
         eng.cov_masked(Y, mw, z_y, zn, mask_remote=False)
+    else:                                                                      # sender-side variants (tango.py:396-409): the
+        zy = out['z_y']                                                        # remote rows are prepared on the host, then fed
+        if mask_for_z == 'distant':                                            # to the same covariance kernel unmasked
+            zs_rows, zn_rows = zy * mw, zy * (1 - mw)
+        elif mask_for_z == 'compressed':
+            mc = eng.tf_mask(out['z_s'], out['z_n'], type=vads[0]).numpy()
+            zs_rows, zn_rows = zy * mc, zy * (1 - mc)
+        elif mask_for_z == 'use_oracle_refs':
+            zs_rows, zn_rows = np.ascontiguousarray(Sh[..., ref_mic]), np.ascontiguousarray(Nh[..., ref_mic])
+        else:                                                                  # 'use_oracle_zs'
+            zs_rows, zn_rows = out['z_s'], out['z_n']
+        eng.cov_masked(Y, mw, zs_rows.astype(np.complex64), zn_rows.astype(np.complex64), mask_remote=False)
     w_glo, _ = eng.gevd_mwf_r1_pending(M + K - 1)
     out['yf'] = eng.apply(Y, w_glo, Z=z_y if K > 1 else None).numpy()
     out['sf'] = eng.apply(S, w_glo, Z=z_s if K > 1 else None).numpy()

@@ -73,10 +73,13 @@ def _solve_bins(Rss, Rnn, mu, solver):
 
 def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=512, hop=256,
                       ref_mics=None, mu=1, precision='f64', pad_mode='reflect', solver='eig',
-                      masks=None):
+                      masks=None, extra_iters=0):
     """Vectorised two-step Tango.  y, s, n: [node][channel] -> time (list or (K, M, L) array).
 
     masks: optional (masks_z, mask_w) lists of (F, T) arrays replacing the oracle masks (DNN stand-in).
+    extra_iters: DANSE-style continuation (NOT in the reference, which is strictly two-step, tango.py:1-2): after
+    step 2 every node re-compresses with the local part of its global filter, z_k <- w_glo,k[:M]^H y_k, and step 2 is
+    run again (BASELINE.json configs[4]; SURVEY.md section 7 item 10 defines it; no reference parity exists).
     Returns a dict with every intermediate: Y,S,N STFTs, masks_z, mask_w, Rss_loc, Rnn_loc, w_loc, t1_loc,
     z_y, z_s, z_n, zn, Rss_glo, Rnn_glo, w_glo, t1_glo, yf, sf, nf (lists over nodes).
     """
@@ -85,8 +88,10 @@ def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=
     y, s, n = _as_node_list(y), _as_node_list(s), _as_node_list(n)
     K = len(y)
     ref_mics = [0] * K if ref_mics is None else list(ref_mics)
-    if mask_for_z not in ('local', None):
-        raise NotImplementedError('oracle implements mask_for_z in ("local", None)')
+    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs')
+    if mask_for_z not in MODES:
+        raise NotImplementedError(f'oracle implements mask_for_z in {MODES}')
+    oracle_sigs = isinstance(mask_for_z, str) and 'use_oracle_' in mask_for_z          # tango.py:343
 
     Y = [so.stft(y[k], n_fft, hop, pad_mode, cdt) for k in range(K)]          # (M, F, T)
     S = [so.stft(s[k], n_fft, hop, pad_mode, cdt) for k in range(K)]
@@ -103,8 +108,11 @@ def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=
         r = ref_mics[k]
         m = masks[0][k] if masks is not None else _oracle_mask(S[k][r], N[k][r], vads[0])
         out['masks_z'][k] = m
-        s_hat = m * Y[k]
-        n_hat = (1 - m) * Y[k]
+        if oracle_sigs:                                                            # tango.py:343-345
+            s_hat, n_hat = S[k], N[k]
+        else:
+            s_hat = m * Y[k]
+            n_hat = (1 - m) * Y[k]
         Rss = _cov_mean(s_hat, ref32)
         Rnn = _cov_mean(n_hat, ref32)
         w, t1 = _solve_bins(Rss, Rnn, mu, solver)
@@ -115,36 +123,62 @@ def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=
         out['z_n'][k] = np.einsum('fm,mft->ft', wc, N[k]).astype(cdt)
         out['zn'][k] = Y[k][r] - out['z_y'][k]
 
-    # ---- exchange + step 2 (tango.py:378-450)
-    z_for_rs = copy.deepcopy(out['z_y'])
-    z_for_rn = copy.deepcopy(out['z_y'])
-    for k in range(K):
-        if masks is not None:
-            mw = masks[1][k]
-        else:
-            mw = _oracle_mask(S[k][0], N[k][0], vads[1])                       # tango.py:391 (channel 0)
-        out['mask_w'][k] = mw
-    s_hat_w = [out['mask_w'][k] * Y[k] for k in range(K)]
-    n_hat_w = [(1 - out['mask_w'][k]) * Y[k] for k in range(K)]
-    for k in range(K):
-        if mask_for_z == 'local':
-            ms, mn = out['mask_w'][k], 1 - out['mask_w'][k]
-        else:                                                                  # None (tango.py:419-422)
-            ms, mn = 1, 1
-            z_for_rn = out['zn']
-        in_y = concatenate_signals(Y, out['z_y'], k)
-        in_s = concatenate_signals(S, out['z_s'], k)
-        in_n = concatenate_signals(N, out['z_n'], k)
-        phi_s = concatenate_signals(s_hat_w, z_for_rs, k, ms)
-        phi_n = concatenate_signals(n_hat_w, z_for_rn, k, mn)
-        Rss = _cov_mean(phi_s.astype(cdt), ref32)
-        Rnn = _cov_mean(phi_n.astype(cdt), ref32)
-        w, t1 = _solve_bins(Rss, Rnn, mu, solver)
-        out['Rss_glo'][k], out['Rnn_glo'][k], out['w_glo'][k], out['t1_glo'][k] = Rss, Rnn, w, t1
-        wc = np.conjugate(w)
-        out['yf'][k] = np.einsum('fp,pft->ft', wc, in_y).astype(cdt)
-        out['sf'][k] = np.einsum('fp,pft->ft', wc, in_s).astype(cdt)
-        out['nf'][k] = np.einsum('fp,pft->ft', wc, in_n).astype(cdt)
+    for it in range(1 + extra_iters):
+        if it > 0:
+            if mask_for_z != 'local':
+                raise NotImplementedError('extra_iters is defined for mask_for_z="local" only')
+            for k in range(K):
+                Mk = Y[k].shape[0]
+                wl = np.conjugate(out['w_glo'][k][:, :Mk])
+                out['z_y'][k] = np.einsum('fm,mft->ft', wl, Y[k]).astype(cdt)
+                out['z_s'][k] = np.einsum('fm,mft->ft', wl, S[k]).astype(cdt)
+                out['z_n'][k] = np.einsum('fm,mft->ft', wl, N[k]).astype(cdt)
+        # ---- exchange + step 2 (tango.py:378-450)
+        z_for_rs = copy.deepcopy(out['z_y'])
+        z_for_rn = copy.deepcopy(out['z_y'])
+        for k in range(K):
+            if masks is not None:
+                mw = masks[1][k]
+            else:
+                mw = _oracle_mask(S[k][0], N[k][0], vads[1])                       # tango.py:391 (channel 0)
+            out['mask_w'][k] = mw
+        for k in range(K):                                                         # tango.py:396-409
+            if mask_for_z == 'distant':
+                z_for_rs[k] = z_for_rs[k] * out['mask_w'][k]
+                z_for_rn[k] = z_for_rn[k] * (1 - out['mask_w'][k])
+            elif mask_for_z == 'compressed':
+                mc = _oracle_mask(out['z_s'][k], out['z_n'][k], vads[0])
+                z_for_rs[k] = z_for_rs[k] * mc
+                z_for_rn[k] = z_for_rn[k] * (1 - mc)
+            elif mask_for_z == 'use_oracle_refs':
+                z_for_rs[k] = S[k][ref_mics[k]]
+                z_for_rn[k] = N[k][ref_mics[k]]
+            elif mask_for_z == 'use_oracle_zs':
+                z_for_rs[k] = out['z_s'][k]
+                z_for_rn[k] = out['z_n'][k]
+        s_hat_w = [out['mask_w'][k] * Y[k] for k in range(K)]
+        n_hat_w = [(1 - out['mask_w'][k]) * Y[k] for k in range(K)]
+        for k in range(K):
+            if mask_for_z == 'local':
+                ms, mn = out['mask_w'][k], 1 - out['mask_w'][k]
+            elif mask_for_z is None:                                               # tango.py:419-422
+                ms, mn = 1, 1
+                z_for_rn = out['zn']
+            else:                                                                  # 'previous' branch, tango.py:428-429
+                ms, mn = 1, 1
+            in_y = concatenate_signals(Y, out['z_y'], k)
+            in_s = concatenate_signals(S, out['z_s'], k)
+            in_n = concatenate_signals(N, out['z_n'], k)
+            phi_s = concatenate_signals(s_hat_w, [np.asarray(a, dtype=cdt) for a in z_for_rs], k, ms)
+            phi_n = concatenate_signals(n_hat_w, [np.asarray(a, dtype=cdt) for a in z_for_rn], k, mn)
+            Rss = _cov_mean(phi_s.astype(cdt), ref32)
+            Rnn = _cov_mean(phi_n.astype(cdt), ref32)
+            w, t1 = _solve_bins(Rss, Rnn, mu, solver)
+            out['Rss_glo'][k], out['Rnn_glo'][k], out['w_glo'][k], out['t1_glo'][k] = Rss, Rnn, w, t1
+            wc = np.conjugate(w)
+            out['yf'][k] = np.einsum('fp,pft->ft', wc, in_y).astype(cdt)
+            out['sf'][k] = np.einsum('fp,pft->ft', wc, in_s).astype(cdt)
+            out['nf'][k] = np.einsum('fp,pft->ft', wc, in_n).astype(cdt)
     return out
 
 

@@ -136,6 +136,18 @@ def main():
         scenes = [('k2m2', 2, [2, 2], 4096), ('k3ragged', 3, [3, 2, 2], 5120), ('k4m4', 4, [4, 4, 4, 4], 6144)]
         for name, K, Mk, L in scenes:
             y, s, n = _toy_scene(rng, K, Mk, L)
+            if name == 'k2m2':
+                # the other mask_for_z modes (tango.py:396-429), yf / sf / nf only, on the smallest scene
+                dm = {'K': np.array(K), 'L': np.array(L)}
+                for k in range(K):
+                    dm[f'y{k}'], dm[f's{k}'], dm[f'n{k}'] = y[k], s[k], n[k]
+                for mfz in ('distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs'):
+                    res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mods=[None, None], mask_for_z=mfz)
+                    for k in range(K):
+                        for nm, arr in zip(['yf', 'sf', 'nf'], res[:3]):
+                            dm[f'{mfz}_{nm}{k}'] = np.asarray(arr[k])
+                np.savez_compressed(os.path.join(HERE, 'tango_ref_modes_k2m2.npz'), **dm)
+                print('mask_for_z modes done')
             for mfz in ('local', None):
                 if mfz is None:
                     # tango.py:343 does `'use_oracle_' in mask_for_z`, a TypeError for None as shipped; the

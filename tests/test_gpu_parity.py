@@ -107,6 +107,36 @@ def test_tango_end_to_end_vs_oracle(make_engine, K, M, L, n_fft, staged):
     print(K, M, L, n_fft, staged, errs)
 
 
+def test_c2_single_node_config(make_engine):
+    """BASELINE.json configs[1] (C2) shape: single node x 4 mics, many rooms; output = iSTFT(z) (K = 1)."""
+    y, s, n = synth.make_rooms_numpy(3, K=1, M=4, L=48000)
+    errs = pc.check_tango_end_to_end(make_engine, y, s, n, tol=1e-4)
+    print('C2', errs)
+
+
+@pytest.mark.parametrize('K,M,L,n_fft,iters', [(3, 2, 30000, 512, 2), (8, 8, 30720, 1024, 2), (2, 2, 20000, 512, 3)])
+def test_iterated_danse_extension(make_engine, K, M, L, n_fft, iters):
+    """BASELINE.json configs[4] (C5): DANSE-style extra iterations of step 2.  This is an EXTENSION: the reference is
+    strictly two-step (tango.py:1-2), so there is no reference parity; the check is against the oracle's restatement
+    of the same definition (z_k <- w_glo,k[:M]^H y_k)."""
+    from oracle import stft_oracle as so
+    from oracle import tango_oracle as to
+    y, s, n = synth.make_rooms_numpy(1, K=K, M=M, L=L)
+    eng = make_engine(rooms=1, nodes=K, mics=M, length=L, n_fft=n_fft)
+    m = eng.mask_oracle(s[0, :, 0], n[0, :, 0]).reshape(1, K, eng.T, eng.F)
+    out, yf = eng.tango_enhance_iterated(y, m, iters=iters)
+    o = to.offline_tango_vec(y[0], s[0], n[0], vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh',
+                             extra_iters=iters - 1)
+    for k in range(K):
+        assert pc.relerr(yf.numpy()[0, k].T, o['yf'][k]) < 1e-4
+        ref = so.istft(o['yf'][k], L, n_fft, n_fft // 2, work_dtype=np.float64)
+        assert pc.relerr(out.numpy()[0, k], ref) < 1e-4
+    # iters = 1 must be the plain two-step path
+    out1, _ = eng.tango_enhance_iterated(y, m, iters=1)
+    out_ref, _, _ = eng.tango_enhance(y, m)
+    assert pc.relerr(out1.numpy(), out_ref.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize('scene', ['k2m2', 'k4m4'])
 def test_tango_vs_reference_golden(make_engine, golden_dir, scene):
     """HIP path against outputs of the REFERENCE'S OWN offline_tango (tests/golden/tango_ref_*.npz).

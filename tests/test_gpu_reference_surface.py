@@ -42,6 +42,27 @@ def test_offline_tango_mask_for_z_none():
         assert relerr(res[0][k], o['yf'][k]) < 1e-4
 
 
+@pytest.mark.parametrize('mode', ['distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs'])
+def test_offline_tango_mask_for_z_modes(mode, golden_dir):
+    """Sender-side mask_for_z variants: vs the float64 oracle on a synthetic room (1e-4) and vs the reference's own
+    outputs on the golden scene."""
+    from disco_amd import synth
+    from disco_amd.speech_enhancement.tango import offline_tango
+    y, s, n, _ = synth.make_room_numpy(8, K=3, M=2, L=20000)
+    res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mask_for_z=mode)
+    o = to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], mask_for_z=mode, precision='f64', solver='eigh')
+    for k in range(3):
+        for i, nm in enumerate(['yf', 'sf', 'nf']):
+            assert relerr(res[i][k], o[nm][k]) < 1e-4, (mode, nm, k)
+    g = np.load(os.path.join(golden_dir, 'tango_ref_modes_k2m2.npz'))
+    yg = [g['y0'], g['y1']]
+    sg = [g['s0'], g['s1']]
+    ng = [g['n0'], g['n1']]
+    res = offline_tango(yg, sg, ng, vads=['irm1', 'irm1'], mask_for_z=mode)
+    for k in range(2):
+        assert relerr(res[0][k], g[f'{mode}_yf{k}']) < 1e-2
+
+
 def test_get_z_signals_variant():
     from disco_amd import synth
     from disco_amd.speech_enhancement.get_z_signals import offline_tango

@@ -115,3 +115,17 @@ def test_vectorised_oracle_matches_literal_port():
         worst = max(relerr(out[nm][k], arr[k]) for nm, arr in zip(names, lit) for k in range(3))
         print(precision, solver, 'worst vs literal', worst)
         assert worst < tol
+
+
+@pytest.mark.parametrize('mode', ['distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs'])
+def test_vectorised_oracle_mask_for_z_modes_match_reference(golden_dir, mode):
+    """The other mask_for_z modes (tango.py:343-345, 396-429) against the reference's own outputs."""
+    g = np.load(os.path.join(golden_dir, 'tango_ref_modes_k2m2.npz'))
+    K = int(g['K'])
+    y = [g[f'y{k}'] for k in range(K)]
+    s = [g[f's{k}'] for k in range(K)]
+    n = [g[f'n{k}'] for k in range(K)]
+    out = to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], mask_for_z=mode, precision='ref32', solver='eig')
+    worst = max(relerr(out[nm][k], g[f'{mode}_{nm}{k}']) for nm in ('yf', 'sf', 'nf') for k in range(K))
+    print(mode, 'worst vs reference', worst)
+    assert worst < 2e-3          # tiny, badly conditioned scene: the reference's complex64 noise floor (see above)
