@@ -19,7 +19,9 @@ def build_hip(force=False, verbose=True):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', OUT, SRC]
+    # -fno-slp-vectorize: hipcc's SLP pass fuses adjacent f32 ops into v_pk_*_f32, which issue slower than the scalar
+    # pair on gfx950 (guide: "packed f32 VALU ... an anti-lever"); measured -0.9 ms on k_stft_cov, -0.6 ms on k_step2_cov_fused
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-shared', '-fPIC', '-o', OUT, SRC]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

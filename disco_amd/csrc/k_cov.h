@@ -13,6 +13,28 @@ namespace disco {
 template <int P>
 __device__ __forceinline__ constexpr int tri_index(int i, int j) { return i * P - (i * (i - 1)) / 2 + (j - i); }
 
+// One frame's contribution when both statistics weigh the SAME vector u (step 1, and step 2 with mask_for_z = 'local'):
+//   Rss += a u u^H,  Rnn += b u u^H  with a = m^2, b = (1-m)^2.  The product u_i conj(u_j) is formed once and added into
+// both accumulators (8 instructions per off-diagonal pair, no per-row scaling).
+template <int P>
+__device__ __forceinline__ void cov_accumulate_shared(const c32* u, float a, float b, c32* acc_s, c32* acc_n) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int j = i; j < P; ++j) {
+            const int q = tri_index<P>(i, j);
+            const float pr = fmaf(u[i].x, u[j].x, u[i].y * u[j].y);
+            acc_s[q].x = fmaf(a, pr, acc_s[q].x);
+            acc_n[q].x = fmaf(b, pr, acc_n[q].x);
+            if (j != i) {
+                const float pi = fmaf(u[i].y, u[j].x, -(u[i].x * u[j].y));
+                acc_s[q].y = fmaf(a, pi, acc_s[q].y);
+                acc_n[q].y = fmaf(b, pi, acc_n[q].y);
+            }
+        }
+    }
+}
+
 struct CovArgs {
     const c32* X;        // [R][K][T][F][M]
     const float* mask;   // [R][K][T][F]

@@ -119,32 +119,15 @@ __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
         for (int u = 0; u < U; ++u) {
             const bool live = tu + u * gm.t_stride + gm.t_lane < gm.t1;       // frames past the chunk were loaded clamped: weigh them 0
             const float ms = live ? m[u] : 0.f, mc = live ? 1.f - m[u] : 0.f;
-            c32 vs[P], vn[P];
+            c32 uu[P];
 #pragma unroll
-            for (int i = 0; i < M; ++i) {
-                vs[i] = make_float2(ms * x[u][i].x, ms * x[u][i].y);
-                vn[i] = make_float2(mc * x[u][i].x, mc * x[u][i].y);
-            }
+            for (int i = 0; i < M; ++i) uu[i] = x[u][i];
 #pragma unroll
-            for (int jj = 0; jj < K - 1; ++jj) {       // concatenate_signals order; 'local': remote rows carry this node's mask
+            for (int jj = 0; jj < K - 1; ++jj) {       // concatenate_signals order; 'local': remote rows carry this node's mask too
                 const int j = jj < k ? jj : jj + 1;
-                const c32 z = zbuf[buf][u][j][lane];
-                vs[M + jj] = make_float2(ms * z.x, ms * z.y);
-                vn[M + jj] = make_float2(mc * z.x, mc * z.y);
+                uu[M + jj] = zbuf[buf][u][j][lane];
             }
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-#pragma unroll
-                for (int j = i; j < P; ++j) {
-                    const int q = tri_index<P>(i, j);
-                    acc_s[q].x = fmaf(vs[i].x, vs[j].x, fmaf(vs[i].y, vs[j].y, acc_s[q].x));
-                    acc_n[q].x = fmaf(vn[i].x, vn[j].x, fmaf(vn[i].y, vn[j].y, acc_n[q].x));
-                    if (j != i) {
-                        acc_s[q].y = fmaf(vs[i].y, vs[j].x, fmaf(-vs[i].x, vs[j].y, acc_s[q].y));
-                        acc_n[q].y = fmaf(vn[i].y, vn[j].x, fmaf(-vn[i].x, vn[j].y, acc_n[q].y));
-                    }
-                }
-            }
+            cov_accumulate_shared<P>(uu, ms * ms, mc * mc, acc_s, acc_n);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

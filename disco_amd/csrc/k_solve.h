@@ -148,6 +148,8 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
     }
 
     // ---- one-sided Jacobi, round-robin over G players (lanes >= P carry zero columns)
+    // Convergence is quadratic: once every pair of a sweep was already orthogonal to 1e-7 (g2 <= 1e-14 alpha beta) before
+    // being rotated, the sweep leaves it at ~1e-14 and a further (verification) sweep would rotate nothing that matters.
     for (int sweep = 0; sweep < 40; ++sweep) {
         int rotated = 0;
         for (int rd = 0; rd < G - 1; ++rd) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
             }
             const double g2 = gr * gr + gi * gi;
             if (g2 > 1e-28 * alpha * beta && g2 > 0.0) {
-                rotated = 1;
+                if (g2 > 1e-14 * alpha * beta) rotated = 1;
                 const double ag = sqrt(g2);
                 const double zeta = (beta - alpha) / (2.0 * ag);
                 const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

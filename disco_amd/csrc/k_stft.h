@@ -450,25 +450,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __res
                         for (int i = 0; i < M; ++i) Xo[(long long)f * M + i] = xv[i];
                     }
                     const float m = mv[ww][b], mc = 1.f - m;
-                    c32 vs[M], vn[M];
-#pragma unroll
-                    for (int i = 0; i < M; ++i) {
-                        vs[i] = make_float2(m * xv[i].x, m * xv[i].y);
-                        vn[i] = make_float2(mc * xv[i].x, mc * xv[i].y);
-                    }
-#pragma unroll
-                    for (int i = 0; i < M; ++i) {
-#pragma unroll
-                        for (int j = i; j < M; ++j) {
-                            const int q = tri_index<M>(i, j);
-                            acc_s[b][q].x = fmaf(vs[i].x, vs[j].x, fmaf(vs[i].y, vs[j].y, acc_s[b][q].x));
-                            acc_n[b][q].x = fmaf(vn[i].x, vn[j].x, fmaf(vn[i].y, vn[j].y, acc_n[b][q].x));
-                            if (j != i) {
-                                acc_s[b][q].y = fmaf(vs[i].y, vs[j].x, fmaf(-vs[i].x, vs[j].y, acc_s[b][q].y));
-                                acc_n[b][q].y = fmaf(vn[i].y, vn[j].x, fmaf(-vn[i].x, vn[j].y, acc_n[b][q].y));
-                            }
-                        }
-                    }
+                    cov_accumulate_shared<M>(xv, m * m, mc * mc, acc_s[b], acc_n[b]);
                 }
                 // Nyquist bin
                 if ((M & 1) != 0 && tid < M) Xo[(long long)(F - 1) * M + tid] = sh.tile[ww][F - 1][tid];

@@ -12,7 +12,7 @@ for spec in sys.argv[1:]:
     name, _, flags = spec.partition(':')
     flags = [f for f in flags.split(',') if f]
     out = os.path.join(out_dir, f'libdisco_{name}.so')
-    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', out,
+    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-shared', '-fPIC', '-o', out,
            os.path.join(REPO, 'disco_amd', 'csrc', 'disco_hip.hip')] + flags
     procs.append((name, subprocess.Popen(cmd)))
 for name, p in procs:

@@ -8,7 +8,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(REPO, 'disco_amd', 'csrc', 'disco_hip.hip')
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', '-fPIC', '-Rpass-analysis=kernel-resource-usage',
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-c', '-fPIC', '-Rpass-analysis=kernel-resource-usage',
        '-o', '/tmp/_res.o', src] + [a for a in sys.argv[1:] if a.startswith('-D')]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
