@@ -329,8 +329,11 @@ struct alignas(16) StftCovShared {
     c32 tile[STFT_WAVES][N / 2 + 1][2 * CHP];
 };
 
+#ifndef DISCO_SC_WPE
+#define DISCO_SC_WPE 3
+#endif
 template <int N, int M>
-__global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
+__global__ __launch_bounds__(64 * STFT_WAVES, DISCO_SC_WPE) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
                                                                c32* __restrict__ X, float4* __restrict__ part,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
                                                                int L, int T, int pad_mode, int chunks) {
