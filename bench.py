@@ -44,6 +44,7 @@ def kernel_alg_bytes(M, K, F, H):
         'apply2': M * F * 8 + (K - 1) * F * 8 + F * 8,        # X + remote z in, yf out
         'step2_cov': M * F * 8 + F * 4,                       # X + mask in (z stays on chip)
         'step2_apply': M * F * 8 + F * 8,                     # X in, yf out
+        'step2_apply_istft': M * F * 8 + H * 4,               # X in, hop samples out (yf stays on chip)
         'istft': F * 8 + H * 4,                               # yf in, hop samples out
     }
 
@@ -165,9 +166,12 @@ def main():
             calls += [
                 ('step2_cov', lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), NUL, NUL, NUL, None)),
                 ('solve2', lambda: lib.disco_gevd_mwf_r1_pending(eng.ctx, 1.0, p(w2), NUL, None)),
-                ('step2_apply', lambda: lib.disco_step2_apply_fused(eng.ctx, p(X), p(w), p(w2), NUL, p(yf), None)),
-                ('istft', lambda: lib.disco_istft(eng.ctx, p(yf), G, p(out), None)),
             ]
+            if N == 512:
+                calls += [('step2_apply_istft', lambda: lib.disco_step2_apply_istft_fused(eng.ctx, p(X), p(w), p(w2), p(out), None))]
+            else:
+                calls += [('step2_apply', lambda: lib.disco_step2_apply_fused(eng.ctx, p(X), p(w), p(w2), NUL, p(yf), None)),
+                          ('istft', lambda: lib.disco_istft(eng.ctx, p(yf), G, p(out), None))]
         else:
             calls += [('apply1', lambda: lib.disco_apply(eng.ctx, p(X), NUL, p(w), M, 1, p(z), None)),
                       ('istft', lambda: lib.disco_istft(eng.ctx, p(z), G, p(out), None))]

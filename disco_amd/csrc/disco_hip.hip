@@ -631,6 +631,53 @@ extern "C" int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const
     return check_launch(ctx, "k_step2_apply_fused");
 }
 
+template <int M, int K>
+static bool launch_apply_istft(const Step2Args& a, float* out, const float* win, const c32* tw, int L, int bpr, dim3 grid,
+                               hipStream_t st) {
+    if constexpr (sizeof(ApplyIstftShared<512, M, K>) <= 160 * 1024) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_apply_istft<512, M, K>), grid, dim3(64 * K), 0, st, a, out, win, tw, L, bpr);
+        return true;
+    } else {
+        return false;
+    }
+}
+
+extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc,
+                                             const disco_c32* w_glo, float* out, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!X || !w_loc || !w_glo || !out) return fail(ctx, DISCO_E_ARG, "disco_step2_apply_istft_fused: null argument");
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes, P = M + K - 1;
+    if (c.n_fft != 512 || P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_istft_fused: needs n_fft = 512 and M + K - 1 <= 8");
+    Step2Args a;
+    a.X = (const c32*)X;
+    a.mask = nullptr;
+    a.w_loc = (const c32*)w_loc;
+    a.w_glo = (const c32*)w_glo;
+    a.z_out = nullptr;
+    a.yf = nullptr;
+    a.part = nullptr;
+    a.K = K;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    a.chunks = 1;
+    const int n_seg = (c.length + c.hop - 1) / c.hop;
+    const int bpr = (n_seg + 2 * AI_PAIRS - 2) / (2 * AI_PAIRS - 1);
+    const long long nblk = (long long)c.rooms * bpr;
+    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_istft_fused: batch too large");
+    bool launched = false, tried = false;
+#define X_(M_, KR_)                                                                                                  \
+    if (!tried && M == M_ && K == KR_ + 1) {                                                                         \
+        tried = true;                                                                                                \
+        launched = launch_apply_istft<M_, KR_ + 1>(a, out, ctx->d_win, ctx->d_tw, c.length, bpr, dim3((unsigned)nblk), \
+                                                   (hipStream_t)s);                                                  \
+    }
+    DISCO_FOR_MKR(X_)
+#undef X_
+    if (!launched) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_istft_fused: shape does not fit the LDS budget");
+    return check_launch(ctx, "k_step2_apply_istft");
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // whole path
 // ---------------------------------------------------------------------------------------------------------
@@ -739,6 +786,10 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
     if ((rc = solve_from_partials(ctx, chunks, M, w_loc, s))) return rc;
     if ((rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s))) return rc;
     if ((rc = solve_from_partials(ctx, chunks, P2, w_glo, s))) return rc;
+    if (!yf && c.n_fft == 512) {           // yf not asked for: filter + iSTFT in one pass, yf stays on chip
+        rc = disco_step2_apply_istft_fused(ctx, X, w_loc, w_glo, out, s);
+        if (rc != DISCO_E_UNSUPPORTED) return rc;
+    }
     if ((rc = disco_step2_apply_fused(ctx, X, w_loc, w_glo, nullptr, yo, s))) return rc;
     return disco_istft(ctx, yo, G, out, s);
 }

@@ -210,3 +210,157 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_fused(Step2Args a) {
 }
 
 }  // namespace disco
+
+// ---- step-2 filter + iSTFT in one pass over X (tango.py:445 + 528) ------------------------------------------------
+// yf never touches HBM: wave k of a workgroup streams node k's STFT frames two at a time for ALL bins (lane owns
+// f = lane + 64 j), filters them (z exchange through LDS as above), packs the two filtered frames into one complex
+// inverse FFT (fft.h), windows, overlap-adds against the half frame it carries in registers and stores hop segments.
+// A workgroup owns AI_PAIRS frame pairs = 2*AI_PAIRS - 1 hop segments of one room; consecutive workgroups overlap by
+// one frame.  w_loc lives in LDS (shared by the frames of the room), w_glo in registers.
+#include "k_stft.h"
+
+namespace disco {
+
+constexpr int AI_PAIRS = 8;
+
+template <int N, int M, int K>
+struct alignas(16) ApplyIstftShared {
+    c32 buf[K][fft_buf_len<N>()];
+    c32 zbuf[2][K][N / 2 + 1];
+    c32 wl[K][N / 2 + 1][M];
+};
+
+template <int N, int M, int K>
+__global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float* __restrict__ out,
+                                                               const float* __restrict__ win, const c32* __restrict__ tw,
+                                                               int L, int blocks_per_room) {
+    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2, EH = E / 2, NJ = EH + 1, P = M + K - 1;
+    __shared__ ApplyIstftShared<N, M, K> sh;
+    const int k = wave_id(), lane = threadIdx.x & 63;
+    const long long r = blockIdx.x / blocks_per_room;
+    const int s0 = (int)(blockIdx.x % blocks_per_room) * (2 * AI_PAIRS - 1);       // first hop segment == first frame
+    const int T = a.T;
+    const long long g = r * K + k;
+    const c32* Xg = a.X + (g * T * (long long)F) * M;
+    // the room's local filters -> LDS (every wave needs all of them only through z; its own row is read per frame)
+    {
+        const c32* src = a.w_loc + (r * K) * (long long)F * M;
+        c32* dst = &sh.wl[0][0][0];
+        for (int i = threadIdx.x; i < K * F * M; i += 64 * K) dst[i] = src[i];
+    }
+    c32 wg[NJ][P];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int f = (j < EH) ? lane + 64 * j : F - 1;
+#pragma unroll
+        for (int i = 0; i < P; ++i) wg[j][i] = a.w_glo[(g * F + f) * P + i];
+    }
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
+    float w[E];
+    load_window<N>(w, win, lane);
+    float carry[EH];
+#pragma unroll
+    for (int e = 0; e < EH; ++e) carry[e] = 0.f;
+    float* og = out + g * (long long)L;
+    __syncthreads();
+    for (int pr = 0; pr < AI_PAIRS; ++pr) {
+        const int tA = s0 + 2 * pr;
+        c32 yf[2][NJ];
+        // ---- local part of yf and z for both frames
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+            const int t = tA + fr;
+            const bool tv = t < T;
+            const long long tf0 = (long long)(tv ? t : T - 1) * F;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = (j < EH) ? lane + 64 * j : F - 1;
+                c32 x[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const c32 v = Xg[(tf0 + f) * M + i];
+                    x[i] = tv ? v : make_float2(0.f, 0.f);
+                }
+                c32 wl[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) wl[i] = sh.wl[k][f][i];
+                const c32 z = filt_conj<M>(wl, x);
+                if (j < EH || lane == 0) sh.zbuf[fr][k][f] = z;
+                yf[fr][j] = filt_conj<M>(wg[j], x);
+            }
+        }
+        __syncthreads();
+        // ---- remote rows: yf += sum_jj conj(wg[M+jj]) z_j   (concatenate_signals order)
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = (j < EH) ? lane + 64 * j : F - 1;
+#pragma unroll
+                for (int jj = 0; jj < K - 1; ++jj) {
+                    const int jn = jj < k ? jj : jj + 1;
+                    const c32 z = sh.zbuf[fr][jn][f];
+                    const c32 ww = wg[j][M + jj];
+                    yf[fr][j].x = fmaf(ww.x, z.x, fmaf(ww.y, z.y, yf[fr][j].x));
+                    yf[fr][j].y = fmaf(ww.x, z.y, fmaf(-ww.y, z.x, yf[fr][j].y));
+                }
+            }
+        }
+        // ---- V = A~ + i B~ (Hermitian extensions of the two frames), conjugated for the inverse-by-forward trick
+        c32* buf = sh.buf[k];
+        DISCO_LDS_WAR();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < EH || lane == 0) {
+                const int f = (j < EH) ? lane + 64 * j : F - 1;
+                c32 A = yf[0][j], B = yf[1][j];
+                if (f == 0 || f == N / 2) {          // irfft ignores the imaginary part of DC and Nyquist
+                    A.y = 0.f;
+                    B.y = 0.f;
+                }
+                // conj(V[f]) with V[f] = A + iB = (A.x - B.y, A.y + B.x)
+                buf[fft_pad<N>(f)] = make_float2(A.x - B.y, -(A.y + B.x));
+                // conj(V[N-f]) with V[N-f] = conj(A) + i conj(B) = (A.x + B.y, -A.y + B.x)
+                if (f != 0 && f != N / 2) buf[fft_pad<N>(N - f)] = make_float2(A.x + B.y, A.y - B.x);
+            }
+        }
+        DISCO_LDS_RAW();
+        c32 v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = buf[fft_pad<N>(lane + 64 * e)];
+        fft_wave<N>(v, wtw, buf, lane);
+        // time frames: gA[n] = win[n] Re(conj(out))/N = win[n] v.x / N ; gB[n] = -win[n] v.y / N ;  n = lane + 64 e
+        const float inv = 1.0f / N;
+        float gA[E], gB[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            gA[e] = v[e].x * (w[e] * inv);
+            gB[e] = -v[e].y * (w[e] * inv);
+        }
+        // ---- overlap-add: segment (tA-1) = carry + gA[lo], segment tA = gA[hi] + gB[lo], carry <- gB[hi]
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int seg = tA - 1 + which;
+            const bool emit = (which == 1 || pr > 0) && seg >= 0 && seg < T;     // the block's first "carry" segment belongs to its predecessor
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const float hi = which == 0 ? carry[e] : gA[e + EH];
+                const float lo = which == 0 ? gA[e] : gB[e];
+                const long long pos = (long long)seg * H + lane + 64 * e;
+                float wss = w[e + EH] * w[e + EH];
+                if (seg + 1 < T) wss += w[e] * w[e];
+                float val = hi + lo;
+                if (wss > 1.17549435e-38f) val /= wss;
+                if (emit && pos < L) og[pos] = val;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EH; ++e) carry[e] = gB[e + EH];
+        // zbuf is rewritten by the next pair only after every wave has passed the next __syncthreads... but a fast wave
+        // could reach its z stores of pair pr+1 while a slow one still reads zbuf of pair pr: fence the reuse
+        __syncthreads();
+    }
+}
+
+}  // namespace disco

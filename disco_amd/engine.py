@@ -244,6 +244,15 @@ class Engine:
         self._chk(self.lib.disco_step2_apply_fused(self.ctx, px, pl, pg, z.ptr if z else None, yf.ptr, self.stream))
         return yf, z
 
+    def step2_apply_istft_fused(self, X, w_loc, w_glo):
+        """X, w_loc, w_glo -> enhanced time signals (R, K, L); yf stays on chip."""
+        px, kx = self.to_device(X, np.complex64)
+        pl, kl = self.to_device(w_loc, np.complex64)
+        pg, kg = self.to_device(w_glo, np.complex64)
+        out = self.empty((self.R, self.K, self.Lsamp), np.float32)
+        self._chk(self.lib.disco_step2_apply_istft_fused(self.ctx, px, pl, pg, out.ptr, self.stream))
+        return out
+
     def tango_enhance_iterated(self, y, mask_z, mask_w=None, iters=2):
         """DANSE-style continuation of the two-step scheme (BASELINE.json configs[4]; not in the reference): step 2 is
         run `iters` times, each time with z_k <- w_glo,k[:M]^H y_k.  iters=1 is exactly offline_tango's y branch.

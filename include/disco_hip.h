@@ -168,6 +168,12 @@ int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_
 int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc, const disco_c32* w_glo,
                             disco_c32* z_out, disco_c32* yf, disco_stream s);
 
+/* disco_step2_apply_fused followed by disco_istft, without yf ever reaching HBM (tango.py:445 + 528-529): every
+ * wave filters two frames of its node, packs them into one complex inverse FFT, overlap-adds and stores time samples.
+ * out: float [R][K][L].  512-point STFT, M + K - 1 <= 8; DISCO_E_UNSUPPORTED otherwise (use the two calls). */
+int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc, const disco_c32* w_glo,
+                                  float* out, disco_stream s);
+
 /* ---- whole path -------------------------------------------------------------------------------------- */
 
 /* offline_tango(y, ..., mask_for_z='local') restricted to the y branch ("enhanced" outputs), device resident:

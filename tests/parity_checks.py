@@ -222,6 +222,12 @@ def check_step2_fused(make_engine, R=2, K=4, M=4, L=4096, n_fft=512, seed=5):
     errs['yf'] = relerr(yf.numpy(), yf_ref)
     errs['z2'] = relerr(z2.numpy(), z_ref)
     assert errs['yf'] < 2e-6 and errs['z2'] < 2e-6, errs
+    if n_fft == 512 and K > 1:
+        # filter + iSTFT in one kernel vs the two kernels it replaces
+        t_fused = eng.step2_apply_istft_fused(X, w_loc, w_glo).numpy()
+        t_staged = eng.istft(yf.reshape(R * K, T, F)).numpy().reshape(R, K, L)
+        errs['apply_istft'] = maxrel(t_fused, t_staged)
+        assert errs['apply_istft'] < 3e-6, errs
     return errs
 
 

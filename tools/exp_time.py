@@ -45,6 +45,7 @@ calls = {
  'stftcov': lambda: lib.disco_stft_cov_fused(eng.ctx, p(y), p(mask), p(X), p(Rss), p(Rnn), None),
  's2cov': lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), None, p(Rss), p(Rnn), None),
  's2cov_z': lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), p(z), p(Rss), p(Rnn), None),
+ 's2ai': lambda: lib.disco_step2_apply_istft_fused(eng.ctx, p(X), p(w), p(w), p(out), None),
  's2apply': lambda: lib.disco_step2_apply_fused(eng.ctx, p(X), p(w), p(w), None, p(yf), None),
 }
 res = {}
