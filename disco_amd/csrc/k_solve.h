@@ -22,6 +22,23 @@ namespace disco {
 constexpr double SOLVE_EPS = 2.220446049250313e-16;     // internal_formulas.py:6  sys.float_info.epsilon
 constexpr double SOLVE_ETA = 1e6;                       // internal_formulas.py:7
 
+// 1/sqrt(x) and 1/x in float64 from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~26 good bits) plus two Newton steps:
+// ~9 / ~5 instructions instead of the ~50 / ~25 of the IEEE-exact sqrt / divide expansions, 1-2 ulp.  The Jacobi
+// rotations only need cs^2 + sn^2 = 1 and |phase| = 1 to rounding, which these deliver; the inputs are O(1)
+// covariance entries, far from the denormal / overflow corners the exact expansions exist for.
+__device__ __forceinline__ double rsqrt64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+__device__ __forceinline__ double rcp64(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+
 template <int P>
 struct SolveGeom {
     static constexpr int G = P <= 4 ? 4 : (P <= 8 ? 8 : 16);
@@ -104,19 +121,21 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
     __syncthreads();
 
     // ---- Cholesky, one column per step; every lane keeps the (real) diagonal in registers
-    double dd[P];
+    double dd[P], rdd[P];
 #pragma unroll
     for (int c = 0; c < P; ++c) {
         double d2 = Lm[c][c].x;
 #pragma unroll
         for (int k = 0; k < c; ++k) d2 -= Lm[c][k].x * Lm[c][k].x + Lm[c][k].y * Lm[c][k].y;
-        const double d = sqrt(fmax(d2, 1e-300));
-        dd[c] = d;
+        const double d2c = fmax(d2, 1e-300);
+        const double rd = rsqrt64(d2c);                 // 1 / L[c][c]
+        dd[c] = d2c * rd;                               //     L[c][c]
+        rdd[c] = rd;
         if (j > c && j < P) {
             c64 s = Lm[j][c];
 #pragma unroll
             for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lm[j][k], Lm[c][k]));
-            Lm[j][c] = zscale(s, 1.0 / d);
+            Lm[j][c] = zscale(s, rd);
         }
         __syncthreads();
     }
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
         c64 a = make_double2((double)rowA[i].x, -(double)rowA[i].y);
 #pragma unroll
         for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[i][k], y[k]));
-        y[i] = zscale(a, 1.0 / dd[i]);
+        y[i] = zscale(a, rdd[i]);
     }
     if (j < P) {
 #pragma unroll
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
         if (j < P) a = make_double2(Ym[j][i].x, -Ym[j][i].y);
 #pragma unroll
         for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[i][k], g[k]));
-        g[i] = zscale(a, 1.0 / dd[i]);
+        g[i] = zscale(a, rdd[i]);
     }
 
     // ---- one-sided Jacobi, round-robin over G players (lanes >= P carry zero columns)
@@ -167,23 +186,28 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
                 o[i].y = __shfl(g[i].y, pj, G);
             }
             const bool lo = j < pj;                       // own column plays "p" (first), partner's plays "q"
-            double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+            // |own|^2, |other|^2 and own^H other, then ordered as (alpha, beta, gamma) = (|gp|^2, |gq|^2, gp^H gq):
+            // four selects on scalars instead of 2P selects on the columns
+            double n_own = 0.0, n_oth = 0.0, cr = 0.0, ci = 0.0;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                const c64 gp = lo ? g[i] : o[i], gq = lo ? o[i] : g[i];
-                alpha += gp.x * gp.x + gp.y * gp.y;
-                beta += gq.x * gq.x + gq.y * gq.y;
-                gr += gp.x * gq.x + gp.y * gq.y;          // gamma = gp^H gq
-                gi += gp.x * gq.y - gp.y * gq.x;
+                n_own += g[i].x * g[i].x + g[i].y * g[i].y;
+                n_oth += o[i].x * o[i].x + o[i].y * o[i].y;
+                cr += g[i].x * o[i].x + g[i].y * o[i].y;
+                ci += g[i].x * o[i].y - g[i].y * o[i].x;
             }
+            const double alpha = lo ? n_own : n_oth, beta = lo ? n_oth : n_own;
+            const double gr = cr, gi = lo ? ci : -ci;     // gq^H gp = conj(gp^H gq)
             const double g2 = gr * gr + gi * gi;
             if (g2 > 1e-28 * alpha * beta && g2 > 0.0) {
                 if (g2 > 1e-14 * alpha * beta) rotated = 1;
-                const double ag = sqrt(g2);
-                const double zeta = (beta - alpha) / (2.0 * ag);
-                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                const c64 ph = make_double2(gr / ag, gi / ag);        // e^{i phi}
+                const double rg = rsqrt64(g2);                                  // 1 / |gamma|
+                const double zeta = 0.5 * (beta - alpha) * rg;
+                const double hz = 1.0 + zeta * zeta;
+                double t = rcp64(fabs(zeta) + hz * rsqrt64(hz));
+                t = zeta >= 0.0 ? t : -t;
+                const double cs = rsqrt64(1.0 + t * t), sn = cs * t;
+                const c64 ph = make_double2(gr * rg, gi * rg);                  // e^{i phi}
                 // gp' = cs gp - sn e^{-i phi} gq ;  gq' = sn e^{i phi} gp + cs gq
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
@@ -216,12 +240,13 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
         }
     }
     c64 v0[P];
-    const double d0 = sqrt(best);
+    const double rb = best > 0.0 ? rsqrt64(best) : 0.0;
+    const double d0 = best * rb;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         v0[i].x = __shfl(g[i].x, bj, G);
         v0[i].y = __shfl(g[i].y, bj, G);
-        if (d0 > 0.0) v0[i] = zscale(v0[i], 1.0 / d0);
+        if (d0 > 0.0) v0[i] = zscale(v0[i], rb);
         else v0[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
     }
 
@@ -232,7 +257,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
         c64 a = v0[i];
 #pragma unroll
         for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Lm[k][i].x, -Lm[k][i].y), q[k]));
-        q[i] = zscale(a, 1.0 / dd[i]);
+        q[i] = zscale(a, rdd[i]);
     }
     const double dcl = fmin(fmax(d0, SOLVE_EPS), SOLVE_ETA);
     const c64 gsc = make_double2(dd[0] * v0[0].x, -dd[0] * v0[0].y);     // L[0,0] conj(v0[0]) = (Q^-1)[0,0]

@@ -165,6 +165,8 @@ static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only 
 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
+static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
+static inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
