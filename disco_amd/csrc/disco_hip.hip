@@ -465,13 +465,13 @@ extern "C" int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const di
 // ---------------------------------------------------------------------------------------------------------
 template <int N>
 static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, const float* mask, c32* X, float4* part,
-                            const float* win, const c32* tw, int L, int T, int pad_mode, int chunks) {
+                            const float* win, const c32* tw, int L, int T, int pad_mode, int chunks, int runw) {
     const dim3 block(64 * STFT_WAVES);
     switch (M) {
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
-                           chunks);                                                                                     \
+                           chunks, runw);                                                                               \
         return true;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6)
 #undef C_
@@ -481,7 +481,7 @@ static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, co
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
-                           chunks);                                                                                     \
+                           chunks, runw);                                                                               \
         return true;
             C_(7) C_(8)
 #undef C_
@@ -503,8 +503,12 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
         if (rc0) return rc0;
         return cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s);
     }
-    const int chunks = (ctx->T + STFT_WAVES * SC_RUNW - 1) / (STFT_WAVES * SC_RUNW);
     const long long G = (long long)c.rooms * c.nodes;
+    // frames per wave: as long as possible (<= 80) while leaving >= ~2048 workgroups for the chip
+    const long long chunks_wanted = std::max<long long>(1, (2048 + G - 1) / G);
+    int runw = (int)((ctx->T + STFT_WAVES * chunks_wanted - 1) / (STFT_WAVES * chunks_wanted));
+    runw = std::min(80, std::max(8, runw));
+    const int chunks = (ctx->T + STFT_WAVES * runw - 1) / (STFT_WAVES * runw);
     const int NP = M * (M + 1) / 2;
     int rc = ensure_scratch(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
     if (rc) return rc;
@@ -512,9 +516,9 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
     const dim3 grid((unsigned)(G * chunks));
     const bool ok = c.n_fft == 512
         ? launch_stft_cov<512>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
-                               ctx->T, c.pad_mode, chunks)
+                               ctx->T, c.pad_mode, chunks, runw)
         : launch_stft_cov<1024>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
-                                ctx->T, c.pad_mode, chunks);
+                                ctx->T, c.pad_mode, chunks, runw);
     if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: unsupported mic count");
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
@@ -632,10 +636,10 @@ extern "C" int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const
 }
 
 template <int M, int K>
-static bool launch_apply_istft(const Step2Args& a, float* out, const float* win, const c32* tw, int L, int bpr, dim3 grid,
+static bool launch_apply_istft(const Step2Args& a, float* out, const float* win, const c32* tw, int L, int bpr, int pairs, dim3 grid,
                                hipStream_t st) {
     if constexpr (sizeof(ApplyIstftShared<512, M, K>) <= 160 * 1024) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_apply_istft<512, M, K>), grid, dim3(64 * K), 0, st, a, out, win, tw, L, bpr);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_apply_istft<512, M, K>), grid, dim3(64 * K), 0, st, a, out, win, tw, L, bpr, pairs);
         return true;
     } else {
         return false;
@@ -662,14 +666,18 @@ extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X,
     a.F = ctx->F;
     a.chunks = 1;
     const int n_seg = (c.length + c.hop - 1) / c.hop;
-    const int bpr = (n_seg + 2 * AI_PAIRS - 2) / (2 * AI_PAIRS - 1);
+    // frame pairs per workgroup: as many as possible (<= 64) while leaving >= ~2048 workgroups
+    const long long bpr_wanted = std::max<long long>(1, (2048 + c.rooms - 1) / c.rooms);
+    int pairs = (int)(((n_seg + bpr_wanted - 1) / bpr_wanted + 2) / 2);
+    pairs = std::min(64, std::max(4, pairs));
+    const int bpr = (n_seg + 2 * pairs - 2) / (2 * pairs - 1);
     const long long nblk = (long long)c.rooms * bpr;
     if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_istft_fused: batch too large");
     bool launched = false, tried = false;
 #define X_(M_, KR_)                                                                                                  \
     if (!tried && M == M_ && K == KR_ + 1) {                                                                         \
         tried = true;                                                                                                \
-        launched = launch_apply_istft<M_, KR_ + 1>(a, out, ctx->d_win, ctx->d_tw, c.length, bpr, dim3((unsigned)nblk), \
+        launched = launch_apply_istft<M_, KR_ + 1>(a, out, ctx->d_win, ctx->d_tw, c.length, bpr, pairs, dim3((unsigned)nblk), \
                                                    (hipStream_t)s);                                                  \
     }
     DISCO_FOR_MKR(X_)

@@ -215,13 +215,13 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_fused(Step2Args a) {
 // yf never touches HBM: wave k of a workgroup streams node k's STFT frames two at a time for ALL bins (lane owns
 // f = lane + 64 j), filters them (z exchange through LDS as above), packs the two filtered frames into one complex
 // inverse FFT (fft.h), windows, overlap-adds against the half frame it carries in registers and stores hop segments.
-// A workgroup owns AI_PAIRS frame pairs = 2*AI_PAIRS - 1 hop segments of one room; consecutive workgroups overlap by
+// A workgroup owns `pairs` frame pairs = 2*pairs - 1 hop segments of one room; consecutive workgroups overlap by
 // one frame.  w_loc lives in LDS (shared by the frames of the room), w_glo in registers.
 #include "k_stft.h"
 
 namespace disco {
 
-constexpr int AI_PAIRS = 8;
+// frame pairs per workgroup are a launch parameter (`pairs`): 2*pairs - 1 hop segments per workgroup
 
 template <int N, int M, int K>
 struct alignas(16) ApplyIstftShared {
@@ -233,12 +233,12 @@ struct alignas(16) ApplyIstftShared {
 template <int N, int M, int K>
 __global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float* __restrict__ out,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
-                                                               int L, int blocks_per_room) {
+                                                               int L, int blocks_per_room, int pairs) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2, EH = E / 2, NJ = EH + 1, P = M + K - 1;
     __shared__ ApplyIstftShared<N, M, K> sh;
     const int k = wave_id(), lane = threadIdx.x & 63;
     const long long r = blockIdx.x / blocks_per_room;
-    const int s0 = (int)(blockIdx.x % blocks_per_room) * (2 * AI_PAIRS - 1);       // first hop segment == first frame
+    const int s0 = (int)(blockIdx.x % blocks_per_room) * (2 * pairs - 1);       // first hop segment == first frame
     const int T = a.T;
     const long long g = r * K + k;
     const c32* Xg = a.X + (g * T * (long long)F) * M;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float
     for (int e = 0; e < EH; ++e) carry[e] = 0.f;
     float* og = out + g * (long long)L;
     __syncthreads();
-    for (int pr = 0; pr < AI_PAIRS; ++pr) {
+    for (int pr = 0; pr < pairs; ++pr) {
         const int tA = s0 + 2 * pr;
         c32 yf[2][NJ];
         // ---- local part of yf and z for both frames

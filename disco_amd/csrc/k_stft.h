@@ -19,9 +19,6 @@ namespace disco {
 #ifndef DISCO_STFT_RUN
 #define DISCO_STFT_RUN 16
 #endif
-#ifndef DISCO_EXP
-#define DISCO_EXP 0            // kernel-ablation switch for tools/exp_*.py only; 0 in every shipped build
-#endif
 constexpr int STFT_WAVES = DISCO_STFT_WAVES;     // waves per block; each streams its own run of frames
 constexpr int STFT_RUN = DISCO_STFT_RUN;         // consecutive frames per wave
 
@@ -131,7 +128,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restric
                 raw[p][e] = raw[p][e + EH];
                 raw[p][e + EH] = nxt[p][e];
             }
-        if (!(DISCO_EXP & 1) || A[0][0].x == 1.2345f) {
+        {
             c32* Xo = X + ((g * T + t) * (long long)F) * chans;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -321,7 +318,8 @@ namespace disco {
 // every thread copies its bin's M-vector to X (coalesced 8*M*64-byte wave stores) and folds it into the
 // P(P+1)/2 covariance accumulators it keeps in registers for the whole run.  Saves the separate covariance
 // pass over X (8*M*F bytes per node-frame).
-constexpr int SC_RUNW = 20;              // frames per wave per workgroup (a workgroup covers 4 * SC_RUNW frames)
+// frames per wave per workgroup are a launch parameter (`runw`; a workgroup covers 4 * runw frames): long runs amortise the
+// first-frame load and the partial-sum write-out (80 is best at C3), short ones keep small batches spread over the chip
 
 template <int N, int CHP>
 struct alignas(16) StftCovShared {
@@ -336,7 +334,7 @@ template <int N, int M>
 __global__ __launch_bounds__(64 * STFT_WAVES, DISCO_SC_WPE) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
                                                                c32* __restrict__ X, float4* __restrict__ part,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
-                                                               int L, int T, int pad_mode, int chunks) {
+                                                               int L, int T, int pad_mode, int chunks, int runw) {
     static_assert(STFT_WAVES == 4, "one bin per thread needs 4 waves for 256 bins");
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, CHP = (M + 1) / 2, MP = 2 * CHP;
     constexpr int NP = M * (M + 1) / 2;
@@ -345,9 +343,9 @@ __global__ __launch_bounds__(64 * STFT_WAVES, DISCO_SC_WPE) void k_stft_cov(cons
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63;
     const long long g = blockIdx.x / chunks;
     const int c = (int)(blockIdx.x % chunks);
-    const int tb = c * STFT_WAVES * SC_RUNW;
-    const int ts = tb + wave * SC_RUNW;
-    const int te = min(T, ts + SC_RUNW);
+    const int tb = c * STFT_WAVES * runw;
+    const int ts = tb + wave * runw;
+    const int te = min(T, ts + runw);
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     float w[E];
@@ -386,14 +384,14 @@ __global__ __launch_bounds__(64 * STFT_WAVES, DISCO_SC_WPE) void k_stft_cov(cons
         ny_j = i + q;
     }
     const float* mg = mask + g * T * (long long)F;
-    for (int it = 0; it < SC_RUNW; ++it) {
+    for (int it = 0; it < runw; ++it) {
         const int t = ts + it;
         const bool valid = t < te;
         // masks of the 4 frames this thread will reduce after the barrier (requested early)
         float mv[STFT_WAVES][BPT], mny[STFT_WAVES];
 #pragma unroll
         for (int ww = 0; ww < STFT_WAVES; ++ww) {
-            const int t2 = min(tb + ww * SC_RUNW + it, T - 1);          // clamped: unconditional loads, used only when valid
+            const int t2 = min(tb + ww * runw + it, T - 1);          // clamped: unconditional loads, used only when valid
 #pragma unroll
             for (int b = 0; b < BPT; ++b) mv[ww][b] = mg[(long long)t2 * F + tid + 256 * b];
             mny[ww] = mg[(long long)t2 * F + F - 1];
@@ -428,8 +426,8 @@ __global__ __launch_bounds__(64 * STFT_WAVES, DISCO_SC_WPE) void k_stft_cov(cons
         // ---- one thread per bin: copy out + reduce the (up to) 4 frames of this iteration
 #pragma unroll
         for (int ww = 0; ww < STFT_WAVES; ++ww) {
-            const int t2 = tb + ww * SC_RUNW + it;
-            if (t2 < min(T, tb + (ww + 1) * SC_RUNW)) {          // workgroup-uniform
+            const int t2 = tb + ww * runw + it;
+            if (t2 < min(T, tb + (ww + 1) * runw)) {          // workgroup-uniform
                 c32* Xo = X + ((g * T + t2) * (long long)F) * M;
                 if ((M & 1) == 0) {
                     // even M: the tile row IS the X row (F*M complex, contiguous) -> straight 16-B-per-lane copy, every
