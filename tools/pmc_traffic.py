@@ -12,7 +12,7 @@ import json
 import sys
 
 STAGE_OF = {'k_stft_cov<': 'stft_cov1', 'k_stft<': 'stft', 'k_mask_oracle<': 'mask_oracle', 'k_istft<': 'istft',
-            'k_step2_cov_fused<': 'step2_cov', 'k_step2_apply_fused<': 'step2_apply', 'k_cov<': 'cov', 'k_apply<': 'apply',
+            'k_step2_cov_fused<': 'step2_cov', 'k_step2_apply_istft<': 'step2_apply_istft', 'k_step2_apply_fused<': 'step2_apply', 'k_cov<': 'cov', 'k_apply<': 'apply',
             'k_gevd_mwf_r1<': 'solve'}
 
 raw = json.load(open(sys.argv[1]))
