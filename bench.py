@@ -77,6 +77,8 @@ def main():
     ap.add_argument('--mics', type=int, default=4)
     ap.add_argument('--length', type=int, default=160000)
     ap.add_argument('--n-fft', type=int, default=512)
+    ap.add_argument('--mask', default='oracle', choices=['oracle', 'crnn'],
+                    help="'crnn': BASELINE configs[3] -- randomly initialised CRNN mask estimators (PyTorch-ROCm) in the loop")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--pmc-calibrate', action='store_true', help='also run a 4 GiB device copy (known bytes) for PMC calibration')
@@ -113,7 +115,17 @@ def main():
     ws = torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
     G = R * K
 
+    if args.mask == 'crnn':
+        from disco_amd.dnn.crnn import build_crnn
+        from disco_amd.dnn.inloop import tango_enhance_dnn
+        torch.manual_seed(0)
+        model_z = build_crnn(1, device=dev)
+        model_w = build_crnn(K, device=dev) if K > 1 else None
+
     def step():
+        if args.mask == 'crnn':
+            out.copy_(tango_enhance_dnn(eng, y, model_z, model_w))
+            return
         eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), None))
         eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
                                          None, None, ws.data_ptr(), ws.numel(), None))
@@ -144,7 +156,7 @@ def main():
 
     # ---- per-stage timing with HIP events on the launch stream (rank 0, N=1), for the roofline object
     roofline, stages = None, None
-    if rank == 0 and not args.no_stage_timing:
+    if rank == 0 and not args.no_stage_timing and args.mask == 'oracle':
         X = torch.empty((R, K, T, F, M), dtype=torch.complex64, device=dev)
         z = torch.empty((R, K, T, F), dtype=torch.complex64, device=dev)
         yf = torch.empty_like(z)
@@ -217,14 +229,15 @@ def main():
         cpu = cpu_baseline(K, M, Ls)
 
     if rank == 0:
+        mask_desc = 'oracle irm1 mask' if args.mask == 'oracle' else 'CRNN masks in the loop (random weights, fp32 PyTorch-ROCm)'
         line = {
             'metric': 'STFT node-frames/s, whole MWF path (STFT->mask->cov->GEVD-MWF->z exchange->MWF->iSTFT)',
             'value': value, 'unit': 'node-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'x_realtime': x_rt,
-            'config': {'workload': f'C3: {R} rooms/GPU x {K} nodes x {M} mics, 16 kHz, L={Ls}, {N}-pt STFT hop {H}, '
-                                   f'oracle irm1 mask, two-step Tango (mask_for_z=local), outputs=enhanced',
+            'config': {'workload': f'{"C3" if args.mask == "oracle" else "C4"}: {R} rooms/GPU x {K} nodes x {M} mics, 16 kHz, L={Ls}, '
+                                   f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced',
                        'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
                        'parallelism': f'rooms sharded over {world} GPU(s), no data-path collective'},
             'roofline': roofline, 'cpu_baseline': cpu, 'stages': stages,

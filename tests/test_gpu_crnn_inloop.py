@@ -1,0 +1,64 @@
+"""BASELINE.json configs[3] plumbing: CRNN masks (PyTorch-ROCm) in the loop around the HIP kernels."""
+import numpy as np
+import pytest
+
+import parity_checks as pc
+from disco_amd import _lib, synth
+from disco_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_model(n_ch, seed, device):
+    import torch
+    from torch import nn
+    from disco_amd.dnn.crnn import build_crnn
+    torch.manual_seed(seed)
+    m = build_crnn(n_ch=n_ch)
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+    with torch.no_grad():                     # spread the (random) masks over (0, 1): masks stuck near 0.5 would make
+        m.ff.layers[0].weight.mul_(40.0)      # Rss ~ Rnn, a degenerate eigenproblem no implementation can reproduce tightly
+    return m.to(device).eval()
+
+
+@pytest.mark.parametrize('K,M,two_models', [(3, 2, True), (4, 4, False), (1, 4, True)])
+def test_crnn_in_loop_vs_oracle(K, M, two_models):
+    import torch
+    from disco_amd.dnn.inloop import tango_enhance_dnn
+    from oracle import stft_oracle as so
+    from oracle import tango_oracle as to
+    R, L = 2, 24000
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    eng = Engine(rooms=R, nodes=K, mics=M, length=L, lib=_lib.load())
+    dev = torch.device('cuda', 0)
+    model_z = _rand_model(1, 1, dev)
+    model_w = _rand_model(K, 2, dev) if (two_models and K > 1) else None
+    out, mz, mw = tango_enhance_dnn(eng, torch.from_numpy(y).to(dev), model_z, model_w, want_masks=True)
+    out, mz, mw = out.cpu().numpy(), mz.cpu().numpy(), mw.cpu().numpy()
+    assert np.all((mz >= 0) & (mz <= 1)) and np.all(np.isfinite(out))
+    cpu_z = _rand_model(1, 1, 'cpu').double()
+    for r in range(R):
+        # 1) the MWF around the masks: feed the SAME masks to the float64 oracle
+        masks = ([mz[r, k].T.astype(np.float64) for k in range(K)], [mw[r, k].T.astype(np.float64) for k in range(K)])
+        o = to.offline_tango_vec(y[r], s[r], n[r], masks=masks, precision='f64', solver='eigh')
+        for k in range(K):
+            ref = so.istft(o['yf'][k], L, work_dtype=np.float64)
+            # randomly initialised networks give masks close to 0.5 everywhere, i.e. Rss almost proportional to Rnn and a
+            # nearly degenerate generalized eigenproblem: the 1e-4 bar of the oracle-mask tests relaxes to 1e-3 here
+            assert pc.relerr(out[r, k], ref) < 1e-3, (r, k, pc.relerr(out[r, k], ref))
+        # 2) the step-1 masks themselves: the same network in float64 on the oracle's |Y_ref|
+        mag = np.stack([np.abs(o['Y'][k][0]).T for k in range(K)])[:, None]            # (K, 1, T, F)
+        ref_mz = cpu_z.predict_masks(torch.from_numpy(mag)).numpy()
+        assert np.abs(ref_mz - mz[r]).max() < 2e-4
+        # 3) the step-2 masks: channel order [|Y_k|, |z_j| j != k] (tango.py:158-186, 391)
+        if model_w is not None:
+            cpu_w = _rand_model(K, 2, 'cpu').double()
+            zmag = [np.abs(o['z_y'][j]).T for j in range(K)]
+            inp = np.stack([np.stack([np.abs(o['Y'][k][0]).T] + [zmag[j] for j in range(K) if j != k]) for k in range(K)])
+            ref_mw = cpu_w.predict_masks(torch.from_numpy(inp)).numpy()
+            assert np.abs(ref_mw - mw[r]).max() < 2e-3          # |z| carries the (bounded) step-1 mask differences
+        else:
+            assert np.array_equal(mw, mz)                        # tango.py:388-389
