@@ -34,6 +34,7 @@ PROTOTYPES = {
     'disco_n_frames': (_int, [_vp]),
     'disco_n_freq': (_int, [_vp]),
     'disco_workspace_bytes': (_sz, [_vp]),
+    'disco_set_node_shard': (_int, [_vp, _int, _int]),
     'disco_dev_alloc': (_int, [_vp, _sz, C.POINTER(_vp)]),
     'disco_dev_free': (_int, [_vp, _vp]),
     'disco_h2d': (_int, [_vp, _vp, _vp, _sz, _vp]),

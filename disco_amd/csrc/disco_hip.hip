@@ -26,6 +26,7 @@ struct disco_ctx {
     void* scratch;            // covariance chunk partials (grown on demand)
     size_t scratch_bytes;
     int pending_chunks, pending_P;   // geometry of the partials currently in `scratch` (0 = none)
+    int k0, Kl;                      // node shard: this context holds nodes [k0, k0 + Kl) of every room (default 0, K)
     char err[512];
 };
 
@@ -99,6 +100,8 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->scratch_bytes = 0;
     ctx->pending_chunks = 0;
     ctx->pending_P = 0;
+    ctx->k0 = 0;
+    ctx->Kl = cfg->nodes;
     ctx->err[0] = 0;
     const int N = cfg->n_fft;
     std::vector<float> win(N);
@@ -131,6 +134,18 @@ extern "C" void disco_destroy(disco_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
 }
+
+extern "C" int disco_set_node_shard(disco_ctx* ctx, int first_node, int node_count) {
+    if (!ctx) return DISCO_E_ARG;
+    if (first_node < 0 || node_count < 1 || first_node + node_count > ctx->cfg.nodes)
+        return fail(ctx, DISCO_E_ARG, "disco_set_node_shard: shard outside [0, nodes)");
+    ctx->k0 = first_node;
+    ctx->Kl = node_count;
+    ctx->pending_chunks = 0;
+    return 0;
+}
+
+static inline bool sharded(const disco_ctx* ctx) { return ctx->Kl != ctx->cfg.nodes; }
 
 extern "C" int disco_n_frames(const disco_ctx* ctx) { return ctx ? ctx->T : DISCO_E_ARG; }
 extern "C" int disco_n_freq(const disco_ctx* ctx) { return ctx ? ctx->F : DISCO_E_ARG; }
@@ -288,7 +303,7 @@ static int ensure_scratch(disco_ctx* ctx, size_t bytes) {
 }
 
 static int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
-    const long long n_gf = (long long)ctx->cfg.rooms * ctx->cfg.nodes * ctx->F;
+    const long long n_gf = (long long)ctx->cfg.rooms * ctx->Kl * ctx->F;
     hipLaunchKernelGGL(k_cov_finalize, dim3((unsigned)std::min<long long>((n_gf + 127) / 128, 65535)), dim3(128), 0,
                        (hipStream_t)s, (const float4*)ctx->scratch, (c32*)Rss, (c32*)Rnn, n_gf, ctx->F, chunks, P,
                        1.0f / (float)ctx->T);
@@ -305,7 +320,7 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     if (KR > 0 && (!Zs || !Zn)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Zs/Zn required when P > M");
     if (P > CB_PMAX || M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: P > 16 or M > 8");
     const int chunks = cov_chunks(ctx);
-    const long long G = (long long)c.rooms * c.nodes;
+    const long long G = (long long)c.rooms * ctx->Kl;
     const int NP = P * (P + 1) / 2;
     const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
     int rc = ensure_scratch(ctx, need);
@@ -321,6 +336,8 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     a.F = ctx->F;
     a.chunks = chunks;
     a.mask_remote = mask_remote;
+    a.Kl = ctx->Kl;
+    a.k0 = ctx->k0;
     const bool same = (Zs == Zn);
     const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
     bool launched = false;
@@ -418,7 +435,7 @@ extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w,
     src.F = ctx->F;
     src.chunks = ctx->pending_chunks;
     src.inv_T = 1.0f / (float)ctx->T;
-    return solve_dispatch(ctx, src, (int64_t)ctx->cfg.rooms * ctx->cfg.nodes * ctx->F, ctx->pending_P, mu, w, t1, s);
+    return solve_dispatch(ctx, src, (int64_t)ctx->cfg.rooms * ctx->Kl * ctx->F, ctx->pending_P, mu, w, t1, s);
 }
 
 extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, int P, int conj_w,
@@ -430,7 +447,7 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_apply: P must be M or M + K - 1");
     if (KR > 0 && !Z) return fail(ctx, DISCO_E_ARG, "disco_apply: Z required when P > M");
     if (P > CB_PMAX) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_apply: P > 16 not supported");
-    const long long G = (long long)c.rooms * c.nodes;
+    const long long G = (long long)c.rooms * ctx->Kl;
     const long long TF = (long long)ctx->T * ctx->F;
     int bpn = (int)std::min<long long>((TF + 255) / 256, 64);
     while ((long long)bpn * G > 0x7fffffffLL && bpn > 1) bpn >>= 1;
@@ -439,14 +456,15 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
 #define X_(M_, KR_)                                                                                                  \
     if (!launched && M == M_ && KR == KR_) {                                                                         \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply<M_, KR_>), grid, block, 0, (hipStream_t)s, (const c32*)X,         \
-                           (const c32*)Z, (const c32*)w, (c32*)out, c.nodes, ctx->T, ctx->F, conj_w, bpn);           \
+                           (const c32*)Z, (const c32*)w, (c32*)out, c.nodes, ctx->T, ctx->F, conj_w, bpn, ctx->Kl,   \
+                           ctx->k0);                                                                                 \
         launched = true;                                                                                             \
     }
     DISCO_FOR_MKR(X_)
 #undef X_
     if (!launched)
         hipLaunchKernelGGL(k_apply_generic, grid, block, 0, (hipStream_t)s, (const c32*)X, (const c32*)Z, (const c32*)w,
-                           (c32*)out, M, KR, c.nodes, ctx->T, ctx->F, conj_w, bpn);
+                           (c32*)out, M, KR, c.nodes, ctx->T, ctx->F, conj_w, bpn, ctx->Kl, ctx->k0);
     return check_launch(ctx, "k_apply");
 }
 
@@ -454,7 +472,7 @@ extern "C" int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const di
     if (!ctx) return DISCO_E_ARG;
     if (!X || !z || !zn) return fail(ctx, DISCO_E_ARG, "disco_noise_residual: null argument");
     const disco_cfg& c = ctx->cfg;
-    const long long n = (long long)c.rooms * c.nodes * ctx->T * ctx->F;
+    const long long n = (long long)c.rooms * ctx->Kl * ctx->T * ctx->F;
     hipLaunchKernelGGL(k_noise_residual, dim3((unsigned)std::min<long long>((n + 255) / 256, 16384)), dim3(256), 0,
                        (hipStream_t)s, (const c32*)X, (const c32*)z, (c32*)zn, n, c.mics, c.ref_mic);
     return check_launch(ctx, "k_noise_residual");
@@ -495,6 +513,7 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
 
 static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s) {
     if (!y || !mask_z || !X) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics;
     if (M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: more than 8 mics per node");
@@ -551,6 +570,7 @@ static int step2_chunks(const disco_ctx* ctx, int tiles_plus_1) {
 static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
                               disco_c32* z_out, int* chunks_out, disco_stream s) {
     if (!X || !mask_w || !w_loc) return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused: null argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes, P = M + K - 1;
     if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_cov_fused: M + K - 1 > 8 not supported yet");
@@ -604,6 +624,7 @@ extern "C" int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const
                                        disco_c32* z_out, disco_c32* yf, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
     if (!X || !w_loc || !w_glo || !yf) return fail(ctx, DISCO_E_ARG, "disco_step2_apply_fused: null argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes, P = M + K - 1;
     if (P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_fused: M + K - 1 > 8 not supported yet");
@@ -650,6 +671,7 @@ extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X,
                                              const disco_c32* w_glo, float* out, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
     if (!X || !w_loc || !w_glo || !out) return fail(ctx, DISCO_E_ARG, "disco_step2_apply_istft_fused: null argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes, P = M + K - 1;
     if (c.n_fft != 512 || P > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_istft_fused: needs n_fft = 512 and M + K - 1 <= 8");
@@ -732,6 +754,7 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
                                    disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
     if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: null argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: node shard active, drive the staged calls around an all-gather of z");
     const disco_cfg& c = ctx->cfg;
     const WsLayout l = ws_layout(ctx);
     char* ws = (char*)workspace;

@@ -9,12 +9,12 @@ namespace disco {
 template <int M, int KR>
 __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const c32* __restrict__ Z,
                                                 const c32* __restrict__ w, c32* __restrict__ out,
-                                                int K, int T, int F, int conj_w, int blocks_per_node) {
+                                                int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0) {
     constexpr int P = M + KR;
-    const long long g = blockIdx.x / blocks_per_node;
+    const long long g = blockIdx.x / blocks_per_node;            // local unit r*Kl + kl (see CovArgs)
     const int b = (int)(blockIdx.x % blocks_per_node);
-    const long long r = g / K;
-    const int k = (int)(g % K);
+    const long long r = g / Kl;
+    const int k = k0 + (int)(g % Kl);
     const long long TF = (long long)T * F;
     const float sgn = conj_w ? -1.f : 1.f;
     const c32* wg = w + g * F * (long long)P;
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const 
 // re-read from L1 per element.
 __global__ __launch_bounds__(256) void k_apply_generic(const c32* __restrict__ X, const c32* __restrict__ Z,
                                                         const c32* __restrict__ w, c32* __restrict__ out, int M, int KR,
-                                                        int K, int T, int F, int conj_w, int blocks_per_node) {
+                                                        int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0) {
     const int P = M + KR;
     const long long g = blockIdx.x / blocks_per_node;
     const int b = (int)(blockIdx.x % blocks_per_node);
-    const long long r = g / K;
-    const int k = (int)(g % K);
+    const long long r = g / Kl;
+    const int k = k0 + (int)(g % Kl);
     const long long TF = (long long)T * F;
     const float sgn = conj_w ? -1.f : 1.f;
     const c32* wg = w + g * F * (long long)P;

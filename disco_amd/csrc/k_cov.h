@@ -40,8 +40,12 @@ struct CovArgs {
     const float* mask;   // [R][K][T][F]
     const c32* Zs;       // [R][K][T][F] or null
     const c32* Zn;       // [R][K][T][F] or null
-    float4* part;        // [R*K][chunks][F][NP] of (Rss.re, Rss.im, Rnn.re, Rnn.im) sums
+    float4* part;        // [R*Kl][chunks][F][NP] of (Rss.re, Rss.im, Rnn.re, Rnn.im) sums
     int K, T, F, chunks, mask_remote;
+    // node shard (disco_set_node_shard): this context holds nodes [k0, k0 + Kl) of every room.  X, mask and part are
+    // indexed by the LOCAL unit g = r*Kl + kl; only the remote rows Zs/Zn are indexed by global node (they come from the
+    // all-gather of z).  Kl == K, k0 == 0 when all nodes of a room live here.
+    int Kl, k0;
 };
 
 template <int M, int KR, bool SAMEZ>
@@ -49,8 +53,8 @@ __device__ __forceinline__ void cov_walk(const CovArgs& a, long long g, int f, i
                                          c32* acc_s, c32* acc_n) {
     constexpr int P = M + KR;
     const int K = a.K, T = a.T, F = a.F;
-    const long long r = g / K;
-    const int k = (int)(g % K);
+    const long long r = g / a.Kl;
+    const int k = a.k0 + (int)(g % a.Kl);
     const c32* Xg = a.X + (g * T * (long long)F) * M;
     const float* mg = a.mask + g * T * (long long)F;
     for (int t = t_begin; t < t_end; t += t_step) {
@@ -146,8 +150,8 @@ template <int SI, bool SAMEZ>
 __device__ __forceinline__ void cov_big_walk(const CovArgs& a, int M, int KR, long long g, int f, bool live, int t0, int t1,
                                              int t_step, int t_off, c32* acc_s, c32* acc_n) {
     const int K = a.K, T = a.T, F = a.F, P = M + KR;
-    const long long r = g / K;
-    const int k = (int)(g % K);
+    const long long r = g / a.Kl;
+    const int k = a.k0 + (int)(g % a.Kl);
     const c32* Xg = a.X + (g * T * (long long)F) * M;
     const float* mg = a.mask + g * T * (long long)F;
     for (int tu = t0; tu < t1; tu += t_step) {

@@ -77,6 +77,7 @@ class Engine:
         if rc != 0:
             raise DiscoError(f'disco_create failed ({rc}): {self.lib.disco_last_error(None).decode()}')
         self.R, self.K, self.M, self.Lsamp = rooms, nodes, mics, length
+        self.Kl, self.k0 = nodes, 0                     # node shard held by this engine (all nodes by default)
         self.T = self.lib.disco_n_frames(self.ctx)
         self.F = self.lib.disco_n_freq(self.ctx)
         self.stream = None
@@ -96,6 +97,12 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_node_shard(self, first_node, node_count):
+        """Hold only nodes [first_node, first_node + node_count) of every room (the rest live on other GPUs): the staged
+        methods then take / return `node_count` nodes per room, while Zs / Zn / Z keep all K nodes (all-gathered z)."""
+        self._chk(self.lib.disco_set_node_shard(self.ctx, first_node, node_count))
+        self.k0, self.Kl = first_node, node_count
 
     def sync(self):
         self._chk(self.lib.disco_sync(self.ctx, self.stream))
@@ -169,8 +176,8 @@ class Engine:
         if not Rss_out:          # leave the partial sums in the context for gevd_mwf_r1_pending
             self._chk(self.lib.disco_cov_masked(self.ctx, px, pm, pzs, pzn, int(bool(mask_remote)), P, None, None, self.stream))
             return None, None
-        Rss = self.empty((self.R, self.K, self.F, P, P), np.complex64)
-        Rnn = self.empty((self.R, self.K, self.F, P, P), np.complex64)
+        Rss = self.empty((self.R, self.Kl, self.F, P, P), np.complex64)
+        Rnn = self.empty((self.R, self.Kl, self.F, P, P), np.complex64)
         self._chk(self.lib.disco_cov_masked(self.ctx, px, pm, pzs, pzn, int(bool(mask_remote)), P, Rss.ptr, Rnn.ptr,
                                             self.stream))
         return Rss, Rnn
@@ -190,8 +197,8 @@ class Engine:
 
     def gevd_mwf_r1_pending(self, P, mu=None, want_t1=False):
         """Solve straight from the partial sums the last covariance call left in the context."""
-        w = self.empty((self.R, self.K, self.F, P), np.complex64)
-        t1 = self.empty((self.R, self.K, self.F, P), np.complex64) if want_t1 else None
+        w = self.empty((self.R, self.Kl, self.F, P), np.complex64)
+        t1 = self.empty((self.R, self.Kl, self.F, P), np.complex64) if want_t1 else None
         self._chk(self.lib.disco_gevd_mwf_r1_pending(self.ctx, self.cfg.mu if mu is None else mu, w.ptr,
                                                      t1.ptr if want_t1 else None, self.stream))
         return w, t1
@@ -202,14 +209,14 @@ class Engine:
         px, kx = self.to_device(X, np.complex64)
         pz, kz = self.to_device(Z, np.complex64)
         pw, kw = self.to_device(w, np.complex64)
-        out = self.empty((self.R, self.K, self.T, self.F), np.complex64)
+        out = self.empty((self.R, self.Kl, self.T, self.F), np.complex64)
         self._chk(self.lib.disco_apply(self.ctx, px, pz, pw, P, int(bool(conj)), out.ptr, self.stream))
         return out
 
     def noise_residual(self, X, z):
         px, kx = self.to_device(X, np.complex64)
         pz, kz = self.to_device(z, np.complex64)
-        zn = self.empty((self.R, self.K, self.T, self.F), np.complex64)
+        zn = self.empty((self.R, self.Kl, self.T, self.F), np.complex64)
         self._chk(self.lib.disco_noise_residual(self.ctx, px, pz, zn.ptr, self.stream))
         return zn
 

@@ -86,6 +86,14 @@ int  disco_n_freq(const disco_ctx* ctx);                 /* F = n_fft/2 + 1     
 /* Bytes of device workspace disco_tango_enhance needs for this cfg (STFT + z + yf + covariances). */
 size_t disco_workspace_bytes(const disco_ctx* ctx);
 
+/* Node-sharded operation (SURVEY 8e "finer sharding"): this context holds only nodes [first_node, first_node + count)
+ * of every room; the other nodes live on other GPUs and their compressed signals arrive through an all-gather of z
+ * (RCCL) between step 1 and step 2 -- the one exchange DISCO's algorithm performs (tango.py:378-386).
+ * Afterwards every per-node array of the STAGED entry points (X, masks, out/z of disco_apply, Rss/Rnn, w) has
+ * `count` nodes per room, while Zs/Zn/Z keep all cfg.nodes nodes (global order).  The fused entry points and
+ * disco_tango_enhance need all nodes on one GPU and return DISCO_E_UNSUPPORTED while a shard is active. */
+int  disco_set_node_shard(disco_ctx* ctx, int first_node, int node_count);
+
 /* ---- plain device-memory helpers (so a numpy-only host can drive the library without torch) -------- */
 int  disco_dev_alloc(disco_ctx* ctx, size_t bytes, void** dptr);
 int  disco_dev_free(disco_ctx* ctx, void* dptr);

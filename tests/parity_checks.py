@@ -231,6 +231,44 @@ def check_step2_fused(make_engine, R=2, K=4, M=4, L=4096, n_fft=512, seed=5):
     return errs
 
 
+def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
+    """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
+    The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""
+    from disco_amd import synth
+    from disco_amd.node_sharded import node_range, tango_enhance_node_sharded
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    full = make_engine(rooms=R, nodes=K, mics=M, length=L, staged_step2=True)
+    T, F = full.T, full.F
+    mask = full.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F).numpy()
+    out_full, z_full, yf_full = full.tango_enhance(y, mask)
+    out_full, z_full = out_full.numpy(), z_full.numpy()
+    # pass 1: every shard's z (what the all-gather would deliver)
+    shards = []
+    for q in range(world):
+        k0, kl = node_range(q, world, K)
+        e = make_engine(rooms=R, nodes=K, mics=M, length=L)
+        e.set_node_shard(k0, kl)
+        shards.append((e, k0, kl))
+    z_parts = {}
+
+    def fake_gather_factory(q):
+        def gather(z_local):
+            z_parts[q] = z_local
+            # the other shards' z: taken from the reference run (they would arrive over the wire)
+            parts = [z_local if qq == q else z_full[:, qq * (K // world):(qq + 1) * (K // world)] for qq in range(world)]
+            return np.concatenate(parts, axis=1)
+        return gather
+    worst = 0.0
+    for q, (e, k0, kl) in enumerate(shards):
+        out, yf, z_all = tango_enhance_node_sharded(e, y[:, k0:k0 + kl], mask[:, k0:k0 + kl], mask[:, k0:k0 + kl], fake_gather_factory(q))
+        worst = max(worst, maxrel(out.numpy(), out_full[:, k0:k0 + kl]))
+        # (the single-GPU run uses the fused STFT+covariance kernel, the shards the staged pair: same math, different
+        #  accumulation order / fma contraction, so agreement is to fp32 rounding through the solver, not bit-for-bit)
+        assert maxrel(z_parts[q], z_full[:, k0:k0 + kl]) < 5e-5
+    assert worst < 1e-4, worst
+    return worst
+
+
 def check_solver_vs_reference_golden(make_engine, golden_dir):
     """HIP solver against intern_filter outputs of the REFERENCE'S OWN CODE (tests/golden/intern_filter_ref.npz)."""
     import os

@@ -51,6 +51,10 @@ def test_emu_step2_fused(make_engine, K, M):
     print(pc.check_step2_fused(make_engine, R=1, K=K, M=M, L=2304))
 
 
+def test_emu_node_sharded(make_engine):
+    print(pc.check_node_sharded(make_engine, R=1, K=2, M=2, L=4096, world=2))
+
+
 def test_emu_solver_vs_reference_golden(make_engine, golden_dir):
     print(pc.check_solver_vs_reference_golden(make_engine, golden_dir))
 

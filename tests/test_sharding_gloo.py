@@ -63,3 +63,47 @@ def test_split_rooms_balanced():
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         sizes = [b - a for a, b in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+# ---- node-sharded mode: the z all-gather between the two steps (tango.py:378-386) over a real process group ------------
+def _node_worker(rank, world, port, q):
+    import numpy as np
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dd.init('gloo', rank, world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_build                                        # kernel sources under the hipemu CPU emulator (test tooling)
+    from disco_amd import synth
+    from disco_amd.engine import Engine
+    from disco_amd.node_sharded import node_range, tango_enhance_node_sharded, torch_all_gather
+    from oracle import tango_oracle as to
+    R, K, M, L = 1, 2, 2, 4096
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    o = to.offline_tango_vec(y[0], s[0], n[0], vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+    k0, kl = node_range(rank, world, K)
+    eng = Engine(rooms=R, nodes=K, mics=M, length=L, lib=emu_build.load_emu())
+    eng.set_node_shard(k0, kl)
+    mask = np.stack([o['masks_z'][k].T for k in range(k0, k0 + kl)])[None].astype(np.float32)       # (1, kl, T, F)
+    out, yf, z_all = tango_enhance_node_sharded(eng, y[:, k0:k0 + kl], mask, mask, torch_all_gather(world))
+    err_z = max(float(np.linalg.norm(z_all[0, k].T - o['z_y'][k]) / np.linalg.norm(o['z_y'][k])) for k in range(K))
+    err_yf = max(float(np.linalg.norm(yf.numpy()[0, i].T - o['yf'][k0 + i]) / np.linalg.norm(o['yf'][k0 + i])) for i in range(kl))
+    q.put((rank, err_z, err_yf))
+    dist.destroy_process_group()
+
+
+def test_node_sharded_all_gather_two_ranks():
+    """Two gloo ranks, one node each: step 1 local, all-gather of z, step 2 local -- both ranks match the float64 oracle
+    (every rank sees ALL z after the gather; its own filtered output covers its own node)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_node_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, err_z, err_yf in res:
+        assert err_z < 1e-5 and err_yf < 1e-5, (rank, err_z, err_yf)
