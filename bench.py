@@ -176,7 +176,7 @@ def main():
         ]
         if K > 1:
             calls += [
-                ('step2_cov', lambda: lib.disco_step2_cov_fused(eng.ctx, p(X), p(mask), p(w), NUL, NUL, NUL, None)),
+                ('step2_cov', lambda: lib.disco_step2_cov_fused_reuse(eng.ctx, p(X), p(mask), p(w), NUL, None)),
                 ('solve2', lambda: lib.disco_gevd_mwf_r1_pending(eng.ctx, 1.0, p(w2), NUL, None)),
             ]
             if N == 512:

@@ -51,6 +51,7 @@ PROTOTYPES = {
     'disco_noise_residual': (_int, [_vp, _vp, _vp, _vp, _vp]),
     'disco_stft_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'disco_step2_cov_fused_reuse': (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_apply_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_apply_istft_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_tango_enhance': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

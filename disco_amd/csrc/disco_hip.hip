@@ -26,6 +26,10 @@ struct disco_ctx {
     void* scratch;            // covariance chunk partials (grown on demand)
     size_t scratch_bytes;
     int pending_chunks, pending_P;   // geometry of the partials currently in `scratch` (0 = none)
+    void* scratch2;                  // step-2 partials when the step-1 ones in `scratch` are re-used (SKIPLOC)
+    size_t scratch2_bytes;
+    int loc_chunks, loc_M;           // geometry of the step-1 partials kept in `scratch` for that re-use
+    int pending_skiploc;             // the pending step-2 partials (scratch2) lack their leading loc_M x loc_M block
     int k0, Kl;                      // node shard: this context holds nodes [k0, k0 + Kl) of every room (default 0, K)
     char err[512];
 };
@@ -102,6 +106,11 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->pending_P = 0;
     ctx->k0 = 0;
     ctx->Kl = cfg->nodes;
+    ctx->scratch2 = nullptr;
+    ctx->scratch2_bytes = 0;
+    ctx->loc_chunks = 0;
+    ctx->loc_M = 0;
+    ctx->pending_skiploc = 0;
     ctx->err[0] = 0;
     const int N = cfg->n_fft;
     std::vector<float> win(N);
@@ -132,6 +141,7 @@ extern "C" void disco_destroy(disco_ctx* ctx) {
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->own_ws) (void)hipFree(ctx->own_ws);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     delete ctx;
 }
 
@@ -370,6 +380,8 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
     ctx->pending_P = P;
+    ctx->pending_skiploc = 0;
+    ctx->loc_M = 0;                    // `scratch` no longer holds k_stft_cov's step-1 partials
     return check_launch(ctx, "k_cov");
 }
 
@@ -420,6 +432,9 @@ extern "C" int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const dis
     src.F = 1;
     src.chunks = 1;
     src.inv_T = 1.f;
+    src.part_loc = nullptr;
+    src.chunks_loc = 0;
+    src.M_loc = 0;
     return solve_dispatch(ctx, src, n_prob, P, mu, w, t1, s);
 }
 
@@ -431,10 +446,13 @@ extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w,
     SolveSrc src;
     src.Rss = nullptr;
     src.Rnn = nullptr;
-    src.part = (const float4*)ctx->scratch;
+    src.part = (const float4*)(ctx->pending_skiploc ? ctx->scratch2 : ctx->scratch);
     src.F = ctx->F;
     src.chunks = ctx->pending_chunks;
     src.inv_T = 1.0f / (float)ctx->T;
+    src.part_loc = ctx->pending_skiploc ? (const float4*)ctx->scratch : nullptr;
+    src.chunks_loc = ctx->pending_skiploc ? ctx->loc_chunks : 0;
+    src.M_loc = ctx->pending_skiploc ? ctx->loc_M : 0;
     return solve_dispatch(ctx, src, (int64_t)ctx->cfg.rooms * ctx->Kl * ctx->F, ctx->pending_P, mu, w, t1, s);
 }
 
@@ -542,6 +560,9 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
     ctx->pending_P = M;
+    ctx->pending_skiploc = 0;
+    ctx->loc_chunks = chunks;          // kept for a possible re-use by step 2 of the same disco_tango_enhance call
+    ctx->loc_M = M;
     return check_launch(ctx, "k_stft_cov");
 }
 
@@ -567,8 +588,11 @@ static int step2_chunks(const disco_ctx* ctx, int tiles_plus_1) {
     return (int)c;
 }
 
+// skiploc: the caller guarantees that `scratch` still holds the step-1 partial sums of THIS X with THIS mask (only
+// disco_tango_enhance can know); the leading M x M block is then neither accumulated nor written and the step-2 partials
+// go to `scratch2`.
 static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
-                              disco_c32* z_out, int* chunks_out, disco_stream s) {
+                              disco_c32* z_out, int* chunks_out, disco_stream s, bool skiploc = false) {
     if (!X || !mask_w || !w_loc) return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused: null argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
@@ -578,7 +602,19 @@ static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* m
     const int chunks = step2_chunks(ctx, tiles + 1);
     const long long G = (long long)c.rooms * K;
     const int NP = P * (P + 1) / 2;
-    int rc = ensure_scratch(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
+    const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
+    int rc = 0;
+    if (skiploc) {
+        if (ctx->scratch2_bytes < need) {
+            if (ctx->scratch2) HIPCHK(ctx, hipFree(ctx->scratch2));
+            ctx->scratch2 = nullptr;
+            ctx->scratch2_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->scratch2, need));
+            ctx->scratch2_bytes = need;
+        }
+    } else {
+        rc = ensure_scratch(ctx, need);
+    }
     if (rc) return rc;
     Step2Args a;
     a.X = (const c32*)X;
@@ -587,7 +623,7 @@ static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* m
     a.w_glo = nullptr;
     a.z_out = (c32*)z_out;
     a.yf = nullptr;
-    a.part = (float4*)ctx->scratch;
+    a.part = (float4*)(skiploc ? ctx->scratch2 : ctx->scratch);
     a.K = K;
     a.T = ctx->T;
     a.F = ctx->F;
@@ -597,8 +633,12 @@ static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* m
     bool launched = false;
 #define X_(M_, KR_)                                                                                                  \
     if (!launched && M == M_ && K == KR_ + 1) {                                                                      \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_cov_fused<M_, KR_ + 1>), dim3((unsigned)nblk), dim3(64 * (KR_ + 1)), 0, \
-                           (hipStream_t)s, a);                                                                       \
+        if (skiploc)                                                                                                 \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_cov_fused<M_, KR_ + 1, true>), dim3((unsigned)nblk),          \
+                               dim3(64 * (KR_ + 1)), 0, (hipStream_t)s, a);                                          \
+        else                                                                                                         \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_cov_fused<M_, KR_ + 1, false>), dim3((unsigned)nblk),         \
+                               dim3(64 * (KR_ + 1)), 0, (hipStream_t)s, a);                                          \
         launched = true;                                                                                             \
     }
     DISCO_FOR_MKR(X_)
@@ -607,9 +647,19 @@ static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* m
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
     ctx->pending_P = P;
+    ctx->pending_skiploc = skiploc ? 1 : 0;
+    if (!skiploc) ctx->loc_M = 0;
     return check_launch(ctx, "k_step2_cov_fused");
 }
 
+extern "C" int disco_step2_cov_fused_reuse(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
+                                           disco_c32* z_out, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (ctx->loc_M != ctx->cfg.mics || ctx->cfg.nodes < 2 || ctx->Kl != ctx->cfg.nodes)
+        return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused_reuse: no step-1 partial sums of disco_stft_cov_fused are held by this context");
+    int chunks = 1;
+    return step2_cov_partials(ctx, X, mask_w, w_loc, z_out, &chunks, s, true);
+}
 extern "C" int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
                                      disco_c32* z_out, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
     if (!ctx) return DISCO_E_ARG;
@@ -740,14 +790,9 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
                                disco_c32* z_y, disco_c32* yf, char* ws, const WsLayout& l, disco_stream s);
 
 static int solve_from_partials(disco_ctx* ctx, int chunks, int P, disco_c32* w, disco_stream s) {
-    SolveSrc src;
-    src.Rss = nullptr;
-    src.Rnn = nullptr;
-    src.part = (const float4*)ctx->scratch;
-    src.F = ctx->F;
-    src.chunks = chunks;
-    src.inv_T = 1.0f / (float)ctx->T;
-    return solve_dispatch(ctx, src, (int64_t)ctx->cfg.rooms * ctx->cfg.nodes * ctx->F, P, ctx->cfg.mu, w, nullptr, s);
+    (void)chunks;
+    (void)P;                     // geometry is the pending state the covariance call just recorded
+    return disco_gevd_mwf_r1_pending(ctx, ctx->cfg.mu, w, nullptr, s);
 }
 
 extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
@@ -815,7 +860,13 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
     int chunks = 1;
     if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
     if ((rc = solve_from_partials(ctx, chunks, M, w_loc, s))) return rc;
-    if ((rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s))) return rc;
+    // same mask array in both steps (oracle masks; a DNN mask re-used, tango.py:388-389): the leading M x M block of the
+    // step-2 covariances IS the step-1 covariance still held as partial sums -> not recomputed
+    if (mask_w == mask_z && ctx->loc_M == M && c.nodes > 1)
+        rc = disco_step2_cov_fused_reuse(ctx, X, mask_w, w_loc, z_y, s);
+    else
+        rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s);
+    if (rc) return rc;
     if ((rc = solve_from_partials(ctx, chunks, P2, w_glo, s))) return rc;
     if (!yf && c.n_fft == 512) {           // yf not asked for: filter + iSTFT in one pass, yf stays on chip
         rc = disco_step2_apply_istft_fused(ctx, X, w_loc, w_glo, out, s);

@@ -16,12 +16,14 @@ __device__ __forceinline__ constexpr int tri_index(int i, int j) { return i * P 
 // One frame's contribution when both statistics weigh the SAME vector u (step 1, and step 2 with mask_for_z = 'local'):
 //   Rss += a u u^H,  Rnn += b u u^H  with a = m^2, b = (1-m)^2.  The product u_i conj(u_j) is formed once and added into
 // both accumulators (8 instructions per off-diagonal pair, no per-row scaling).
-template <int P>
+// JMIN > 0 skips the pairs with j < JMIN, i.e. the leading JMIN x JMIN block (step 2 re-using the local block that
+// step 1 already accumulated with the same mask).
+template <int P, int JMIN = 0>
 __device__ __forceinline__ void cov_accumulate_shared(const c32* u, float a, float b, c32* acc_s, c32* acc_n) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
 #pragma unroll
-        for (int j = i; j < P; ++j) {
+        for (int j = (i > JMIN ? i : JMIN); j < P; ++j) {
             const int q = tri_index<P>(i, j);
             const float pr = fmaf(u[i].x, u[j].x, u[i].y * u[j].y);
             acc_s[q].x = fmaf(a, pr, acc_s[q].x);

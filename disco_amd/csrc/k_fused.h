@@ -70,8 +70,11 @@ __device__ __forceinline__ c32 filt_conj(const c32* w, const c32* x) {      // s
 constexpr int S2_U_COV = DISCO_S2_U_COV;        // frames per barrier in the covariance kernel (register budget)
 constexpr int S2_U_APPLY = DISCO_S2_U_APPLY;    // frames per barrier in the apply kernel
 
-// grid = R * (F/64 + 1) * chunks blocks of 64*K threads
-template <int M, int K>
+// grid = R * (F/64 + 1) * chunks blocks of 64*K threads.
+// SKIPLOC: mask_w is the very array step 1 used (oracle masks, or a DNN's mask reused, tango.py:388-389), so the leading
+// M x M block of both step-2 covariances equals the step-1 covariances already sitting in the context as partial sums:
+// those 10 of 28 entry pairs (M = 4, K = 4) are neither accumulated nor written, the solver takes them from step 1.
+template <int M, int K, bool SKIPLOC>
 __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
     constexpr int P = M + K - 1, NP = P * (P + 1) / 2, U = S2_U_COV;
     __shared__ c32 zbuf[2][U][K][64];
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
                 const int j = jj < k ? jj : jj + 1;
                 uu[M + jj] = zbuf[buf][u][j][lane];
             }
-            cov_accumulate_shared<P>(uu, ms * ms, mc * mc, acc_s, acc_n);
+            cov_accumulate_shared<P, SKIPLOC ? M : 0>(uu, ms * ms, mc * mc, acc_s, acc_n);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -136,9 +139,20 @@ __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
             m[u] = mn[u];
         }
     }
+    // entries of the skipped leading block (never accumulated): q = tri_index(i, j) with j < M
+    auto skipped = [](int q) {
+        if (!SKIPLOC) return false;
+        int i = 0, qq = q;
+        while (qq >= P - i) {
+            qq -= P - i;
+            ++i;
+        }
+        return i + qq < M;
+    };
     if (gm.nyq) {                    // lanes of a wave hold partial sums over disjoint frames of the same (node, bin)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
+            if (skipped(q)) continue;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
                 acc_s[q].x += __shfl_xor(acc_s[q].x, off);
@@ -151,7 +165,8 @@ __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
     if (!gm.nyq || lane == 0) {
         float4* o = a.part + (((g * a.chunks + gm.c) * F) + f) * (long long)NP;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) o[q] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+        for (int q = 0; q < NP; ++q)
+            if (!skipped(q)) o[q] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
     }
 }
 

@@ -55,6 +55,10 @@ struct SolveSrc {
     const float4* part;
     int F, chunks;
     float inv_T;
+    // optional second source for the leading M_loc x M_loc block (step-1 partial sums re-used by step 2, see
+    // k_step2_cov_fused<SKIPLOC>): entries (j, c) with max(j, c) < M_loc come from here.  M_loc = 0: unused.
+    const float4* part_loc;
+    int chunks_loc, M_loc;
 };
 
 // row j of both Hermitian matrices of problem pid: rs[c] = Rss[j][c], rn[c] = Rnn[j][c]
@@ -73,10 +77,16 @@ __device__ __forceinline__ void solve_load_row(const SolveSrc& src, long long pi
 #pragma unroll
         for (int c = 0; c < P; ++c) {
             const bool up = c >= j;
-            const int q = up ? (j * P - (j * (j - 1)) / 2 + (c - j)) : (c * P - (c * (c - 1)) / 2 + (j - c));
+            const int lo_ = up ? j : c, hi_ = up ? c : j;            // upper-triangle coordinates (lo_, hi_)
+            const bool loc = hi_ < src.M_loc;
+            const int Pq = loc ? src.M_loc : P;
+            const int q = lo_ * Pq - (lo_ * (lo_ - 1)) / 2 + (hi_ - lo_);
+            const float4* base = loc ? src.part_loc : src.part;
+            const int nch = loc ? src.chunks_loc : src.chunks;
+            const long long npq = loc ? (long long)(src.M_loc * (src.M_loc + 1) / 2) : (long long)NP;
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int ch = 0; ch < src.chunks; ++ch) {
-                const float4 v = src.part[(((g * src.chunks + ch) * src.F) + f) * (long long)NP + q];
+            for (int ch = 0; ch < nch; ++ch) {
+                const float4 v = base[(((g * nch + ch) * src.F) + f) * npq + q];
                 s.x += v.x;
                 s.y += v.y;
                 s.z += v.z;

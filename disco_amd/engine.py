@@ -242,6 +242,16 @@ class Engine:
         self._chk(self.lib.disco_step2_cov_fused(self.ctx, px, pm, pw, z.ptr if z else None, Rss.ptr, Rnn.ptr, self.stream))
         return Rss, Rnn, z
 
+    def step2_cov_fused_reuse(self, X, mask_w, w_loc, want_z=False):
+        """step2_cov_fused when mask_w is the step-1 mask and the step-1 partial sums of `stft_cov_fused` are still in the
+        context: their M x M block is not recomputed.  Leaves the pencil pending for `gevd_mwf_r1_pending(M+K-1)`."""
+        px, kx = self.to_device(X, np.complex64)
+        pm, km = self.to_device(mask_w, np.float32)
+        pw, kw = self.to_device(w_loc, np.complex64)
+        z = self.empty((self.R, self.K, self.T, self.F), np.complex64) if want_z else None
+        self._chk(self.lib.disco_step2_cov_fused_reuse(self.ctx, px, pm, pw, z.ptr if z else None, self.stream))
+        return z
+
     def step2_apply_fused(self, X, w_loc, w_glo, want_z=False):
         px, kx = self.to_device(X, np.complex64)
         pl, kl = self.to_device(w_loc, np.complex64)

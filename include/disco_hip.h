@@ -170,6 +170,16 @@ int disco_stft_cov_fused(disco_ctx* ctx, const float* y, const float* mask_z, di
 int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
                           disco_c32* z_out, disco_c32* Rss, disco_c32* Rnn, disco_stream s);
 
+/* The same pass when mask_w IS the step-1 mask (oracle masks; a DNN mask re-used, tango.py:388-389): the leading
+ * M x M block of every node's step-2 covariance then equals its step-1 covariance, whose partial sums the preceding
+ * disco_stft_cov_fused call left in this context; that block is neither accumulated nor written, and
+ * disco_gevd_mwf_r1_pending assembles the pencil from both sets of partial sums.
+ * Contract: the LAST covariance call of this context was disco_stft_cov_fused(y, mask_w, X, ...) producing THIS X with
+ * THIS mask_w (only disco_gevd_mwf_r1_pending may have run in between); anything else returns DISCO_E_ARG.
+ * The matrices themselves are not available from this entry point (use disco_step2_cov_fused for Rss / Rnn). */
+int disco_step2_cov_fused_reuse(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
+                                disco_c32* z_out, disco_stream s);
+
 /* tango.py:369 + 382 + 445 in one pass over X: yf_k = w_glo,k^H [y_k ; z_j (j<k) ; z_j (j>k)] with z recomputed
  * from w_loc.  Equivalent to disco_apply(X, w_loc) -> z ; disco_apply(X, z, w_glo, M+K-1).
  * w_glo [R][K][F][P]; yf [R][K][T][F]; z_out [R][K][T][F] or NULL. */

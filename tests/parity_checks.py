@@ -231,6 +231,29 @@ def check_step2_fused(make_engine, R=2, K=4, M=4, L=4096, n_fft=512, seed=5):
     return errs
 
 
+def check_step2_reuse(make_engine, R=1, K=3, M=2, L=6000):
+    """disco_step2_cov_fused_reuse (leading M x M block taken from the step-1 partial sums) gives the same step-2
+    filters as the full step-2 covariance; its contract violations are refused."""
+    import pytest
+    from disco_amd import synth
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L)
+    T, F = eng.T, eng.F
+    mask = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F).numpy()
+    P = M + K - 1
+    X, _, _ = eng.stft_cov_fused(y, mask)
+    w_loc, _ = eng.gevd_mwf_r1_pending(M)
+    z = eng.step2_cov_fused_reuse(X, mask, w_loc, want_z=True)
+    w_a, t_a = eng.gevd_mwf_r1_pending(P, want_t1=True)
+    Rss, Rnn, z_b = eng.step2_cov_fused(X, mask, w_loc, want_z=True)
+    w_b, t_b = eng.gevd_mwf_r1(Rss, Rnn, want_t1=True)
+    errs = {'z': relerr(z.numpy(), z_b.numpy()), 'w': relerr(w_a.numpy(), w_b.numpy()), 't1': relerr(t_a.numpy(), t_b.numpy())}
+    assert errs['z'] == 0.0 and errs['w'] < 2e-5 and errs['t1'] < 2e-5, errs
+    with pytest.raises(Exception):          # scratch now holds step-2 sums: nothing to re-use
+        eng.step2_cov_fused_reuse(X, mask, w_loc)
+    return errs
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

@@ -63,6 +63,11 @@ def test_step2_fused(make_engine, R, K, M):
     pc.check_step2_fused(make_engine, R=R, K=K, M=M, L=16000)
 
 
+@pytest.mark.parametrize('R,K,M', [(3, 4, 4), (2, 2, 2), (1, 5, 3), (2, 3, 5)])
+def test_step2_reuse(make_engine, R, K, M):
+    pc.check_step2_reuse(make_engine, R=R, K=K, M=M, L=40000)
+
+
 @pytest.mark.parametrize('K,M,world', [(4, 4, 2), (4, 2, 4), (6, 2, 3)])
 def test_node_sharded_equals_single_gpu(make_engine, K, M, world):
     pc.check_node_sharded(make_engine, R=2, K=K, M=M, L=30000, world=world)

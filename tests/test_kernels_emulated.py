@@ -51,6 +51,10 @@ def test_emu_step2_fused(make_engine, K, M):
     print(pc.check_step2_fused(make_engine, R=1, K=K, M=M, L=2304))
 
 
+def test_emu_step2_reuse(make_engine):
+    print(pc.check_step2_reuse(make_engine, R=1, K=3, M=2, L=4096))
+
+
 def test_emu_node_sharded(make_engine):
     print(pc.check_node_sharded(make_engine, R=1, K=2, M=2, L=4096, world=2))
 
