@@ -79,6 +79,9 @@ def main():
     ap.add_argument('--n-fft', type=int, default=512)
     ap.add_argument('--mask', default='oracle', choices=['oracle', 'crnn'],
                     help="'crnn': BASELINE configs[3] -- randomly initialised CRNN mask estimators (PyTorch-ROCm) in the loop")
+    ap.add_argument('--online-every', type=int, default=0,
+                    help='> 0: time the ONLINE pipeline (SURVEY 8f-2) with a filter update every this many frames instead of '
+                         'the batch path (not the headline metric; stage timing / roofline are skipped)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--pmc-calibrate', action='store_true', help='also run a 4 GiB device copy (known bytes) for PMC calibration')
@@ -127,6 +130,10 @@ def main():
             out.copy_(tango_enhance_dnn(eng, y, model_z, model_w))
             return
         eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), None))
+        if args.online_every > 0:
+            eng._chk(lib.disco_tango_online(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), 0.95, args.online_every,
+                                            1e-3, out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
+            return
         eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
                                          None, None, ws.data_ptr(), ws.numel(), None))
 
@@ -156,7 +163,7 @@ def main():
 
     # ---- per-stage timing with HIP events on the launch stream (rank 0, N=1), for the roofline object
     roofline, stages = None, None
-    if rank == 0 and not args.no_stage_timing and args.mask == 'oracle':
+    if rank == 0 and not args.no_stage_timing and args.mask == 'oracle' and args.online_every == 0:
         X = torch.empty((R, K, T, F, M), dtype=torch.complex64, device=dev)
         z = torch.empty((R, K, T, F), dtype=torch.complex64, device=dev)
         yf = torch.empty_like(z)
@@ -237,7 +244,8 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'x_realtime': x_rt,
             'config': {'workload': f'{"C3" if args.mask == "oracle" else "C4"}: {R} rooms/GPU x {K} nodes x {M} mics, 16 kHz, L={Ls}, '
-                                   f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced',
+                                   f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced'
+                                   + (f', ONLINE mode lambda=0.95 update_every={args.online_every}' if args.online_every else ''),
                        'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
                        'parallelism': f'rooms sharded over {world} GPU(s), no data-path collective'},
             'roofline': roofline, 'cpu_baseline': cpu, 'stages': stages,

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/disco_hip.h"
@@ -12,6 +13,7 @@
 #include "k_cov.h"
 #include "k_fused.h"
 #include "k_solve.h"
+#include "k_online.h"
 #include "k_stft.h"
 
 using namespace disco;
@@ -795,16 +797,14 @@ static int solve_from_partials(disco_ctx* ctx, int chunks, int P, disco_c32* w, 
     return disco_gevd_mwf_r1_pending(ctx, ctx->cfg.mu, w, nullptr, s);
 }
 
-extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
-                                   disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
-    if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: null argument");
-    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: node shard active, drive the staged calls around an all-gather of z");
-    const disco_cfg& c = ctx->cfg;
-    const WsLayout l = ws_layout(ctx);
+// caller's workspace if given (size-checked), else the context's own (grown on demand)
+static int acquire_ws(disco_ctx* ctx, void* workspace, size_t workspace_bytes, const WsLayout& l, char** ws_out, const char* who) {
     char* ws = (char*)workspace;
     if (ws) {
-        if (workspace_bytes < l.total) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: workspace too small");
+        if (workspace_bytes < l.total) {
+            std::string m = std::string(who) + ": workspace too small";
+            return fail(ctx, DISCO_E_ARG, m.c_str());
+        }
     } else {
         if (ctx->own_ws_bytes < l.total) {
             if (ctx->own_ws) {
@@ -817,6 +817,20 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
         }
         ws = (char*)ctx->own_ws;
     }
+    *ws_out = ws;
+    return 0;
+}
+
+extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
+                                   disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: null argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: node shard active, drive the staged calls around an all-gather of z");
+    const disco_cfg& c = ctx->cfg;
+    const WsLayout l = ws_layout(ctx);
+    char* ws = nullptr;
+    int rcw = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance");
+    if (rcw) return rcw;
     if (c.nodes > 1 && c.mics + c.nodes - 1 <= 8 && !(c.flags & DISCO_FLAG_STAGED_STEP2))
         return tango_enhance_fused(ctx, y, mask_z, mask_w, out, z_y, yf, ws, l, s);
     disco_c32* X = (disco_c32*)(ws + l.X);
@@ -873,5 +887,73 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
         if (rc != DISCO_E_UNSUPPORTED) return rc;
     }
     if ((rc = disco_step2_apply_fused(ctx, X, w_loc, w_glo, nullptr, yo, s))) return rc;
+    return disco_istft(ctx, yo, G, out, s);
+}
+
+// ---- online / adaptive mode ------------------------------------------------------------------------------
+
+extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const float* mask, int P,
+                                float lambda_cor, float mu, int update_every, float init_diag, disco_c32* out,
+                                disco_c32* w_last, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    const disco_cfg& c = ctx->cfg;
+    if (!X || !mask || !out) return fail(ctx, DISCO_E_ARG, "disco_online_mwf: null argument");
+    if (P != c.mics && P != c.mics + c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_online_mwf: P must be mics or mics + nodes - 1");
+    if (P > c.mics && !Z) return fail(ctx, DISCO_E_ARG, "disco_online_mwf: P > mics needs the exchanged z");
+    if (!(lambda_cor >= 0.f && lambda_cor < 1.f) || update_every < 1 || !(init_diag > 0.f))
+        return fail(ctx, DISCO_E_ARG, "disco_online_mwf: need 0 <= lambda < 1, update_every >= 1, init_diag > 0");
+    if (P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_online_mwf: P must be <= 16");
+    OnlineArgs a;
+    a.X = (const c32*)X;
+    a.Z = P > c.mics ? (const c32*)Z : nullptr;
+    a.mask = mask;
+    a.out = (c32*)out;
+    a.w_last = (c32*)w_last;
+    a.K = c.nodes;
+    a.Kl = ctx->Kl;
+    a.k0 = ctx->k0;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    a.M = c.mics;
+    a.update_every = update_every;
+    a.lambda_cor = lambda_cor;
+    a.init_diag = init_diag;
+    a.mu = (double)mu;
+    a.n_prob = (long long)c.rooms * ctx->Kl * ctx->F;
+    hipStream_t st = (hipStream_t)s;
+    switch (P) {
+#define C_(P_)                                                                                                          \
+    case P_: {                                                                                                          \
+        const long long grid = (a.n_prob + SolveGeom<P_>::PROBS - 1) / SolveGeom<P_>::PROBS;                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf<P_>), dim3((unsigned)grid), dim3(SolveGeom<P_>::THREADS), 0, st, a); \
+    } break;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+#undef C_
+    }
+    return check_launch(ctx, "k_online_mwf");
+}
+
+extern "C" int disco_tango_online(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float lambda_cor,
+                                  int update_every, float init_diag, float* out, disco_c32* z_y, disco_c32* yf,
+                                  void* workspace, size_t workspace_bytes, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_online: null argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_online: node shard active, drive disco_online_mwf around an all-gather of z");
+    const disco_cfg& c = ctx->cfg;
+    const WsLayout l = ws_layout(ctx);
+    char* ws = nullptr;
+    int rc = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_online");
+    if (rc) return rc;
+    disco_c32* X = (disco_c32*)(ws + l.X);
+    disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
+    disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
+    const int64_t G = (int64_t)c.rooms * c.nodes;
+    if ((rc = disco_stft(ctx, y, G, c.mics, X, s))) return rc;
+    if ((rc = disco_online_mwf(ctx, X, nullptr, mask_z, c.mics, lambda_cor, c.mu, update_every, init_diag, z, nullptr, s))) return rc;
+    if (c.nodes == 1 && mask_w == mask_z) {             // nothing to append: step 2 would repeat step 1
+        if (yf) HIPCHK(ctx, hipMemcpyAsync(yf, z, (size_t)G * ctx->T * ctx->F * sizeof(c32), hipMemcpyDeviceToDevice, (hipStream_t)s));
+        return disco_istft(ctx, z, G, out, s);
+    }
+    if ((rc = disco_online_mwf(ctx, X, z, mask_w, c.mics + c.nodes - 1, lambda_cor, c.mu, update_every, init_diag, yo, nullptr, s))) return rc;
     return disco_istft(ctx, yo, G, out, s);
 }

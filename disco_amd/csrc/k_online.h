@@ -1,0 +1,113 @@
+// Online / adaptive MWF: the reference ships the primitive
+//     spatial_correlation_matrix   R <- lambda R + M (1 - lambda) x x^H      se_utils/internal_formulas.py:84-103
+// and the filter intern_filter('gevd', rank=1) (:56-73) but no loop around them.  This kernel is that loop, per bin:
+//     Rss_t = lambda Rss_{t-1} + (1-lambda)      m_t  v_t v_t^H          Rss_-1 = 0
+//     Rnn_t = lambda Rnn_{t-1} + (1-lambda) (1 - m_t) v_t v_t^H          Rnn_-1 = init_diag I
+//     w_t   = gevd-mwf(Rss_t, Rnn_t, mu)  when t % update_every == 0, else w_{t-1}
+//     out_t = w_t^H v_t,       v_t = [X_k(t, f, 0..M-1) ; Z_j(t, f), j < k ; Z_j(t, f), j > k]      (tango.py:142-155)
+// (restated in oracle/online_oracle.py, pinned on the reference's two functions by tests/golden/online_ref.npz).
+//
+// Mapping: as the batch solver -- a group of G lanes owns one (room, node, bin) problem for the whole signal, lane j owns
+// row j of both smoothed matrices (float32 registers: the forgetting factor keeps rounding from accumulating) and calls
+// the float64 group solve every update.  Consecutive groups of a block are consecutive bins, so the per-frame loads of
+// X / Z / mask are contiguous across the block.  The walk over t is causal, which makes the two-step pipeline two
+// launches of this kernel (step 1: P = M, Z = NULL -> z; step 2: P = M + K - 1, Z = z) with no other barrier.
+#pragma once
+#include "k_solve.h"
+
+namespace disco {
+
+struct OnlineArgs {
+    const c32* X;        // [R][Kl][T][F][M]
+    const c32* Z;        // [R][K][T][F] or NULL (P == M)
+    const float* mask;   // [R][Kl][T][F]
+    c32* out;            // [R][Kl][T][F]
+    c32* w_last;         // [R][Kl][F][P] or NULL: the filter in force at the last frame
+    int K, Kl, k0, T, F, M;
+    int update_every;
+    float lambda_cor, init_diag;
+    double mu;
+    long long n_prob;    // R * Kl * F
+};
+
+template <int P>
+__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_online_mwf(OnlineArgs a) {
+    constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
+    __shared__ c64 s_L[PROBS][P][P + 1];
+    __shared__ c64 s_Y[PROBS][P][P + 1];
+    const int j = threadIdx.x % G;
+    const int slot = threadIdx.x / G;
+    const long long pid = (long long)blockIdx.x * PROBS + slot;
+    const bool live = pid < a.n_prob;
+    const bool col = live && j < P;
+    const long long pc = live ? pid : 0;                  // dead groups walk problem 0 and write nothing
+    const long long g = pc / a.F;                         // (room, local node)
+    const int f = (int)(pc % a.F);
+    const long long r = g / a.Kl;
+    const int k = a.k0 + (int)(g % a.Kl);                 // global node index (remote-row order depends on it)
+    const int M = a.M;
+
+    // row c of v_t: local channels first, then the other nodes' z in node order (tango.py:150-153)
+    const c32* xb = a.X + ((g * a.T) * a.F + f) * (long long)M;
+    const c32* zb = a.Z ? a.Z + ((r * a.K) * a.T) * a.F + f : nullptr;
+    const long long TF = (long long)a.T * a.F;
+    const float* mp = a.mask + (g * a.T) * a.F + f;
+
+    c32 rowA[P], rowB[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        rowA[c] = make_float2(0.f, 0.f);
+        rowB[c] = make_float2(c == j ? (col ? a.init_diag : 1.f) : 0.f, 0.f);
+    }
+    const float lam = a.lambda_cor, oml = 1.f - a.lambda_cor;
+    c32 wj = make_float2(0.f, 0.f);
+    int until_update = 0;
+    for (int t = 0; t < a.T; ++t) {
+        c32 v[P];
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            if (c < M) {
+                v[c] = xb[(long long)t * a.F * M + c];
+            } else {
+                const int jn = (c - M) < k ? (c - M) : (c - M) + 1;        // skip the node's own z
+                v[c] = zb ? zb[jn * TF + (long long)t * a.F] : make_float2(0.f, 0.f);
+            }
+        }
+        const float m = mp[(long long)t * a.F];
+        c32 vj = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            if (c == j) vj = v[c];
+        }
+        if (col) {
+            const float cs = oml * m, cn = oml * (1.f - m);
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                const float pr = vj.x * v[c].x + vj.y * v[c].y;          // v_j conj(v_c)
+                const float pi = vj.y * v[c].x - vj.x * v[c].y;
+                rowA[c] = make_float2(lam * rowA[c].x + cs * pr, lam * rowA[c].y + cs * pi);
+                rowB[c] = make_float2(lam * rowB[c].x + cn * pr, lam * rowB[c].y + cn * pi);
+            }
+        }
+        if (until_update == 0) {                           // block-uniform: every group updates at the same frames
+            c64 t1;
+            double gain;
+            gevd_solve_group<P, true>(rowA, rowB, s_L[slot], s_Y[slot], j, a.mu, t1, gain);
+            wj = make_float2((float)(t1.x * gain), (float)(t1.y * gain));
+            until_update = a.update_every;
+        }
+        --until_update;
+        // out_t = sum_j conj(w_j) v_j over the group's lanes
+        float orx = j < P ? wj.x * vj.x + wj.y * vj.y : 0.f;
+        float oix = j < P ? wj.x * vj.y - wj.y * vj.x : 0.f;
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            orx += __shfl_xor(orx, off, G);
+            oix += __shfl_xor(oix, off, G);
+        }
+        if (live && j == 0) a.out[(g * a.T + t) * a.F + f] = make_float2(orx, oix);
+    }
+    if (col && a.w_last) a.w_last[pid * P + j] = wj;
+}
+
+}  // namespace disco

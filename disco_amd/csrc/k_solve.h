@@ -99,31 +99,15 @@ __device__ __forceinline__ void solve_load_row(const SolveSrc& src, long long pi
     }
 }
 
-template <int P, bool FROM_PART>
-__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
-                                                                        c32* __restrict__ w_out, c32* __restrict__ t1_out) {
-    constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
-    __shared__ c64 s_L[PROBS][P][P + 1];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]
-    __shared__ c64 s_Y[PROBS][P][P + 1];
-    const int j = threadIdx.x % G;             // column owned by this lane
-    const int slot = threadIdx.x / G;
-    const long long pid = (long long)blockIdx.x * PROBS + slot;
-    const bool live = pid < n_prob;
-    const bool col = live && j < P;
-    c64 (*Lm)[P + 1] = s_L[slot];
-    c64 (*Ym)[P + 1] = s_Y[slot];
-
-    // ---- row j of both matrices; stage Rnn in LDS as float64
-    c32 rowA[P], rowB[P];
-    if (col) {
-        solve_load_row<P, FROM_PART>(src, pid, j, rowA, rowB);
-    } else {
-#pragma unroll
-        for (int c = 0; c < P; ++c) {
-            rowA[c] = make_float2(0.f, 0.f);
-            rowB[c] = make_float2(c == j ? 1.f : 0.f, 0.f);
-        }
-    }
+// The solve proper for the group of G lanes that owns one pencil: lane j (< P) passes row j of Rxx (rowA) and of Rnn
+// (rowB); Lm / Ym are the group's two LDS matrices.  Returns this lane's component of t1 and the scalar gain
+// d0 / (d0 + mu)  (w_j = t1_j * gain).  Contains block-level barriers: every thread of the block must call it, the same
+// number of times.  REENTER: a barrier first, so that a previous call's readers of Lm / Ym are done (callers in a loop).
+template <int P, bool REENTER>
+__device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* rowB, c64 (*Lm)[P + 1], c64 (*Ym)[P + 1],
+                                                 const int j, const double mu, c64& t1_j, double& gain_out) {
+    constexpr int G = SolveGeom<P>::G;
+    if constexpr (REENTER) __syncthreads();
     if (j < P) {
 #pragma unroll
         for (int c = 0; c < P; ++c) Lm[j][c] = make_double2((double)rowB[c].x, (double)rowB[c].y);
@@ -272,13 +256,43 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc 
     const double dcl = fmin(fmax(d0, SOLVE_EPS), SOLVE_ETA);
     const c64 gsc = make_double2(dd[0] * v0[0].x, -dd[0] * v0[0].y);     // L[0,0] conj(v0[0]) = (Q^-1)[0,0]
     const double gain = dcl / (dcl + mu);
+    t1_j = make_double2(0.0, 0.0);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        if (col && i == j) {
-            const c64 t1 = zmul(q[i], gsc);
-            if (t1_out) t1_out[pid * P + i] = make_float2((float)t1.x, (float)t1.y);
-            w_out[pid * P + i] = make_float2((float)(t1.x * gain), (float)(t1.y * gain));
+        if (i == j) t1_j = zmul(q[i], gsc);
+    }
+    gain_out = gain;
+}
+
+template <int P, bool FROM_PART>
+__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
+                                                                        c32* __restrict__ w_out, c32* __restrict__ t1_out) {
+    constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
+    __shared__ c64 s_L[PROBS][P][P + 1];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]
+    __shared__ c64 s_Y[PROBS][P][P + 1];
+    const int j = threadIdx.x % G;             // column owned by this lane
+    const int slot = threadIdx.x / G;
+    const long long pid = (long long)blockIdx.x * PROBS + slot;
+    const bool live = pid < n_prob;
+    const bool col = live && j < P;
+
+    // ---- row j of both matrices
+    c32 rowA[P], rowB[P];
+    if (col) {
+        solve_load_row<P, FROM_PART>(src, pid, j, rowA, rowB);
+    } else {
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            rowA[c] = make_float2(0.f, 0.f);
+            rowB[c] = make_float2(c == j ? 1.f : 0.f, 0.f);
         }
+    }
+    c64 t1;
+    double gain;
+    gevd_solve_group<P, false>(rowA, rowB, s_L[slot], s_Y[slot], j, mu, t1, gain);
+    if (col) {
+        if (t1_out) t1_out[pid * P + j] = make_float2((float)t1.x, (float)t1.y);
+        w_out[pid * P + j] = make_float2((float)(t1.x * gain), (float)(t1.y * gain));
     }
 }
 

@@ -98,6 +98,38 @@ class Engine:
         except Exception:
             pass
 
+    # ---- online / adaptive mode (primitives internal_formulas.py:84-103 and :56-73)
+    def online_mwf(self, X, mask, Z=None, lambda_cor=0.95, mu=None, update_every=1, init_diag=1e-3, want_w=False):
+        """Exponentially smoothed covariances + a filter update every `update_every` frames, causal in t.
+        X (R,Kl,T,F,M), mask (R,Kl,T,F)[, Z (R,K,T,F) -> P = M+K-1]  ->  out (R,Kl,T,F)[, w_last (R,Kl,F,P)]."""
+        P = self.M + (self.K - 1 if Z is not None else 0)
+        px, kx = self.to_device(X, np.complex64)
+        pz, kz = self.to_device(Z, np.complex64)
+        pm, km = self.to_device(mask, np.float32)
+        out = self.empty((self.R, self.Kl, self.T, self.F), np.complex64)
+        w = self.empty((self.R, self.Kl, self.F, P), np.complex64) if want_w else None
+        self._chk(self.lib.disco_online_mwf(self.ctx, px, pz, pm, P, lambda_cor, self.cfg.mu if mu is None else mu,
+                                            update_every, init_diag, out.ptr, w.ptr if w else None, self.stream))
+        return (out, w) if want_w else out
+
+    def tango_online(self, y, mask_z, mask_w=None, lambda_cor=0.95, update_every=1, init_diag=1e-3, want_z=True,
+                     want_yf=True, out=None):
+        """The two-step path in online mode: y (R,K,M,L), masks (R,K,T,F) -> out (R,K,L)[, z_y, yf (R,K,T,F)]."""
+        py, ky = self.to_device(y, np.float32)
+        pmz, kmz = self.to_device(mask_z, np.float32)
+        if mask_w is None or mask_w is mask_z:
+            pmw, kmw = pmz, kmz
+        else:
+            pmw, kmw = self.to_device(mask_w, np.float32)
+        if out is None:
+            out = self.empty((self.R, self.K, self.Lsamp), np.float32)
+        po, ko = self.to_device(out, np.float32)
+        z = self.empty((self.R, self.K, self.T, self.F), np.complex64) if want_z else None
+        yf = self.empty((self.R, self.K, self.T, self.F), np.complex64) if want_yf else None
+        self._chk(self.lib.disco_tango_online(self.ctx, py, pmz, pmw, lambda_cor, update_every, init_diag, po,
+                                              z.ptr if z else None, yf.ptr if yf else None, None, 0, self.stream))
+        return out, z, yf
+
     def set_node_shard(self, first_node, node_count):
         """Hold only nodes [first_node, first_node + node_count) of every room (the rest live on other GPUs): the staged
         methods then take / return `node_count` nodes per room, while Zs / Zn / Z keep all K nodes (all-gathered z)."""

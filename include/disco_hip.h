@@ -207,6 +207,28 @@ int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, con
                         float* out, disco_c32* z_y, disco_c32* yf,
                         void* workspace, size_t workspace_bytes, disco_stream s);
 
+/* ---- online / adaptive mode -----------------------------------------------------------------
+ * The reference ships the smoothing primitive spatial_correlation_matrix (se_utils/internal_formulas.py:84-103:
+ * R <- lambda R + M (1 - lambda) x x^H) and intern_filter (:56-73) but no loop around them; these entry points are
+ * that loop, causal in t, per (room, node, bin):
+ *     Rss_t = lambda Rss_{t-1} + (1-lambda) m_t v_t v_t^H ,        Rss_-1 = 0
+ *     Rnn_t = lambda Rnn_{t-1} + (1-lambda) (1-m_t) v_t v_t^H ,    Rnn_-1 = init_diag I
+ *     w_t   = intern_filter(Rss_t, Rnn_t, mu, 'gevd', rank=1)  when t % update_every == 0, else w_{t-1}
+ *     out_t = w_t^H v_t ,   v_t = [X_k(t,f,:) ; Z_j(t,f) j<k ; Z_j(t,f) j>k]   (concatenate_signals, tango.py:142-155)
+ * X [R][Kl][T][F][M]; Z [R][K][T][F] (all nodes; needed iff P = M + K - 1, ignored iff P = M); mask [R][Kl][T][F];
+ * out [R][Kl][T][F]; w_last [R][Kl][F][P] or NULL (the filter in force at the last frame).  P <= 16. */
+int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const float* mask, int P,
+                     float lambda_cor, float mu, int update_every, float init_diag,
+                     disco_c32* out, disco_c32* w_last, disco_stream s);
+
+/* The two-step path in online mode: disco_stft -> disco_online_mwf(P = M) -> z -> disco_online_mwf(P = M + K - 1)
+ * -> yf -> disco_istft.  Both steps are causal in t, so frame t of the output depends on frames <= t of the inputs
+ * (plus the half-window look-ahead of the centred STFT).  Arguments as disco_tango_enhance; mu from the cfg. */
+int disco_tango_online(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w,
+                       float lambda_cor, int update_every, float init_diag,
+                       float* out, disco_c32* z_y, disco_c32* yf,
+                       void* workspace, size_t workspace_bytes, disco_stream s);
+
 #ifdef __cplusplus
 }
 #endif

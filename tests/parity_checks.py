@@ -254,6 +254,65 @@ def check_step2_reuse(make_engine, R=1, K=3, M=2, L=6000):
     return errs
 
 
+def check_online_golden(make_engine, golden_dir, t_max=None):
+    """disco_online_mwf against outputs of the reference's own spatial_correlation_matrix + intern_filter driven frame by
+    frame (tests/golden/make_golden_online.py).  The recursion is causal, so a prefix of the golden frames is itself a
+    golden case (t_max: the slow CPU emulation runs a prefix only)."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'online_ref.npz'))
+    errs = {}
+    for tag in ('p3', 'p5u4'):
+        V, mask, ref, w_ref = g[tag + '_V'], g[tag + '_mask'], g[tag + '_out'], g[tag + '_w']
+        lam, mu, init, U = (float(x) for x in g[tag + '_params'])
+        if t_max is not None:
+            V, mask, ref, w_ref = V[:, :, :t_max], mask[:, :t_max], ref[:, :t_max], w_ref[:, :t_max]
+        P, F, T = V.shape
+        # one room, one node with P "mics"; the golden bins occupy the first F of the engine's 257, the rest carry zeros
+        eng = make_engine(rooms=1, nodes=1, mics=P, length=(T - 1) * 256, n_fft=512)
+        assert eng.T == T, (eng.T, T)
+        X = np.zeros((1, 1, T, eng.F, P), np.complex64)
+        X[0, 0, :, :F] = V.transpose(2, 1, 0)
+        mk = np.full((1, 1, T, eng.F), 0.5, np.float32)
+        mk[0, 0, :, :F] = mask.T
+        out, w = eng.online_mwf(X, mk, lambda_cor=lam, mu=mu, update_every=int(U), init_diag=init, want_w=True)
+        out, w = out.numpy()[:, :, :, :F], w.numpy()[:, :, :F]
+        assert np.isfinite(out).all()
+        errs[tag] = relerr(out[0, 0].T, ref)
+        errs[tag + '_w'] = relerr(w[0, 0], w_ref[:, -1])
+        assert errs[tag] < 5e-5 and errs[tag + '_w'] < 5e-5, errs
+    return errs
+
+
+def check_online_mwf(make_engine, R=2, K=3, M=2, L=6000, n_fft=512, update_every=1, tol=1e-4):
+    """Both launches of the online kernel (P = M and P = M + K - 1 with the exchanged z) and the whole online pipeline
+    against oracle/online_oracle.py on synthetic rooms."""
+    from disco_amd import synth
+    from oracle import online_oracle as oo
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    T, F = eng.T, eng.F
+    mask = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F).numpy()
+    out, z, yf = eng.tango_online(y, mask, update_every=update_every)
+    out, z, yf = out.numpy(), z.numpy(), yf.numpy()
+    errs = {'z': 0.0, 'yf': 0.0, 'out': 0.0}
+    for r in range(R):
+        o = oo.online_tango(y[r], s[r], n[r], n_fft=n_fft, hop=n_fft // 2, update_every=update_every)
+        for k in range(K):
+            errs['z'] = max(errs['z'], relerr(z[r, k].T, o['z'][k]))
+            errs['yf'] = max(errs['yf'], relerr(yf[r, k].T, o['yf'][k]))
+            errs['out'] = max(errs['out'], relerr(out[r, k], o['out'][k]))
+    assert errs['z'] < tol and errs['yf'] < tol and errs['out'] < tol, errs
+    # the staged call with a node shard: nodes [1, K) only, remote rows from the full z
+    if K > 1:
+        X = eng.stft(y.reshape(R * K, M, L)).numpy().reshape(R, K, T, F, M)
+        sh = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+        sh.set_node_shard(1, K - 1)
+        yf_sh = sh.online_mwf(X[:, 1:], mask[:, 1:], Z=z, update_every=update_every).numpy()
+        errs['sharded'] = relerr(yf_sh, yf[:, 1:])
+        assert errs['sharded'] < 1e-6, errs
+    return errs
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

@@ -68,6 +68,16 @@ def test_step2_reuse(make_engine, R, K, M):
     pc.check_step2_reuse(make_engine, R=R, K=K, M=M, L=40000)
 
 
+def test_online_golden(make_engine, golden_dir):
+    pc.check_online_golden(make_engine, golden_dir)
+
+
+@pytest.mark.parametrize('R,K,M,L,n_fft,U', [(2, 4, 4, 12000, 512, 1), (2, 3, 2, 20000, 512, 4), (1, 1, 4, 16000, 512, 1),
+                                             (1, 2, 3, 30000, 1024, 2), (1, 5, 1, 8000, 512, 1)])
+def test_online_mwf(make_engine, R, K, M, L, n_fft, U):
+    pc.check_online_mwf(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft, update_every=U)
+
+
 @pytest.mark.parametrize('K,M,world', [(4, 4, 2), (4, 2, 4), (6, 2, 3)])
 def test_node_sharded_equals_single_gpu(make_engine, K, M, world):
     pc.check_node_sharded(make_engine, R=2, K=K, M=M, L=30000, world=world)

@@ -55,6 +55,14 @@ def test_emu_step2_reuse(make_engine):
     print(pc.check_step2_reuse(make_engine, R=1, K=3, M=2, L=4096))
 
 
+def test_emu_online_golden(make_engine, golden_dir):
+    print(pc.check_online_golden(make_engine, golden_dir, t_max=5))
+
+
+def test_emu_online_mwf(make_engine):
+    print(pc.check_online_mwf(make_engine, R=1, K=2, M=2, L=1536, update_every=3))
+
+
 def test_emu_node_sharded(make_engine):
     print(pc.check_node_sharded(make_engine, R=1, K=2, M=2, L=4096, world=2))
 

@@ -129,3 +129,26 @@ def test_vectorised_oracle_mask_for_z_modes_match_reference(golden_dir, mode):
     worst = max(relerr(out[nm][k], g[f'{mode}_{nm}{k}']) for nm in ('yf', 'sf', 'nf') for k in range(K))
     print(mode, 'worst vs reference', worst)
     assert worst < 2e-3          # tiny, badly conditioned scene: the reference's complex64 noise floor (see above)
+
+
+@pytest.mark.parametrize('tag', ['p3', 'p5u4'])
+def test_online_oracle_matches_reference_primitives(golden_dir, tag):
+    """oracle/online_oracle.py == the reference's spatial_correlation_matrix + intern_filter driven frame by frame
+    (tests/golden/make_golden_online.py)."""
+    from oracle import online_oracle as oo
+    g = np.load(os.path.join(golden_dir, 'online_ref.npz'))
+    lam, mu, init, U = (float(x) for x in g[tag + '_params'])
+    out, w = oo.online_mwf(g[tag + '_V'], g[tag + '_mask'], lam, mu, int(U), init)
+    assert np.abs(out - g[tag + '_out']).max() < 1e-10 * np.abs(g[tag + '_out']).max()
+    assert np.abs(w - g[tag + '_w']).max() < 1e-10 * np.abs(g[tag + '_w']).max()
+
+
+def test_online_primitive_matches_reference_update():
+    """spatial_correlation_matrix: both forms of internal_formulas.py:99-102."""
+    rng = np.random.default_rng(3)
+    R = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+    x = rng.standard_normal(3) + 1j * rng.standard_normal(3)
+    a = mo.spatial_correlation_matrix(R, x, 0.9)
+    assert np.allclose(a, 0.9 * R + 0.1 * np.outer(x, x.conj()))
+    b = mo.spatial_correlation_matrix(R, x, 0.9, M=0.25)
+    assert np.allclose(b, 0.9 * R + 0.025 * np.outer(x, x.conj()))
