@@ -33,8 +33,8 @@ struct OnlineArgs {
 template <int P>
 __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_online_mwf(OnlineArgs a) {
     constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
-    __shared__ c64 s_L[PROBS][P][P + 1];
-    __shared__ c64 s_Y[PROBS][P][P + 1];
+    __shared__ c64 s_L[PROBS][SolveGeom<P>::LSZ];
+    __shared__ c64 s_Y[PROBS][P][SolveGeom<P>::YW];
     const int j = threadIdx.x % G;
     const int slot = threadIdx.x / G;
     const long long pid = (long long)blockIdx.x * PROBS + slot;

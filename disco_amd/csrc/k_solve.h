@@ -19,6 +19,14 @@
 
 namespace disco {
 
+#ifndef DISCO_SOLVE_PACKED
+#define DISCO_SOLVE_PACKED 1
+#endif
+// a sweep whose every pair was orthogonal to sqrt(DISCO_JACOBI_DONE) before being rotated ends the iteration
+#ifndef DISCO_JACOBI_DONE
+#define DISCO_JACOBI_DONE 1e-14
+#endif
+
 constexpr double SOLVE_EPS = 2.220446049250313e-16;     // internal_formulas.py:6  sys.float_info.epsilon
 constexpr double SOLVE_ETA = 1e6;                       // internal_formulas.py:7
 
@@ -44,6 +52,11 @@ struct SolveGeom {
     static constexpr int G = P <= 4 ? 4 : (P <= 8 ? 8 : 16);
     static constexpr int THREADS = P <= 8 ? 128 : 64;           // keeps the two LDS matrices under 64 KiB
     static constexpr int PROBS = THREADS / G;
+    // LDS words (c64) per problem: L as a packed lower triangle (only that half is ever read), Y as a full matrix with a
+    // padded row.  Packing L takes P = 7 from 1792 to 1344 bytes per problem -- the kernel's occupancy is LDS-bound.
+    static constexpr int YW = (P % 8 == 0) ? P + 1 : P;     // row pitch of Y: padded only where P * 16 B would alias LDS banks
+    static constexpr int LSZ = DISCO_SOLVE_PACKED ? P * (P + 1) / 2 : P * (P + 1);
+    __host__ __device__ static constexpr int lt(int i, int k) { return DISCO_SOLVE_PACKED ? i * (i + 1) / 2 + k : i * (P + 1) + k; }
 };
 
 // Where the pencils come from: either full row-major matrices (the disco_gevd_mwf_r1 ABI) or, inside the fused
@@ -104,13 +117,16 @@ __device__ __forceinline__ void solve_load_row(const SolveSrc& src, long long pi
 // d0 / (d0 + mu)  (w_j = t1_j * gain).  Contains block-level barriers: every thread of the block must call it, the same
 // number of times.  REENTER: a barrier first, so that a previous call's readers of Lm / Ym are done (callers in a loop).
 template <int P, bool REENTER>
-__device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* rowB, c64 (*Lm)[P + 1], c64 (*Ym)[P + 1],
+__device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* rowB, c64* Lm, c64 (*Ym)[SolveGeom<P>::YW],
                                                  const int j, const double mu, c64& t1_j, double& gain_out) {
     constexpr int G = SolveGeom<P>::G;
+    using SG = SolveGeom<P>;
     if constexpr (REENTER) __syncthreads();
     if (j < P) {
 #pragma unroll
-        for (int c = 0; c < P; ++c) Lm[j][c] = make_double2((double)rowB[c].x, (double)rowB[c].y);
+        for (int c = 0; c < P; ++c) {
+            if (c <= j) Lm[SG::lt(j, c)] = make_double2((double)rowB[c].x, (double)rowB[c].y);     // lower triangle only
+        }
     }
     __syncthreads();
 
@@ -118,18 +134,18 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     double dd[P], rdd[P];
 #pragma unroll
     for (int c = 0; c < P; ++c) {
-        double d2 = Lm[c][c].x;
+        double d2 = Lm[SG::lt(c, c)].x;
 #pragma unroll
-        for (int k = 0; k < c; ++k) d2 -= Lm[c][k].x * Lm[c][k].x + Lm[c][k].y * Lm[c][k].y;
+        for (int k = 0; k < c; ++k) d2 -= Lm[SG::lt(c, k)].x * Lm[SG::lt(c, k)].x + Lm[SG::lt(c, k)].y * Lm[SG::lt(c, k)].y;
         const double d2c = fmax(d2, 1e-300);
         const double rd = rsqrt64(d2c);                 // 1 / L[c][c]
         dd[c] = d2c * rd;                               //     L[c][c]
         rdd[c] = rd;
         if (j > c && j < P) {
-            c64 s = Lm[j][c];
+            c64 s = Lm[SG::lt(j, c)];
 #pragma unroll
-            for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lm[j][k], Lm[c][k]));
-            Lm[j][c] = zscale(s, rd);
+            for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lm[SG::lt(j, k)], Lm[SG::lt(c, k)]));
+            Lm[SG::lt(j, c)] = zscale(s, rd);
         }
         __syncthreads();
     }
@@ -140,7 +156,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     for (int i = 0; i < P; ++i) {
         c64 a = make_double2((double)rowA[i].x, -(double)rowA[i].y);
 #pragma unroll
-        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[i][k], y[k]));
+        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], y[k]));
         y[i] = zscale(a, rdd[i]);
     }
     if (j < P) {
@@ -156,7 +172,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         c64 a = make_double2(0.0, 0.0);
         if (j < P) a = make_double2(Ym[j][i].x, -Ym[j][i].y);
 #pragma unroll
-        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[i][k], g[k]));
+        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], g[k]));
         g[i] = zscale(a, rdd[i]);
     }
 
@@ -194,7 +210,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
             const double gr = cr, gi = lo ? ci : -ci;     // gq^H gp = conj(gp^H gq)
             const double g2 = gr * gr + gi * gi;
             if (g2 > 1e-28 * alpha * beta && g2 > 0.0) {
-                if (g2 > 1e-14 * alpha * beta) rotated = 1;
+                if (g2 > DISCO_JACOBI_DONE * alpha * beta) rotated = 1;
                 const double rg = rsqrt64(g2);                                  // 1 / |gamma|
                 const double zeta = 0.5 * (beta - alpha) * rg;
                 const double hz = 1.0 + zeta * zeta;
@@ -217,6 +233,10 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         }
         if (!__any(rotated)) break;
     }
+
+    // L is read again by the back substitution below: make the compiler re-load it from LDS there instead of carrying
+    // the whole strict lower triangle (P(P-1)/2 complex doubles, 84 VGPRs at P = 7) in registers across the Jacobi loop
+    asm volatile("" ::: "memory");
 
     // ---- longest column = d0 v0 ; arg-max over the group (ties: lowest lane)
     double nrm = 0.0;
@@ -250,7 +270,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     for (int i = P - 1; i >= 0; --i) {
         c64 a = v0[i];
 #pragma unroll
-        for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Lm[k][i].x, -Lm[k][i].y), q[k]));
+        for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Lm[SG::lt(k, i)].x, -Lm[SG::lt(k, i)].y), q[k]));
         q[i] = zscale(a, rdd[i]);
     }
     const double dcl = fmin(fmax(d0, SOLVE_EPS), SOLVE_ETA);
@@ -268,8 +288,8 @@ template <int P, bool FROM_PART>
 __global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
                                                                         c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
-    __shared__ c64 s_L[PROBS][P][P + 1];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]
-    __shared__ c64 s_Y[PROBS][P][P + 1];
+    __shared__ c64 s_L[PROBS][SolveGeom<P>::LSZ];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]
+    __shared__ c64 s_Y[PROBS][P][SolveGeom<P>::YW];
     const int j = threadIdx.x % G;             // column owned by this lane
     const int slot = threadIdx.x / G;
     const long long pid = (long long)blockIdx.x * PROBS + slot;
