@@ -14,8 +14,27 @@ typedef double2 c64;   // complex128
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex add / sub as ONE packed instruction (v_pk_add_f32).  Measured on MI355X: the butterflies' adds packed this way
+// are worth ~7 % on the FFT-only kernel; builds that also packed the MULTIPLIES (complex products with op_sel swizzles,
+// packed covariance fma) measured 1.1-1.7x SLOWER per kernel (register-pair pressure, spills) and were dropped.
+// DISCO_PK=0: all scalar (also what the g++ test build uses, ext_vector_type being a clang extension).
+#ifndef DISCO_PK
+#define DISCO_PK 1
+#endif
+#if DISCO_PK && defined(__clang__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) {
+    const v2f r = v2f{a.x, a.y} + v2f{b.x, b.y};
+    return make_float2(r.x, r.y);
+}
+__device__ __forceinline__ c32 csub(c32 a, c32 b) {
+    const v2f r = v2f{a.x, a.y} - v2f{b.x, b.y};
+    return make_float2(r.x, r.y);
+}
+#else
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
+#endif
 __device__ __forceinline__ c32 cconj(c32 a) { return make_float2(a.x, -a.y); }
 // multiply by -i / +i
 __device__ __forceinline__ c32 cmul_mi(c32 a) { return make_float2(a.y, -a.x); }

@@ -329,8 +329,11 @@ struct alignas(16) StftCovShared {
 
 // 3 waves per SIMD (<= 168 VGPRs) is reachable for the common 512-point, M <= 4 shape and worth ~3 %; larger shapes keep
 // whatever occupancy their register need allows
+#ifndef DISCO_SC_WPE
+#define DISCO_SC_WPE 3
+#endif
 template <int N, int M>
-__global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? 3 : 1) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
+__global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WPE : 1) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
                                                                c32* __restrict__ X, float4* __restrict__ part,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
                                                                int L, int T, int pad_mode, int chunks, int runw) {
