@@ -13,6 +13,7 @@
 #include "k_cov.h"
 #include "k_fused.h"
 #include "k_solve.h"
+#include "k_metrics.h"
 #include "k_online.h"
 #include "k_stft.h"
 
@@ -956,4 +957,30 @@ extern "C" int disco_tango_online(disco_ctx* ctx, const float* y, const float* m
     }
     if ((rc = disco_online_mwf(ctx, X, z, mask_w, c.mics + c.nodes - 1, lambda_cor, c.mu, update_every, init_diag, yo, nullptr, s))) return rc;
     return disco_istft(ctx, yo, G, out, s);
+}
+
+// ---- evaluation metrics ----------------------------------------------------------------------------------
+
+extern "C" int disco_pair_stats(disco_ctx* ctx, const float* a, const float* b, int64_t n_sig, int64_t len, int start, int stop,
+                                double* stats, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!a || !b || !stats || n_sig < 1 || len < 1) return fail(ctx, DISCO_E_ARG, "disco_pair_stats: bad argument");
+    if (start < 0 || stop > len || stop < start) return fail(ctx, DISCO_E_ARG, "disco_pair_stats: need 0 <= start <= stop <= len");
+    if (n_sig > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_pair_stats: batch too large");
+    hipLaunchKernelGGL(k_pair_stats, dim3((unsigned)n_sig), dim3(METRIC_THREADS), 0, (hipStream_t)s, a, b, (long long)len, start, stop, stats);
+    return check_launch(ctx, "k_pair_stats");
+}
+
+extern "C" int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, int64_t len, int start, int stop,
+                                const double* b, const double* a, int n_bands, double* stats, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!x || !b || !a || !stats || n_sig < 1 || len < 1) return fail(ctx, DISCO_E_ARG, "disco_band_stats: bad argument");
+    if (start < 0 || stop > len || stop < start) return fail(ctx, DISCO_E_ARG, "disco_band_stats: need 0 <= start <= stop <= len");
+    if (n_bands < 1 || n_bands > METRIC_THREADS) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_band_stats: 1 <= n_bands <= 256");
+    const int spb = std::min(IIR_MAX_SPB, METRIC_THREADS / n_bands);
+    const long long grid = (n_sig + spb - 1) / spb;
+    if (grid > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_band_stats: batch too large");
+    hipLaunchKernelGGL(k_band_stats, dim3((unsigned)grid), dim3(METRIC_THREADS), 0, (hipStream_t)s, x, (long long)n_sig, (long long)len,
+                       start, stop, b, a, n_bands, spb, stats);
+    return check_launch(ctx, "k_band_stats");
 }

@@ -1,0 +1,120 @@
+// Evaluation metrics right after the hot path: the level statistics behind
+//   disco_theque/metrics.py:9-61     snr / delta_snr / sd      var of the NON-ZERO samples (x[x != 0])
+//   disco_theque/metrics.py:342-391  si_sdr                    <ref, est>, |ref|^2, |est|^2
+//   disco_theque/metrics.py:63-128, 211-279  fw_snr / fw_sd    scipy.signal.lfilter(b_i, a_i, x) per third-octave band, then
+//                                                              the same non-zero variance per band
+// so that a 1000-room batch is scored without copying every time signal to the host.  The kernels return raw float64
+// moments; the dB / clipping / importance-weight arithmetic on a handful of numbers per signal stays on the host
+// (disco_amd/metrics.py).  Restated for tests in oracle/metrics_oracle.py, pinned on the reference's own metrics.py.
+#pragma once
+#include "common.h"
+
+namespace disco {
+
+constexpr int PAIR_STATS = 8;      // {cnt_a, sum_a, sumsq_a, cnt_b, sum_b, sumsq_b, dot_ab, n}
+constexpr int BAND_STATS = 3;      // {cnt, sum, sumsq} of the non-zero filtered samples
+constexpr int IIR_NC = 9;          // coefficients per polynomial: order-4 Butterworth band-pass ('ba' form), metrics.py:104
+constexpr int METRIC_THREADS = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one workgroup per signal pair: a[sig][start:stop], b[sig][start:stop]  (b may alias a)
+__global__ __launch_bounds__(METRIC_THREADS) void k_pair_stats(const float* __restrict__ a, const float* __restrict__ b,
+                                                                long long len, int start, int stop,
+                                                                double* __restrict__ stats) {
+    __shared__ double red[METRIC_THREADS / 64][PAIR_STATS];
+    const long long sig = blockIdx.x;
+    const float* pa = a + sig * len;
+    const float* pb = b + sig * len;
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = start + (int)threadIdx.x; i < stop; i += METRIC_THREADS) {
+        const double x = (double)pa[i], y = (double)pb[i];
+        acc[0] += x != 0.0 ? 1.0 : 0.0;
+        acc[1] += x;
+        acc[2] += x * x;
+        acc[3] += y != 0.0 ? 1.0 : 0.0;
+        acc[4] += y;
+        acc[5] += y * y;
+        acc[6] += x * y;
+    }
+    const int w = wave_id(), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const double s = wave_sum(acc[q]);
+        if (lane == 0) red[w][q] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        double s = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < METRIC_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
+        stats[sig * PAIR_STATS + threadIdx.x] = s;
+    }
+    if (threadIdx.x == 7) stats[sig * PAIR_STATS + 7] = (double)(stop > start ? stop - start : 0);
+}
+
+// IIR bank: thread = (signal, band).  A workgroup owns `spb` = METRIC_THREADS / n_bands signals; their samples are staged
+// through LDS in coalesced tiles (row pitch TILE + 1: the spb rows then sit in distinct banks while every lane of a signal
+// reads the same word), and each thread runs scipy.signal.lfilter's recurrence (direct form II transposed, float64,
+// zero initial state at `start` -- the reference slices BEFORE filtering, tango.py:577-590) on its band.
+constexpr int IIR_TILE = 256;
+constexpr int IIR_MAX_SPB = 32;      // signals per workgroup (static LDS: 32 x 257 floats)
+__global__ __launch_bounds__(METRIC_THREADS) void k_band_stats(const float* __restrict__ x, long long n_sig, long long len,
+                                                                int start, int stop, const double* __restrict__ bc,
+                                                                const double* __restrict__ ac, int n_bands, int spb,
+                                                                double* __restrict__ stats) {
+    __shared__ float xs[IIR_MAX_SPB * (IIR_TILE + 1)];   // [spb][IIR_TILE + 1]
+    const int sl = threadIdx.x / n_bands, band = threadIdx.x % n_bands;
+    const long long sig = (long long)blockIdx.x * spb + sl;
+    const bool live = sl < spb && sig < n_sig;
+    double b[IIR_NC], a[IIR_NC], z[IIR_NC - 1];
+#pragma unroll
+    for (int i = 0; i < IIR_NC; ++i) {
+        b[i] = bc[band * IIR_NC + i];
+        a[i] = ac[band * IIR_NC + i];
+    }
+    const double ia0 = 1.0 / a[0];                      // lfilter normalises by a[0]
+#pragma unroll
+    for (int i = 0; i < IIR_NC; ++i) {
+        b[i] *= ia0;
+        a[i] *= ia0;
+    }
+#pragma unroll
+    for (int i = 0; i < IIR_NC - 1; ++i) z[i] = 0.0;
+    double cnt = 0.0, sum = 0.0, sumsq = 0.0;
+    const float* row = xs + (live ? sl : 0) * (IIR_TILE + 1);
+    for (int t0 = start; t0 < stop; t0 += IIR_TILE) {
+        const int nt = (stop - t0) < IIR_TILE ? (stop - t0) : IIR_TILE;
+        __syncthreads();                                // previous tile fully consumed
+        for (int idx = threadIdx.x; idx < spb * IIR_TILE; idx += METRIC_THREADS) {
+            const int s2 = idx / IIR_TILE, off = idx % IIR_TILE;
+            const long long sg = (long long)blockIdx.x * spb + s2;
+            xs[s2 * (IIR_TILE + 1) + off] = (sg < n_sig && off < nt) ? x[sg * len + t0 + off] : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+            for (int i = 0; i < nt; ++i) {
+                const double xv = (double)row[i];
+                const double y = b[0] * xv + z[0];
+#pragma unroll
+                for (int q = 0; q < IIR_NC - 2; ++q) z[q] = b[q + 1] * xv + z[q + 1] - a[q + 1] * y;
+                z[IIR_NC - 2] = b[IIR_NC - 1] * xv - a[IIR_NC - 1] * y;
+                cnt += y != 0.0 ? 1.0 : 0.0;
+                sum += y;
+                sumsq += y * y;
+            }
+        }
+    }
+    if (live) {
+        double* o = stats + (sig * n_bands + band) * BAND_STATS;
+        o[0] = cnt;
+        o[1] = sum;
+        o[2] = sumsq;
+    }
+}
+
+}  // namespace disco

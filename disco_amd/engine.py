@@ -130,6 +130,33 @@ class Engine:
                                               z.ptr if z else None, yf.ptr if yf else None, None, 0, self.stream))
         return out, z, yf
 
+    # ---- evaluation metrics (disco_theque/metrics.py)
+    def pair_stats(self, a, b, start=0, stop=None):
+        """a, b (n_sig, L) float32 -> (n_sig, 8) float64 moments of a[:, start:stop], b[:, start:stop]
+        {#(a!=0), sum a, sum a^2, #(b!=0), sum b, sum b^2, sum ab, n}."""
+        n_sig, L = a.shape
+        stop = L if stop is None else stop
+        pa, ka = self.to_device(a, np.float32)
+        pb, kb = (pa, ka) if b is a else self.to_device(b, np.float32)
+        st = self.empty((n_sig, 8), np.float64)
+        self._chk(self.lib.disco_pair_stats(self.ctx, pa, pb, n_sig, L, start, stop, st.ptr, self.stream))
+        return st
+
+    def band_stats(self, x, b, a, start=0, stop=None):
+        """x (n_sig, L) float32; b, a (n_bands, 9) float64 -> (n_sig, n_bands, 3) float64 {#(y!=0), sum y, sum y^2} of
+        y = lfilter(b_j, a_j, x[:, start:stop])."""
+        n_sig, L = x.shape
+        stop = L if stop is None else stop
+        b = np.ascontiguousarray(b, np.float64)
+        a = np.ascontiguousarray(a, np.float64)
+        assert b.shape == a.shape and b.shape[1] == 9, 'order-4 band-pass (9 coefficients per polynomial) expected'
+        px, kx = self.to_device(x, np.float32)
+        pb, kb = self.to_device(b, np.float64)
+        pa, ka = self.to_device(a, np.float64)
+        st = self.empty((n_sig, b.shape[0], 3), np.float64)
+        self._chk(self.lib.disco_band_stats(self.ctx, px, n_sig, L, start, stop, pb, pa, b.shape[0], st.ptr, self.stream))
+        return st
+
     def set_node_shard(self, first_node, node_count):
         """Hold only nodes [first_node, first_node + node_count) of every room (the rest live on other GPUs): the staged
         methods then take / return `node_count` nodes per room, while Zs / Zn / Z keep all K nodes (all-gathered z)."""

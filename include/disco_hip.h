@@ -229,6 +229,22 @@ int disco_tango_online(disco_ctx* ctx, const float* y, const float* mask_z, cons
                        float* out, disco_c32* z_y, disco_c32* yf,
                        void* workspace, size_t workspace_bytes, disco_stream s);
 
+/* ---- evaluation metrics right after the path --------------------------------------------------
+ * Raw float64 moments behind disco_theque/metrics.py; the dB / clipping / weighting of a handful of numbers per signal
+ * is host arithmetic (disco_amd/metrics.py).
+ *
+ * disco_pair_stats: for each of n_sig signal pairs a[i][start:stop], b[i][start:stop] (rows of `len` floats):
+ *   stats[i][8] = { #(a != 0), sum a, sum a^2, #(b != 0), sum b, sum b^2, sum a b, stop - start }
+ *   -> snr / delta_snr / sd (np.var of the non-zero samples, metrics.py:9-61) and si_sdr (:342-391). */
+int disco_pair_stats(disco_ctx* ctx, const float* a, const float* b, int64_t n_sig, int64_t len, int start, int stop,
+                     double* stats, disco_stream s);
+
+/* disco_band_stats: y_j = scipy.signal.lfilter(b[j], a[j], x[i][start:stop]) for every band j (zero initial state at
+ * `start`), then stats[i][j][3] = { #(y_j != 0), sum y_j, sum y_j^2 } -- the per-band levels of fw_snr / fw_sd
+ * (metrics.py:104-109, 256-260).  b, a: [n_bands][9] float64 (order-4 band-pass 'ba' coefficients, device memory). */
+int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, int64_t len, int start, int stop,
+                     const double* b, const double* a, int n_bands, double* stats, disco_stream s);
+
 #ifdef __cplusplus
 }
 #endif

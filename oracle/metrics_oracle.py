@@ -1,0 +1,112 @@
+"""TEST INFRASTRUCTURE (CPU oracle) -- only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+
+Evaluation metrics that directly follow the hot path, restated from
+    disco_theque/metrics.py:9-24     snr        var of the NON-ZERO samples of s over var of the non-zero samples of n
+    disco_theque/metrics.py:27-45    delta_snr
+    disco_theque/metrics.py:48-61    sd
+    disco_theque/metrics.py:63-128   fw_snr     third-octave IIR bank -> per-band SNR -> clip [-15, 25] dB -> importance weights
+    disco_theque/metrics.py:211-279  fw_sd      same bank on (s_out, s_in), clip [0, 25] dB
+    disco_theque/metrics.py:342-391  si_sdr
+    disco_theque/sigproc_utils.py:90-116  third_octave_filterbank (scipy.signal.butter band-pass per band, 'ba' form)
+Pinned by tests/golden/metrics_ref.npz = the reference's own metrics.py executed by tests/golden/make_golden_metrics.py.
+
+NOT pinned: the band edges.  `third_octave_filterbank` gets them from `acoustics.signal.OctaveBand(center=F, fraction=3)`
+(python-acoustics: third-party, absent, unpinned in requirements.txt).  Restated here from IEC 61260-1 as that package
+implements it: base-10 octave ratio G = 10^(3/10), the nominal centre snapped to the exact mid-band frequency
+1000 G^(n/3), edges = centre * G^(-+1/6).  The golden script injects THIS filterbank into the reference's fw_snr / fw_sd,
+so everything downstream of the coefficients is pinned and the edges are "parity unpinned".
+"""
+import numpy as np
+import scipy.signal
+
+G_OCT = 10.0 ** 0.3
+BIF_F = np.array([160, 200, 250, 315, 400, 500, 630, 800, 1000, 1250, 1600, 2000, 2500, 3150, 4000, 5000, 6300, 8000])
+BIF_I = np.array([83, 95, 150, 289, 440, 578, 653, 711, 818, 844, 882, 898, 868, 844, 771, 527, 364, 185]) * 1e-4
+BIF_F_NB = np.array([200, 250, 315, 400, 500, 630, 800, 1000, 1250, 1600, 2000, 2500, 3150, 4000])
+BIF_I_NB = np.array([128, 320, 320, 447, 447, 639, 639, 767, 959, 1182, 1214, 1086, 1086, 757]) * 1e-4
+
+
+def lin2db(x):
+    return 10 * np.log10(x)                 # math_utils.py:65-76
+
+
+def band_importance(fs):
+    """metrics.py:80-97 -- the centre frequencies whose upper edge F 2^(1/6) lies below fs/2, and their weights."""
+    r = 2 ** (1 / 6)
+    F, I = (BIF_F, BIF_I) if fs / 2 > 4500 else (BIF_F_NB, BIF_I_NB)
+    N = int(np.sum(F * r < fs / 2))
+    return F[:N], I[:N]
+
+
+def third_octave_edges(F):
+    n = np.round(3 * np.log(np.asarray(F, float) / 1000.0) / np.log(G_OCT))
+    fc = 1000.0 * G_OCT ** (n / 3)
+    return fc * G_OCT ** (-1 / 6), fc * G_OCT ** (1 / 6)
+
+
+def third_octave_filterbank(F, fs, order=8):
+    """sigproc_utils.py:90-116: row i = butter(order, [lower_i, upper_i] * 2 / fs, 'bandpass', 'ba')."""
+    lo, hi = third_octave_edges(F)
+    N = len(F)
+    b = np.zeros((N, 2 * order + 1))
+    a = np.zeros((N, 2 * order + 1))
+    for i in range(N):
+        b[i], a[i] = scipy.signal.butter(order, np.array([lo[i], hi[i]]) * 2 / fs, btype='bandpass', output='ba')
+    return b, a
+
+
+def _var_nz(x):
+    return np.var(x[x != 0])
+
+
+def snr(s, n, db=True):
+    v = _var_nz(s) / _var_nz(n)
+    return lin2db(v) if db else v
+
+
+def delta_snr(s_out, n_out, s_in, n_in):
+    return snr(s_out, n_out) - snr(s_in, n_in)
+
+
+def sd(s_out, s_in, db=True):
+    v = _var_nz(s_in) / _var_nz(s_out)
+    return lin2db(v) if db else v
+
+
+def band_levels(x, b, a):
+    """var of the non-zero samples of lfilter(b_i, a_i, x) for every band (metrics.py:106-109), linear."""
+    x = np.asarray(x)
+    out = np.zeros(len(b))
+    for i in range(len(b)):
+        out[i] = _var_nz(scipy.signal.lfilter(b[i], a[i], x, axis=0))
+    return out
+
+
+def fw_snr(s, n, fs, clipping=1):
+    F, I = band_importance(fs)
+    b, a = third_octave_filterbank(F, fs, order=4)
+    snr_var = lin2db(band_levels(s, b, a)) - lin2db(band_levels(n, b, a))
+    if clipping:
+        snr_var = np.minimum(np.maximum(-15, snr_var), 25)
+    fq = I / np.sum(I) * snr_var
+    return fq, np.sum(fq), F
+
+
+def fw_sd(s_out, s_in, fs, clipping=1):
+    F, I = band_importance(fs)
+    b, a = third_octave_filterbank(F, fs, order=4)
+    sd_var = lin2db(band_levels(s_in, b, a)) - lin2db(band_levels(s_out, b, a))
+    if clipping:
+        sd_var = np.minimum(np.maximum(0, sd_var), 25)
+    fq = I / np.sum(I) * sd_var
+    return fq, np.sum(fq), F
+
+
+def si_sdr(reference, estimation):
+    reference = np.asarray(reference, np.float64)
+    estimation = np.asarray(estimation, np.float64)
+    e = np.sum(reference ** 2, axis=-1, keepdims=True)
+    alpha = np.sum(reference * estimation, axis=-1, keepdims=True) / e
+    proj = alpha * reference
+    noise = estimation - proj
+    return 10 * np.log10(np.sum(proj ** 2, axis=-1) / np.sum(noise ** 2, axis=-1))

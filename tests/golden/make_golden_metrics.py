@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Golden fixture for the evaluation metrics, produced by RUNNING THE REFERENCE'S OWN metrics.py.
+
+disco_theque/metrics.py imports cleanly (numpy, scipy, math_utils).  Its fw_snr / fw_sd fetch the filter coefficients from
+disco_theque/sigproc_utils.py:third_octave_filterbank at call time; that module cannot be imported (soundfile and
+python-acoustics are absent), so a stand-in module exposing oracle.metrics_oracle.third_octave_filterbank (the restated
+IEC 61260-1 band edges + scipy.signal.butter, exactly what the reference function does with them) is placed in sys.modules
+-- the ONLY substituted piece.  Everything else (non-zero variance levels, lfilter, clipping, importance weights, si_sdr)
+is the reference's code.  Runs only in the build container.     python -B tests/golden/make_golden_metrics.py
+"""
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+
+
+def main():
+    scratch = tempfile.mkdtemp(prefix='disco_ref_')
+    shutil.copytree(os.path.join(REF, 'disco_theque'), os.path.join(scratch, 'disco_theque'))
+    sys.path.insert(0, scratch)
+    from oracle import metrics_oracle as mo
+    stand_in = types.ModuleType('disco_theque.sigproc_utils')
+    stand_in.third_octave_filterbank = mo.third_octave_filterbank
+    sys.modules['disco_theque.sigproc_utils'] = stand_in
+    from disco_theque import metrics as ref                      # the reference's own module
+
+    fs = 16000
+    rng = np.random.default_rng(11)
+    n_case, L = 4, 24000
+    out = {'fs': np.array(fs)}
+    S_in, N_in, S_out, N_out = [], [], [], []
+    res = {k: [] for k in ('snr_in', 'delta_snr', 'sd', 'fw_snr', 'fw_snr_mean', 'fw_sd', 'fw_sd_mean', 'si_sdr')}
+    for c in range(n_case):
+        # coloured "speech" with a leading silence (exact zeros: the non-zero-sample rule matters) + coloured noise
+        bs, as_ = [1.0, -0.6], [1.0, -1.2, 0.52]
+        s_in = np.zeros(L)
+        s_in[4000:] = np.convolve(rng.standard_normal(L - 4000), [1, 0.5, 0.2])[:L - 4000]
+        s_in = np.asarray(__import__('scipy.signal').signal.lfilter(bs, as_, s_in), np.float32)
+        s_in[:4000] = 0.0
+        n_in = (0.5 * np.convolve(rng.standard_normal(L), [1, -0.3])[:L]).astype(np.float32)
+        g = 0.7 + 0.1 * c
+        s_out = (g * s_in + 0.02 * rng.standard_normal(L) * (s_in != 0)).astype(np.float32)
+        n_out = (0.3 * n_in).astype(np.float32)
+        S_in.append(s_in), N_in.append(n_in), S_out.append(s_out), N_out.append(n_out)
+        res['snr_in'].append(ref.snr(s_in, n_in))
+        res['delta_snr'].append(ref.delta_snr(s_out, n_out, s_in, n_in))
+        res['sd'].append(ref.sd(s_out, s_in))
+        fq, fm, F = ref.fw_snr(s_out, n_out, fs)
+        res['fw_snr'].append(fq), res['fw_snr_mean'].append(fm)
+        fq, fm, _ = ref.fw_sd(s_out, s_in, fs)
+        res['fw_sd'].append(fq), res['fw_sd_mean'].append(fm)
+        res['si_sdr'].append(ref.si_sdr(s_in.astype(np.float64), (s_out + n_out).astype(np.float64)))
+    out.update(s_in=np.stack(S_in), n_in=np.stack(N_in), s_out=np.stack(S_out), n_out=np.stack(N_out), F=np.asarray(F))
+    out.update({k: np.asarray(v) for k, v in res.items()})
+    np.savez_compressed(os.path.join(HERE, 'metrics_ref.npz'), **out)
+    shutil.rmtree(scratch, ignore_errors=True)
+    print('wrote metrics_ref.npz', {k: np.asarray(v).shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -313,6 +313,47 @@ def check_online_mwf(make_engine, R=2, K=3, M=2, L=6000, n_fft=512, update_every
     return errs
 
 
+def check_metrics(make_engine, golden_dir, L_cut=None, start=0):
+    """disco_amd.metrics (HIP moments + host dB arithmetic) against the reference's own metrics.py outputs
+    (tests/golden/metrics_ref.npz) and against oracle/metrics_oracle.py on a sub-span (start > 0: the reference scores
+    [fs:], tango.py:553).  L_cut: the slow CPU emulation runs a short span only (then only the oracle comparison applies)."""
+    import os
+    from disco_amd import metrics as gm
+    from oracle import metrics_oracle as mo
+    g = np.load(os.path.join(golden_dir, 'metrics_ref.npz'))
+    fs = int(g['fs'])
+    sig = {k: g[k] if L_cut is None else np.ascontiguousarray(g[k][:2, 3800:3800 + L_cut]) for k in ('s_in', 'n_in', 's_out', 'n_out')}
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    saved = gm._engine
+    gm._engine = lambda: eng
+    try:
+        s_in, n_in, s_out, n_out = (sig[k] for k in ('s_in', 'n_in', 's_out', 'n_out'))
+        C = s_in.shape[0]
+        got = {'snr_in': gm.snr(s_in, n_in, start=start), 'delta_snr': gm.delta_snr(s_out, n_out, s_in, n_in, start=start),
+               'sd': gm.sd(s_out, s_in, start=start), 'si_sdr': gm.si_sdr(s_in, s_out + n_out, start=start)}
+        got['fw_snr'], got['fw_snr_mean'], F = gm.fw_snr(s_out, n_out, fs, start=start)
+        got['fw_sd'], got['fw_sd_mean'], _ = gm.fw_sd(s_out, s_in, fs, start=start)
+    finally:
+        gm._engine = saved
+    errs = {}
+    for c in range(C):
+        a, b, x, y = s_in[c, start:], n_in[c, start:], s_out[c, start:], n_out[c, start:]
+        want = {'snr_in': mo.snr(a, b), 'delta_snr': mo.delta_snr(x, y, a, b), 'sd': mo.sd(x, a),
+                'si_sdr': mo.si_sdr(a, (s_out + n_out)[c, start:]), 'fw_snr': mo.fw_snr(x, y, fs)[0],
+                'fw_snr_mean': mo.fw_snr(x, y, fs)[1], 'fw_sd': mo.fw_sd(x, a, fs)[0], 'fw_sd_mean': mo.fw_sd(x, a, fs)[1]}
+        for k, v in want.items():
+            assert np.all(np.isfinite(v)) and np.all(np.isfinite(np.asarray(got[k])[c])), (k, v, np.asarray(got[k])[c])
+            errs[k] = max(errs.get(k, 0.0), float(np.max(np.abs(np.asarray(got[k])[c] - v))))
+    assert all(e < 2e-4 for e in errs.values()), errs                 # dB; float32-vs-float64 variance of the reference
+    if L_cut is None and start == 0:
+        for k in got:
+            e = float(np.max(np.abs(np.asarray(got[k]) - g[k])))
+            errs[k + '_vs_reference'] = e
+            assert e < 2e-4, (k, e)
+        assert np.array_equal(F, g['F'])
+    return errs
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

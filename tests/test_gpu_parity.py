@@ -68,6 +68,11 @@ def test_step2_reuse(make_engine, R, K, M):
     pc.check_step2_reuse(make_engine, R=R, K=K, M=M, L=40000)
 
 
+@pytest.mark.parametrize('start', [0, 5000])
+def test_metrics(make_engine, golden_dir, start):
+    pc.check_metrics(make_engine, golden_dir, start=start)
+
+
 def test_online_golden(make_engine, golden_dir):
     pc.check_online_golden(make_engine, golden_dir)
 

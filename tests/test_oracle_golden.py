@@ -152,3 +152,18 @@ def test_online_primitive_matches_reference_update():
     assert np.allclose(a, 0.9 * R + 0.1 * np.outer(x, x.conj()))
     b = mo.spatial_correlation_matrix(R, x, 0.9, M=0.25)
     assert np.allclose(b, 0.9 * R + 0.025 * np.outer(x, x.conj()))
+
+
+def test_metrics_oracle_matches_reference(golden_dir):
+    """oracle/metrics_oracle.py == the reference's own metrics.py (tests/golden/make_golden_metrics.py)."""
+    from oracle import metrics_oracle as mo
+    g = np.load(os.path.join(golden_dir, 'metrics_ref.npz'))
+    fs = int(g['fs'])
+    for c in range(g['s_in'].shape[0]):
+        s_in, n_in, s_out, n_out = (g[k][c] for k in ('s_in', 'n_in', 's_out', 'n_out'))
+        assert abs(mo.snr(s_in, n_in) - g['snr_in'][c]) < 1e-9
+        assert abs(mo.delta_snr(s_out, n_out, s_in, n_in) - g['delta_snr'][c]) < 1e-9
+        assert abs(mo.sd(s_out, s_in) - g['sd'][c]) < 1e-9
+        assert np.abs(mo.fw_snr(s_out, n_out, fs)[0] - g['fw_snr'][c]).max() < 1e-9
+        assert np.abs(mo.fw_sd(s_out, s_in, fs)[0] - g['fw_sd'][c]).max() < 1e-9
+        assert abs(mo.si_sdr(s_in.astype(np.float64), (s_out + n_out).astype(np.float64)) - g['si_sdr'][c]) < 1e-9
