@@ -18,11 +18,10 @@ def concatenate_signals(y, z, k, m=1):
 
 
 def _as_batch(x):
-    """[node][channel] -> time lists or (K, M, L) arrays -> (1, K, M, L) float32."""
+    """[node][channel] -> time lists or (K, M, L) arrays -> (1, K, M, L) float32; None when the nodes are ragged."""
     nodes = [np.asarray(xk, dtype=np.float32) for xk in x]
     if len({xk.shape for xk in nodes}) != 1:
-        raise NotImplementedError('disco_amd.offline_tango needs the same number of channels at every node '
-                                  '(the reference allows ragged nb_ch; the batched GPU layout is uniform)')
+        return None
     return np.ascontiguousarray(np.stack(nodes)[None])
 
 
@@ -99,11 +98,92 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
     return out
 
 
+def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='reflect', ref_mic=0, mu=1.0):
+    """Nodes with DIFFERENT channel counts (the reference allows them: nb_ch is per node, tango.py:259-261, 286).  The
+    batched layout is uniform, so every node runs as a one-node shard (`disco_set_node_shard(k, 1)`) of a K-node context
+    with ITS OWN mic count; the remote rows of step 2 are the z of all K nodes, exactly the node-sharded data flow.
+    Returns per-node lists of (T, F) arrays."""
+    vads = _mask_names(vads)
+    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs')
+    if mask_for_z not in MODES:
+        raise NotImplementedError(f'mask_for_z must be one of {MODES}')
+    oracle_sigs = isinstance(mask_for_z, str) and 'use_oracle_' in mask_for_z
+    y = [np.ascontiguousarray(a, dtype=np.float32) for a in y]
+    s = [np.ascontiguousarray(a, dtype=np.float32) for a in s]
+    n = [np.ascontiguousarray(a, dtype=np.float32) for a in n]
+    K, L = len(y), y[0].shape[-1]
+    assert all(a.shape[-1] == L for a in y + s + n), 'all channels must have the same number of samples'
+    names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
+    out = {nm: [None] * K for nm in names}
+    st = []
+    engines = set()
+    try:
+        for k in range(K):                                                     # step 1 (tango.py:326-376)
+            M = y[k].shape[0]
+            eng = get_engine(rooms=1, nodes=K, mics=M, length=L, n_fft=n_fft, mask=vads[0], pad_mode=pad_mode,
+                             ref_mic=ref_mic, mu=mu, staged_step2=True)
+            engines.add(eng)
+            eng.set_node_shard(k, 1)
+            T, F = eng.T, eng.F
+            Y, S, N = (eng.stft(a[None]).reshape(1, 1, T, F, M) for a in (y[k], s[k], n[k]))
+            Sh, Nh = S.numpy(), N.numpy()
+            mz = eng.tf_mask(np.ascontiguousarray(Sh[..., ref_mic]), np.ascontiguousarray(Nh[..., ref_mic]), type=vads[0]).numpy().astype(np.float32)
+            same = (ref_mic == 0 and vads[1] == vads[0])
+            mw = mz if same else eng.tf_mask(np.ascontiguousarray(Sh[..., 0]), np.ascontiguousarray(Nh[..., 0]), type=vads[1]).numpy().astype(np.float32)
+            if oracle_sigs:
+                Rss, _ = eng.cov_masked(S, np.ones_like(mz))
+                _, Rnn = eng.cov_masked(N, np.zeros_like(mz))
+                w_loc, _ = eng.gevd_mwf_r1(Rss, Rnn, want_t1=False)
+            else:
+                eng.cov_masked(Y, mz)
+                w_loc, _ = eng.gevd_mwf_r1_pending(M)
+            z_y, z_s, z_n = (eng.apply(A, w_loc).numpy() for A in (Y, S, N))
+            zn = eng.noise_residual(Y, z_y).numpy()
+            for nm, v in (('z_y', z_y), ('z_s', z_s), ('z_n', z_n), ('zn', zn), ('masks_z', mz), ('mask_w', mw)):
+                out[nm][k] = v[0, 0]
+            st.append((eng, M, Y.numpy(), Sh, Nh, mw))
+        Zy, Zs, Zn, ZN = (np.ascontiguousarray(np.stack(out[nm])[None]) for nm in ('z_y', 'z_s', 'z_n', 'zn'))
+        MW = np.stack(out['mask_w'])[None]
+        if mask_for_z == 'compressed':                                         # sender-side mask from (z_s, z_n), tango.py:402-405
+            MC = st[0][0].tf_mask(Zs[0], Zn[0], type=vads[0]).numpy()[None]
+        ref_S = np.stack([t[3][0, 0, ..., ref_mic] for t in st])[None]
+        ref_N = np.stack([t[4][0, 0, ..., ref_mic] for t in st])[None]
+        for k in range(K):                                                     # exchange + step 2 (tango.py:378-450)
+            eng, M, Yh, Sh, Nh, mw = st[k]
+            eng.set_node_shard(k, 1)
+            if mask_for_z == 'local':
+                eng.cov_masked(Yh, mw, Zy, Zy, mask_remote=True)
+            elif mask_for_z is None:
+                eng.cov_masked(Yh, mw, Zy, ZN, mask_remote=False)
+            else:
+                if mask_for_z == 'distant':
+                    zs_rows, zn_rows = Zy * MW, Zy * (1 - MW)
+                elif mask_for_z == 'compressed':
+                    zs_rows, zn_rows = Zy * MC, Zy * (1 - MC)
+                elif mask_for_z == 'use_oracle_refs':
+                    zs_rows, zn_rows = ref_S, ref_N
+                else:
+                    zs_rows, zn_rows = Zs, Zn
+                eng.cov_masked(Yh, mw, np.ascontiguousarray(zs_rows, np.complex64), np.ascontiguousarray(zn_rows, np.complex64),
+                               mask_remote=False)
+            w_glo, _ = eng.gevd_mwf_r1_pending(M + K - 1)
+            for nm, A, Z in (('yf', Yh, Zy), ('sf', Sh, Zs), ('nf', Nh, Zn)):
+                out[nm][k] = eng.apply(A, w_glo, Z=Z if K > 1 else None).numpy()[0, 0]
+    finally:
+        for eng in engines:                                                    # the cached engines go back to "all nodes"
+            eng.set_node_shard(0, K)
+    return out
+
+
 def offline_tango(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_sigs='zs_hat'):
     """Drop-in for the reference's `offline_tango`: returns
-    (yf, sf, nf, z_y, z_s, z_n, zn, masks_z, mask_w), each a list over nodes of (F, T) arrays (tango.py:457)."""
-    d = offline_tango_batched(_as_batch(y), _as_batch(s), _as_batch(n), vads=vads, mods=mods, mask_for_z=mask_for_z,
-                              z_sigs=z_sigs)
-    K = d['yf'].shape[1]
+    (yf, sf, nf, z_y, z_s, z_n, zn, masks_z, mask_w), each a list over nodes of (F, T) arrays (tango.py:457).
+    Nodes may have different channel counts, as in the reference."""
     names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
+    yb, sb, nb = _as_batch(y), _as_batch(s), _as_batch(n)
+    if yb is None or sb is None or nb is None:
+        d = _offline_tango_ragged(y, s, n, vads, mask_for_z)
+        return tuple([np.ascontiguousarray(v.T) for v in d[nm]] for nm in names)
+    d = offline_tango_batched(yb, sb, nb, vads=vads, mods=mods, mask_for_z=mask_for_z, z_sigs=z_sigs)
+    K = d['yf'].shape[1]
     return tuple([np.ascontiguousarray(d[nm][0, k].T) for k in range(K)] for nm in names)
