@@ -60,7 +60,13 @@ def cpu_baseline(K, M, L, seconds_hint=25.0):
     to.offline_tango_literal(y, s, n, vads=['irm1', 'irm1'])
     dt = time.perf_counter() - t0
     T = 1 + L // 256
+    # the vectorised NumPy restatement of the same path (float64, batched eigh), same room, one process
+    t0 = time.perf_counter()
+    to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+    dtv = time.perf_counter() - t0
     return {'value': K * T / dt, 'unit': 'node-frames/s', 'cores': 1, 'kind': 'port',
+            'vectorised_numpy': {'value': K * T / dtv, 'unit': 'node-frames/s', 'seconds': round(dtv, 2),
+                                 'what': 'oracle/tango_oracle.py:offline_tango_vec (float64, einsum covariances, batched eigh), same room'},
             'sample': f'1 room ({K} nodes x {M} mics, {L} samples = {K * T} node-frames), literal reference loop nest '
                       f'(tango.py:326-457 restated, bit-exact vs reference), STFTs included, {dt:.1f} s on 1 of '
                       f'{os.cpu_count()} host cores',
@@ -235,6 +241,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(K, M, Ls)
 
+    # BASELINE.json config the shape corresponds to (C3 is the headline; the others are run by hand)
+    shape = (K, M, N)
+    cfg_name = ('C4' if args.mask == 'crnn' else 'C3') if shape == (4, 4, 512) else (
+        'C2' if shape == (1, 4, 512) else ('C5-shaped' if shape == (8, 8, 1024) else 'custom'))
     if rank == 0:
         mask_desc = 'oracle irm1 mask' if args.mask == 'oracle' else 'CRNN masks in the loop (random weights, fp32 PyTorch-ROCm)'
         line = {
@@ -243,7 +253,7 @@ def main():
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'x_realtime': x_rt,
-            'config': {'workload': f'{"C3" if args.mask == "oracle" else "C4"}: {R} rooms/GPU x {K} nodes x {M} mics, 16 kHz, L={Ls}, '
+            'config': {'workload': f'{cfg_name}: {R} rooms/GPU x {K} nodes x {M} mics, 16 kHz, L={Ls}, '
                                    f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced'
                                    + (f', ONLINE mode lambda=0.95 update_every={args.online_every}' if args.online_every else ''),
                        'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
