@@ -483,9 +483,18 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     }
     DISCO_FOR_MKR(X_)
 #undef X_
-    if (!launched)
-        hipLaunchKernelGGL(k_apply_generic, grid, block, 0, (hipStream_t)s, (const c32*)X, (const c32*)Z, (const c32*)w,
-                           (c32*)out, M, KR, c.nodes, ctx->T, ctx->F, conj_w, bpn, ctx->Kl, ctx->k0);
+    if (!launched) {
+        switch (M) {
+#define C_(M_)                                                                                                          \
+    case M_:                                                                                                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_m<M_>), grid, block, 0, (hipStream_t)s, (const c32*)X, (const c32*)Z, \
+                           (const c32*)w, (c32*)out, KR, c.nodes, ctx->T, ctx->F, conj_w, bpn, ctx->Kl, ctx->k0);        \
+        break;
+            C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8)
+#undef C_
+            default: return fail(ctx, DISCO_E_UNSUPPORTED, "disco_apply: more than 8 mics per node");
+        }
+    }
     return check_launch(ctx, "k_apply");
 }
 
@@ -837,8 +846,6 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     disco_c32* X = (disco_c32*)(ws + l.X);
     disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
     disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
-    disco_c32* Rss = (disco_c32*)(ws + l.Rss);
-    disco_c32* Rnn = (disco_c32*)(ws + l.Rnn);
     disco_c32* w = (disco_c32*)(ws + l.w);
     const int64_t G = (int64_t)c.rooms * c.nodes;
     const int M = c.mics, P2 = c.mics + c.nodes - 1;
@@ -855,8 +862,8 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
         return disco_istft(ctx, z, G, out, s);
     }
     // exchange + step 2 (tango.py:378-450), mask_for_z = 'local'
-    if ((rc = disco_cov_masked(ctx, X, mask_w, z, z, 1, P2, Rss, Rnn, s))) return rc;
-    if ((rc = disco_gevd_mwf_r1(ctx, Rss, Rnn, G * ctx->F, P2, c.mu, w, nullptr, s))) return rc;
+    if ((rc = disco_cov_masked(ctx, X, mask_w, z, z, 1, P2, nullptr, nullptr, s))) return rc;     // partial sums stay pending
+    if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w, nullptr, s))) return rc;
     if ((rc = disco_apply(ctx, X, z, w, P2, 1, yo, s))) return rc;
     return disco_istft(ctx, yo, G, out, s);
 }

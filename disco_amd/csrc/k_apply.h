@@ -42,11 +42,13 @@ __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const 
     }
 }
 
-// Run-time (M, K) form for the shapes outside the template table (P > 8): no register arrays, the filter is
-// re-read from L1 per element.
-__global__ __launch_bounds__(256) void k_apply_generic(const c32* __restrict__ X, const c32* __restrict__ Z,
-                                                        const c32* __restrict__ w, c32* __restrict__ out, int M, int KR,
-                                                        int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0) {
+// Shapes outside the (M, KR) template table (P > 8): M stays a template parameter so that the node's own M-vector is ONE
+// unrolled, vectorised load; the remote count KR is a run-time value walked by a fully unrolled, wave-uniformly
+// predicated loop (at most 15 remote rows, P <= 16).
+template <int M>
+__global__ __launch_bounds__(256) void k_apply_m(const c32* __restrict__ X, const c32* __restrict__ Z,
+                                                  const c32* __restrict__ w, c32* __restrict__ out, int KR,
+                                                  int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0) {
     const int P = M + KR;
     const long long g = blockIdx.x / blocks_per_node;
     const int b = (int)(blockIdx.x % blocks_per_node);
@@ -55,23 +57,30 @@ __global__ __launch_bounds__(256) void k_apply_generic(const c32* __restrict__ X
     const long long TF = (long long)T * F;
     const float sgn = conj_w ? -1.f : 1.f;
     const c32* wg = w + g * F * (long long)P;
+    const c32* Zr = Z ? Z + (r * K) * TF : nullptr;
     for (long long tf = (long long)b * blockDim.x + threadIdx.x; tf < TF; tf += (long long)blocks_per_node * blockDim.x) {
         const int f = (int)(tf % F);
-        const c32* wf = wg + f * P;
+        const c32* wf = wg + (long long)f * P;
         const c32* xp = X + (g * TF + tf) * M;
+        c32 x[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) x[i] = xp[i];
         float ar = 0.f, ai = 0.f;
+#pragma unroll
         for (int i = 0; i < M; ++i) {
-            const c32 x = xp[i];
             const c32 ww = make_float2(wf[i].x, sgn * wf[i].y);
-            ar = fmaf(ww.x, x.x, fmaf(-ww.y, x.y, ar));
-            ai = fmaf(ww.x, x.y, fmaf(ww.y, x.x, ai));
+            ar = fmaf(ww.x, x[i].x, fmaf(-ww.y, x[i].y, ar));
+            ai = fmaf(ww.x, x[i].y, fmaf(ww.y, x[i].x, ai));
         }
-        for (int jj = 0; jj < KR; ++jj) {
-            const int j = jj < k ? jj : jj + 1;
-            const c32 x = Z[(r * K + j) * TF + tf];
-            const c32 ww = make_float2(wf[M + jj].x, sgn * wf[M + jj].y);
-            ar = fmaf(ww.x, x.x, fmaf(-ww.y, x.y, ar));
-            ai = fmaf(ww.x, x.y, fmaf(ww.y, x.x, ai));
+#pragma unroll
+        for (int jj = 0; jj < 15; ++jj) {
+            if (jj < KR) {
+                const int j = jj < k ? jj : jj + 1;
+                const c32 z = Zr[j * TF + tf];
+                const c32 ww = make_float2(wf[M + jj].x, sgn * wf[M + jj].y);
+                ar = fmaf(ww.x, z.x, fmaf(-ww.y, z.y, ar));
+                ai = fmaf(ww.x, z.y, fmaf(ww.y, z.x, ai));
+            }
         }
         out[g * TF + tf] = make_float2(ar, ai);
     }
