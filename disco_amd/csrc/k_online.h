@@ -30,8 +30,11 @@ struct OnlineArgs {
     long long n_prob;    // R * Kl * F
 };
 
+#ifndef DISCO_ONLINE_WPE
+#define DISCO_ONLINE_WPE 3        // 168 VGPRs, 3 waves/SIMD: 10 % faster than the 174-VGPR / 2-wave allocation
+#endif
 template <int P>
-__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_online_mwf(OnlineArgs a) {
+__global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ONLINE_WPE : 1) void k_online_mwf(OnlineArgs a) {
     constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
     __shared__ c64 s_L[PROBS][SolveGeom<P>::LSZ];
     __shared__ c64 s_Y[PROBS][P][SolveGeom<P>::YW];
