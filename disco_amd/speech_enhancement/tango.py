@@ -41,7 +41,7 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
     """y, s, n: (R, K, M, L) float32.  Returns a dict of device-computed arrays with a leading room axis, in the
     engine's frame-major layout (R, K, T, F): yf, sf, nf, z_y, z_s, z_n, zn, masks_z, mask_w."""
     vads = _mask_names(vads)
-    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs')
+    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous')
     if mask_for_z not in MODES:
         raise NotImplementedError(f'mask_for_z must be one of {MODES}')       # 'use_oracle_sigs' is broken in the reference
     oracle_sigs = isinstance(mask_for_z, str) and 'use_oracle_' in mask_for_z
@@ -88,8 +88,10 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
             zs_rows, zn_rows = zy * mc, zy * (1 - mc)
         elif mask_for_z == 'use_oracle_refs':
             zs_rows, zn_rows = np.ascontiguousarray(Sh[..., ref_mic]), np.ascontiguousarray(Nh[..., ref_mic])
-        else:                                                                  # 'use_oracle_zs'
+        elif mask_for_z == 'use_oracle_zs':
             zs_rows, zn_rows = out['z_s'], out['z_n']
+        else:                                                                  # 'previous': the reference's final else
+            zs_rows, zn_rows = zy, zy                                          # (tango.py:428-429), unmasked z_y in both
         eng.cov_masked(Y, mw, zs_rows.astype(np.complex64), zn_rows.astype(np.complex64), mask_remote=False)
     w_glo, _ = eng.gevd_mwf_r1_pending(M + K - 1)
     out['yf'] = eng.apply(Y, w_glo, Z=z_y if K > 1 else None).numpy()
@@ -104,7 +106,7 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
     with ITS OWN mic count; the remote rows of step 2 are the z of all K nodes, exactly the node-sharded data flow.
     Returns per-node lists of (T, F) arrays."""
     vads = _mask_names(vads)
-    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs')
+    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous')
     if mask_for_z not in MODES:
         raise NotImplementedError(f'mask_for_z must be one of {MODES}')
     oracle_sigs = isinstance(mask_for_z, str) and 'use_oracle_' in mask_for_z
@@ -162,8 +164,10 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
                     zs_rows, zn_rows = Zy * MC, Zy * (1 - MC)
                 elif mask_for_z == 'use_oracle_refs':
                     zs_rows, zn_rows = ref_S, ref_N
-                else:
+                elif mask_for_z == 'use_oracle_zs':
                     zs_rows, zn_rows = Zs, Zn
+                else:                                                          # 'previous' (tango.py:428-429)
+                    zs_rows, zn_rows = Zy, Zy
                 eng.cov_masked(Yh, mw, np.ascontiguousarray(zs_rows, np.complex64), np.ascontiguousarray(zn_rows, np.complex64),
                                mask_remote=False)
             w_glo, _ = eng.gevd_mwf_r1_pending(M + K - 1)

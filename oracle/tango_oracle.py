@@ -88,7 +88,8 @@ def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=
     y, s, n = _as_node_list(y), _as_node_list(s), _as_node_list(n)
     K = len(y)
     ref_mics = [0] * K if ref_mics is None else list(ref_mics)
-    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs')
+    # 'previous' = any other string in the reference: the final else of tango.py:428-429, remote rows = unmasked z_y
+    MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous')
     if mask_for_z not in MODES:
         raise NotImplementedError(f'oracle implements mask_for_z in {MODES}')
     oracle_sigs = isinstance(mask_for_z, str) and 'use_oracle_' in mask_for_z          # tango.py:343

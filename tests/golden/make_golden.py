@@ -141,7 +141,7 @@ def main():
                 dm = {'K': np.array(K), 'L': np.array(L)}
                 for k in range(K):
                     dm[f'y{k}'], dm[f's{k}'], dm[f'n{k}'] = y[k], s[k], n[k]
-                for mfz in ('distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs'):
+                for mfz in ('distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous'):
                     res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mods=[None, None], mask_for_z=mfz)
                     for k in range(K):
                         for nm, arr in zip(['yf', 'sf', 'nf'], res[:3]):

@@ -42,7 +42,7 @@ def test_offline_tango_mask_for_z_none():
         assert relerr(res[0][k], o['yf'][k]) < 1e-4
 
 
-@pytest.mark.parametrize('mode', ['distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs'])
+@pytest.mark.parametrize('mode', ['distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous'])
 def test_offline_tango_mask_for_z_modes(mode, golden_dir):
     """Sender-side mask_for_z variants: vs the float64 oracle on a synthetic room (1e-4) and vs the reference's own
     outputs on the golden scene."""

@@ -117,7 +117,7 @@ def test_vectorised_oracle_matches_literal_port():
         assert worst < tol
 
 
-@pytest.mark.parametrize('mode', ['distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs'])
+@pytest.mark.parametrize('mode', ['distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous'])
 def test_vectorised_oracle_mask_for_z_modes_match_reference(golden_dir, mode):
     """The other mask_for_z modes (tango.py:343-345, 396-429) against the reference's own outputs."""
     g = np.load(os.path.join(golden_dir, 'tango_ref_modes_k2m2.npz'))
