@@ -16,6 +16,7 @@
 #include "k_metrics.h"
 #include "k_online.h"
 #include "k_stft.h"
+#include "k_vad.h"
 
 using namespace disco;
 
@@ -990,4 +991,17 @@ extern "C" int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, i
     hipLaunchKernelGGL(k_band_stats, dim3((unsigned)grid), dim3(METRIC_THREADS), 0, (hipStream_t)s, x, (long long)n_sig, (long long)len,
                        start, stop, b, a, n_bands, spb, stats);
     return check_launch(ctx, "k_band_stats");
+}
+
+// ---- 'ivad' mask (tango.py:217-221 + sigproc_utils.py:12-55) ---------------------------------------------------------------
+
+extern "C" int disco_mask_ivad(disco_ctx* ctx, const float* s_ref, int64_t n_sig, float* mask, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!s_ref || !mask || n_sig < 1) return fail(ctx, DISCO_E_ARG, "disco_mask_ivad: bad argument");
+    const disco_cfg& c = ctx->cfg;
+    if ((c.length + c.hop - 1) / c.hop > VAD_MAX_SEG) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mask_ivad: signal longer than 4096 hops");
+    if (n_sig > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mask_ivad: batch too large");
+    hipLaunchKernelGGL(k_vad_mask, dim3((unsigned)n_sig), dim3(VAD_THREADS), 0, (hipStream_t)s, s_ref, mask, c.length, ctx->T, ctx->F,
+                       c.n_fft, c.hop, 0.001f, 0.99f, 2);
+    return check_launch(ctx, "k_vad_mask");
 }

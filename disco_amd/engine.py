@@ -130,6 +130,15 @@ class Engine:
                                               z.ptr if z else None, yf.ptr if yf else None, None, 0, self.stream))
         return out, z, yf
 
+    def mask_ivad(self, s_ref):
+        """s_ref (n_sig, L) float32 (target image at channel 0) -> 'ivad' mask (n_sig, T, F)   [tango.py:217-221]"""
+        n_sig, Ls = s_ref.shape
+        assert Ls == self.Lsamp
+        ps, ks = self.to_device(s_ref, np.float32)
+        m = self.empty((n_sig, self.T, self.F), np.float32)
+        self._chk(self.lib.disco_mask_ivad(self.ctx, ps, n_sig, m.ptr, self.stream))
+        return m
+
     # ---- evaluation metrics (SURVEY 8f-3; disco_theque/metrics.py)
     def pair_stats(self, a, b, start=0, stop=None):
         """a, b (n_sig, L) float32 -> (n_sig, 8) float64 moments of a[:, start:stop], b[:, start:stop]

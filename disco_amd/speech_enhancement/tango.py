@@ -29,11 +29,24 @@ def _mask_names(vads):
     if isinstance(vads, str):
         vads = [vads, vads]
     for v in vads[:2]:
-        if v[:-1] not in ('irm', 'ibm', 'iam'):
-            if 'rnn' in v or v == 'ivad':
-                raise NotImplementedError(f"mask type '{v}': only the oracle TF masks are wired in this round (SURVEY 8f-1)")
+        if v[:-1] not in ('irm', 'ibm', 'iam') and v != 'ivad':
+            if 'rnn' in v:
+                raise NotImplementedError(f"mask type '{v}': DNN masks go through disco_amd.dnn.inloop (SURVEY 8f-1)")
             raise ValueError('Unknown value for `mask_type`')                 # tango.py:223
     return list(vads[:2])
+
+
+def _engine_mask_type(v):
+    return 'irm1' if v == 'ivad' else v                                       # the context's TF-mask type is unused for 'ivad'
+
+
+def _get_mask(eng, Sh_c, Nh_c, ts, vad):
+    """get_mask (tango.py:189-225) for the oracle types: TF mask of the channel's STFTs, or the frame VAD of `ts`.
+    Sh_c, Nh_c (..., T, F) STFTs of one channel; ts (n_sig, L) time signals of channel 0.  -> float32 (..., T, F)."""
+    if vad == 'ivad':
+        m = eng.mask_ivad(np.ascontiguousarray(ts, dtype=np.float32)).numpy()
+        return m.reshape(Sh_c.shape)
+    return eng.tf_mask(np.ascontiguousarray(Sh_c), np.ascontiguousarray(Nh_c), type=vad).numpy().astype(np.float32)
 
 
 def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_sigs='zs_hat', n_fft=N_FFT,
@@ -49,20 +62,20 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
     s = np.ascontiguousarray(s, dtype=np.float32)
     n = np.ascontiguousarray(n, dtype=np.float32)
     R, K, M, L = y.shape
-    eng = get_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=vads[0], pad_mode=pad_mode, ref_mic=ref_mic,
-                     mu=mu, staged_step2=True)
+    eng = get_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=_engine_mask_type(vads[0]), pad_mode=pad_mode,
+                     ref_mic=ref_mic, mu=mu, staged_step2=True)
     T, F = eng.T, eng.F
     G = R * K
     Y = eng.stft(y.reshape(G, M, L)).reshape(R, K, T, F, M)
     S = eng.stft(s.reshape(G, M, L)).reshape(R, K, T, F, M)
     N = eng.stft(n.reshape(G, M, L)).reshape(R, K, T, F, M)
     Sh, Nh = S.numpy(), N.numpy()
-    # masks at the reference mic (step 1, tango.py:338-342) and at channel 0 (step 2, tango.py:391)
-    masks_z = eng.tf_mask(np.ascontiguousarray(Sh[..., ref_mic]), np.ascontiguousarray(Nh[..., ref_mic]), type=vads[0])
-    same = (ref_mic == 0 and vads[1] == vads[0])
-    mask_w = masks_z if same else eng.tf_mask(np.ascontiguousarray(Sh[..., 0]), np.ascontiguousarray(Nh[..., 0]), type=vads[1])
-    mz = masks_z.numpy().astype(np.float32)
-    mw = mz if same else mask_w.numpy().astype(np.float32)
+    # masks at the reference mic (step 1, tango.py:338-342) and at channel 0 (step 2, tango.py:391); 'ivad' always takes
+    # the time signal of channel 0 (ts = s[node][0])
+    ts0 = s[:, :, 0].reshape(G, L)
+    mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], ts0, vads[0])
+    same = (vads[1] == vads[0]) and (ref_mic == 0 or vads[0] == 'ivad')
+    mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], ts0, vads[1])
     # step 1 (tango.py:357-376)
     if oracle_sigs:                                                            # statistics from the oracle images (tango.py:343-345)
         Rss, _ = eng.cov_masked(S, np.ones_like(mz))
@@ -84,6 +97,8 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
         if mask_for_z == 'distant':                                            # to the same covariance kernel unmasked
             zs_rows, zn_rows = zy * mw, zy * (1 - mw)
         elif mask_for_z == 'compressed':
+            if vads[0] == 'ivad':
+                raise NotImplementedError("mask_for_z='compressed' with 'ivad': the reference passes no time signal there (tango.py:403) and fails")
             mc = eng.tf_mask(out['z_s'], out['z_n'], type=vads[0]).numpy()
             zs_rows, zn_rows = zy * mc, zy * (1 - mc)
         elif mask_for_z == 'use_oracle_refs':
@@ -122,16 +137,17 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
     try:
         for k in range(K):                                                     # step 1 (tango.py:326-376)
             M = y[k].shape[0]
-            eng = get_engine(rooms=1, nodes=K, mics=M, length=L, n_fft=n_fft, mask=vads[0], pad_mode=pad_mode,
+            eng = get_engine(rooms=1, nodes=K, mics=M, length=L, n_fft=n_fft, mask=_engine_mask_type(vads[0]), pad_mode=pad_mode,
                              ref_mic=ref_mic, mu=mu, staged_step2=True)
             engines.add(eng)
             eng.set_node_shard(k, 1)
             T, F = eng.T, eng.F
             Y, S, N = (eng.stft(a[None]).reshape(1, 1, T, F, M) for a in (y[k], s[k], n[k]))
             Sh, Nh = S.numpy(), N.numpy()
-            mz = eng.tf_mask(np.ascontiguousarray(Sh[..., ref_mic]), np.ascontiguousarray(Nh[..., ref_mic]), type=vads[0]).numpy().astype(np.float32)
-            same = (ref_mic == 0 and vads[1] == vads[0])
-            mw = mz if same else eng.tf_mask(np.ascontiguousarray(Sh[..., 0]), np.ascontiguousarray(Nh[..., 0]), type=vads[1]).numpy().astype(np.float32)
+            ts0 = s[k][0][None]
+            mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], ts0, vads[0])
+            same = (vads[1] == vads[0]) and (ref_mic == 0 or vads[0] == 'ivad')
+            mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], ts0, vads[1])
             if oracle_sigs:
                 Rss, _ = eng.cov_masked(S, np.ones_like(mz))
                 _, Rnn = eng.cov_masked(N, np.zeros_like(mz))
@@ -147,6 +163,8 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
         Zy, Zs, Zn, ZN = (np.ascontiguousarray(np.stack(out[nm])[None]) for nm in ('z_y', 'z_s', 'z_n', 'zn'))
         MW = np.stack(out['mask_w'])[None]
         if mask_for_z == 'compressed':                                         # sender-side mask from (z_s, z_n), tango.py:402-405
+            if vads[0] == 'ivad':
+                raise NotImplementedError("mask_for_z='compressed' with 'ivad': the reference passes no time signal there and fails")
             MC = st[0][0].tf_mask(Zs[0], Zn[0], type=vads[0]).numpy()[None]
         ref_S = np.stack([t[3][0, 0, ..., ref_mic] for t in st])[None]
         ref_N = np.stack([t[4][0, 0, ..., ref_mic] for t in st])[None]

@@ -207,6 +207,12 @@ int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, con
                         float* out, disco_c32* z_y, disco_c32* yf,
                         void* workspace, size_t workspace_bytes, disco_stream s);
 
+/* 'ivad' mask -- get_mask(..., mask_type='ivad', ts=s[node][0]) (tango.py:217-221): vad_oracle_batch (sigproc_utils.py:12-55:
+ * window power test against 0.001 * the 0.99-quantile of the centred signal's instantaneous power, win = n_fft, hop) sampled
+ * every hop and tiled over frequency; frames beyond ceil(L / hop) are 0.
+ * s_ref [n_sig][L] (the target's time signal at channel 0) -> mask [n_sig][T][F] of 0.0 / 1.0.  L <= 4096 hops. */
+int disco_mask_ivad(disco_ctx* ctx, const float* s_ref, int64_t n_sig, float* mask, disco_stream s);
+
 /* ---- online / adaptive mode -----------------------------------------------------------------
  * The reference ships the smoothing primitive spatial_correlation_matrix (se_utils/internal_formulas.py:84-103:
  * R <- lambda R + M (1 - lambda) x x^H) and intern_filter (:56-73) but no loop around them; these entry points are

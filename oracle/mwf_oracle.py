@@ -99,3 +99,25 @@ def spatial_correlation_matrix(Rxx, x, lambda_cor=0.95, M=None):
     if M is None:
         return lambda_cor * Rxx + (1 - lambda_cor) * np.outer(x, np.conjugate(x).T)
     return lambda_cor * Rxx + M * (1 - lambda_cor) * np.outer(x, np.conjugate(x).T)
+
+
+def vad_oracle_batch(x_, win_len=512, win_hop=256, thr=0.001, rat=2):
+    """sigproc_utils.py:12-55 -- power-based oracle VAD, one decision per window, written back over the window's samples."""
+    x = x_ - np.mean(x_)
+    x2 = abs(x ** 2)
+    thr_ = thr * np.quantile(x2, 0.99)
+    vad_o = np.zeros(len(x2))
+    for n in np.arange(int(np.ceil((len(x2) - win_len) / win_hop + 1))):
+        lo, hi = n * win_hop, np.minimum(n * win_hop + win_len, len(x2))
+        nb_va = np.sum(x2[lo:hi] > thr_)
+        if nb_va >= int((hi - lo) / rat):                      # np.int in the reference (numpy 1.18)
+            vad_o[lo:hi] = 1
+    return vad_o
+
+
+def ivad_mask(ts, shape, n_fft=512, hop=256):
+    """get_mask's 'ivad' branch (tango.py:217-221): the VAD sampled every hop, tiled over frequency; float64 zeros beyond."""
+    m = np.zeros(shape)
+    vad = vad_oracle_batch(ts, win_len=n_fft, win_hop=hop)[::hop]
+    m[:, :len(vad)] = np.tile(vad, (shape[0], 1))
+    return m

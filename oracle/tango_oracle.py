@@ -42,9 +42,11 @@ def concatenate_signals(y, z, k, m=1):
     return np.concatenate((y[k], m * np.array(z)[:k], m * np.array(z)[k + 1:]), axis=0)
 
 
-def _oracle_mask(S, N, mask_type):
+def _oracle_mask(S, N, mask_type, ts=None, n_fft=512, hop=256):
     if mask_type[:-1] in ('irm', 'ibm', 'iam'):
         return mo.tf_mask(S, N, type=mask_type)
+    if mask_type == 'ivad':                                    # tango.py:217-221, ts = s[node][0]
+        return mo.ivad_mask(ts, np.shape(S), n_fft, hop)
     raise ValueError('Unknown value for `mask_type`')          # tango.py:223
 
 
@@ -107,7 +109,7 @@ def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=
     # ---- step 1 (tango.py:326-376)
     for k in range(K):
         r = ref_mics[k]
-        m = masks[0][k] if masks is not None else _oracle_mask(S[k][r], N[k][r], vads[0])
+        m = masks[0][k] if masks is not None else _oracle_mask(S[k][r], N[k][r], vads[0], s[k][0], n_fft, hop)
         out['masks_z'][k] = m
         if oracle_sigs:                                                            # tango.py:343-345
             s_hat, n_hat = S[k], N[k]
@@ -141,7 +143,7 @@ def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=
             if masks is not None:
                 mw = masks[1][k]
             else:
-                mw = _oracle_mask(S[k][0], N[k][0], vads[1])                       # tango.py:391 (channel 0)
+                mw = _oracle_mask(S[k][0], N[k][0], vads[1], s[k][0], n_fft, hop)      # tango.py:391 (channel 0)
             out['mask_w'][k] = mw
         for k in range(K):                                                         # tango.py:396-409
             if mask_for_z == 'distant':
@@ -219,7 +221,7 @@ def offline_tango_literal(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_
             Sk.append(so.stft(s[k][c], n_fft, hop, pad_mode))
             Nk.append(so.stft(n[k][c], n_fft, hop, pad_mode))
             if c == ref_mics[k]:
-                mask_z = _oracle_mask(Sk[c], Nk[c], vads[0])
+                mask_z = _oracle_mask(Sk[c], Nk[c], vads[0], s[k][0], n_fft, hop)
                 masks_z[k] = mask_z
             sh.append(mask_z * Yk[c])
             nh.append((1 - mask_z) * Yk[c])
@@ -254,7 +256,7 @@ def offline_tango_literal(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_
         in_y[k] = concatenate_signals(Y, z_y, k)
         in_s[k] = concatenate_signals(S, z_s, k)
         in_n[k] = concatenate_signals(N, z_n, k)
-        mask_w[k] = _oracle_mask(S[k][0], N[k][0], vads[1])
+        mask_w[k] = _oracle_mask(S[k][0], N[k][0], vads[1], s[k][0], n_fft, hop)
     s_hat_w = [[] for _ in range(K)]
     n_hat_w = [[] for _ in range(K)]
     for k in range(K):

@@ -163,6 +163,17 @@ static inline void __builtin_amdgcn_wave_barrier() { pthread_barrier_wait(&hipem
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
 
+static inline int atomicAdd(int* p, int v) { return __sync_fetch_and_add(p, v); }
+static inline unsigned __float_as_uint(float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+static inline float __uint_as_float(unsigned u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }

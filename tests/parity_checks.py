@@ -354,6 +354,31 @@ def check_metrics(make_engine, golden_dir, L_cut=None, start=0):
     return errs
 
 
+def check_ivad(make_engine, golden_dir):
+    """disco_mask_ivad against the reference's own vad_oracle_batch / get_mask('ivad') outputs (tests/golden/ivad_ref.npz)."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'ivad_ref.npz'))
+    errs = {}
+    for i in range(int(g['n_vad'])):
+        x, vad = g[f'vad_x{i}'], g[f'vad_o{i}']
+        L = len(x)
+        eng = make_engine(rooms=1, nodes=1, mics=1, length=L)
+        m = eng.mask_ivad(x[None]).numpy()[0]                       # (T, F)
+        want = np.zeros(eng.T)
+        v = vad[::256]
+        want[:len(v)] = v
+        assert np.all(m == m[:, :1]), 'mask must be constant over frequency'
+        errs[f'vad{i}_frames_wrong'] = int(np.sum(m[:, 0] != want))
+        assert errs[f'vad{i}_frames_wrong'] == 0, errs
+    K, L = int(g['K']), int(g['L'])
+    eng = make_engine(rooms=1, nodes=K, mics=2, length=L)
+    for k in range(K):
+        m = eng.mask_ivad(g[f's{k}'][0][None]).numpy()[0]
+        errs[f'mask{k}_wrong'] = int(np.sum(m.T != g[f'masks_z{k}']))
+        assert errs[f'mask{k}_wrong'] == 0, errs
+    return errs
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

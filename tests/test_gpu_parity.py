@@ -73,6 +73,10 @@ def test_metrics(make_engine, golden_dir, start):
     pc.check_metrics(make_engine, golden_dir, start=start)
 
 
+def test_ivad(make_engine, golden_dir):
+    pc.check_ivad(make_engine, golden_dir)
+
+
 def test_online_golden(make_engine, golden_dir):
     pc.check_online_golden(make_engine, golden_dir)
 

@@ -116,6 +116,22 @@ def test_offline_tango_ragged_nodes(golden_dir, mode):
                 assert relerr(res[i][k], g[f'{nm}{k}']) < 2e-2, (nm, k, relerr(res[i][k], g[f'{nm}{k}']))
 
 
+def test_offline_tango_ivad(golden_dir):
+    """vads = 'ivad' (frame VAD of the target tiled over frequency) against the reference's own offline_tango outputs."""
+    from disco_amd.speech_enhancement.tango import offline_tango
+    g = np.load(os.path.join(golden_dir, 'ivad_ref.npz'))
+    K = int(g['K'])
+    y, s, n = ([g[f'{c}{k}'] for k in range(K)] for c in 'ysn')
+    res = offline_tango(y, s, n, vads=['ivad', 'ivad'], mods=[None, None])
+    names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
+    for i, nm in enumerate(names):
+        for k in range(K):
+            if 'mask' in nm:
+                assert np.array_equal(res[i][k], g[f'{nm}{k}']), (nm, k)
+            else:
+                assert relerr(res[i][k], g[f'{nm}{k}']) < 1e-3, (nm, k, relerr(res[i][k], g[f'{nm}{k}']))
+
+
 def test_offline_tango_errors():
     from disco_amd.speech_enhancement.tango import offline_tango
     y = np.zeros((2, 2, 4096), np.float32)

@@ -67,6 +67,10 @@ def test_emu_metrics(make_engine, golden_dir):
     print(pc.check_metrics(make_engine, golden_dir, L_cut=1500, start=200))
 
 
+def test_emu_ivad(make_engine, golden_dir):
+    print(pc.check_ivad(make_engine, golden_dir))
+
+
 def test_emu_node_sharded(make_engine):
     print(pc.check_node_sharded(make_engine, R=1, K=2, M=2, L=4096, world=2))
 

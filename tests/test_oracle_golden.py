@@ -167,3 +167,17 @@ def test_metrics_oracle_matches_reference(golden_dir):
         assert np.abs(mo.fw_snr(s_out, n_out, fs)[0] - g['fw_snr'][c]).max() < 1e-9
         assert np.abs(mo.fw_sd(s_out, s_in, fs)[0] - g['fw_sd'][c]).max() < 1e-9
         assert abs(mo.si_sdr(s_in.astype(np.float64), (s_out + n_out).astype(np.float64)) - g['si_sdr'][c]) < 1e-9
+
+
+def test_ivad_oracle_matches_reference(golden_dir):
+    """vad_oracle_batch and the whole path with vads='ivad' == the reference's own code (tests/golden/make_golden_ivad.py)."""
+    g = np.load(os.path.join(golden_dir, 'ivad_ref.npz'))
+    for i in range(int(g['n_vad'])):
+        assert np.array_equal(mo.vad_oracle_batch(g[f'vad_x{i}']), g[f'vad_o{i}'])
+    K = int(g['K'])
+    y, s, n = ([g[f'{c}{k}'] for k in range(K)] for c in 'ysn')
+    lit = to.offline_tango_literal(y, s, n, vads=['ivad', 'ivad'])
+    names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
+    for i, nm in enumerate(names):
+        for k in range(K):
+            assert np.array_equal(np.asarray(lit[i][k]), g[f'{nm}{k}']), (nm, k)
