@@ -25,27 +25,44 @@ def _as_batch(x):
     return np.ascontiguousarray(np.stack(nodes)[None])
 
 
-def _mask_names(vads):
+def _mask_names(vads, mods=None):
     if isinstance(vads, str):
         vads = [vads, vads]
-    for v in vads[:2]:
-        if v[:-1] not in ('irm', 'ibm', 'iam') and v != 'ivad':
-            if 'rnn' in v:
-                raise NotImplementedError(f"mask type '{v}': DNN masks go through disco_amd.dnn.inloop (SURVEY 8f-1)")
-            raise ValueError('Unknown value for `mask_type`')                 # tango.py:223
+    mods = [None, None] if mods is None else list(mods)
+    for i, v in enumerate(vads[:2]):
+        if v[:-1] in ('irm', 'ibm', 'iam') or v == 'ivad':
+            continue
+        if v == 'crnn':                                                       # tango.py:209-215; models from dnn/crnn.py
+            if mods[i] is None and not (i == 1 and vads[0] == 'crnn'):        # step 2 may re-use the step-1 mask (388-389)
+                raise ValueError("vads='crnn' needs a model in `mods` (disco_amd.dnn.crnn.build_crnn)")
+            continue
+        if 'rnn' in v:
+            raise NotImplementedError(f"mask type '{v}': the reference's RNN model file (dnn/models/heymann.py) is not shipped")
+        raise ValueError('Unknown value for `mask_type`')                     # tango.py:223
     return list(vads[:2])
 
 
 def _engine_mask_type(v):
-    return 'irm1' if v == 'ivad' else v                                       # the context's TF-mask type is unused for 'ivad'
+    return 'irm1' if v in ('ivad', 'crnn') else v                             # the context's TF-mask type is unused for those
 
 
-def _get_mask(eng, Sh_c, Nh_c, ts, vad):
-    """get_mask (tango.py:189-225) for the oracle types: TF mask of the channel's STFTs, or the frame VAD of `ts`.
-    Sh_c, Nh_c (..., T, F) STFTs of one channel; ts (n_sig, L) time signals of channel 0.  -> float32 (..., T, F)."""
+def _get_mask(eng, Sh_c, Nh_c, ts, vad, mod=None, Yh_c=None, z_rows=None):
+    """get_mask (tango.py:189-225): TF mask of the channel's STFTs, the frame VAD of `ts`, or the CRNN's prediction from
+    |Y| of that channel [+ |z| of the other nodes] (prepare_data / reshape_mask live in dnn/crnn.py:predict_masks).
+    Sh_c, Nh_c, Yh_c (..., T, F) STFTs of one channel; ts (n_sig, L); z_rows (..., C-1, T, F) or None.  -> float32 (..., T, F)."""
     if vad == 'ivad':
         m = eng.mask_ivad(np.ascontiguousarray(ts, dtype=np.float32)).numpy()
         return m.reshape(Sh_c.shape)
+    if vad == 'crnn':
+        import torch
+        T, F = Yh_c.shape[-2:]
+        mag = np.abs(Yh_c).reshape(-1, 1, T, F)
+        if z_rows is not None:
+            mag = np.concatenate([mag, np.abs(z_rows).reshape(mag.shape[0], -1, T, F)], axis=1)
+        par = next(mod.parameters())
+        with torch.no_grad():
+            m = mod.predict_masks(torch.from_numpy(np.ascontiguousarray(mag)).to(par.device, par.dtype))
+        return m.float().cpu().numpy().reshape(Yh_c.shape)
     return eng.tf_mask(np.ascontiguousarray(Sh_c), np.ascontiguousarray(Nh_c), type=vad).numpy().astype(np.float32)
 
 
@@ -53,7 +70,8 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
                           pad_mode='reflect', ref_mic=0, mu=1.0):
     """y, s, n: (R, K, M, L) float32.  Returns a dict of device-computed arrays with a leading room axis, in the
     engine's frame-major layout (R, K, T, F): yf, sf, nf, z_y, z_s, z_n, zn, masks_z, mask_w."""
-    vads = _mask_names(vads)
+    vads = _mask_names(vads, mods)
+    mods = [None, None] if mods is None else list(mods)
     MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous')
     if mask_for_z not in MODES:
         raise NotImplementedError(f'mask_for_z must be one of {MODES}')       # 'use_oracle_sigs' is broken in the reference
@@ -70,12 +88,14 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
     S = eng.stft(s.reshape(G, M, L)).reshape(R, K, T, F, M)
     N = eng.stft(n.reshape(G, M, L)).reshape(R, K, T, F, M)
     Sh, Nh = S.numpy(), N.numpy()
-    # masks at the reference mic (step 1, tango.py:338-342) and at channel 0 (step 2, tango.py:391); 'ivad' always takes
-    # the time signal of channel 0 (ts = s[node][0])
-    ts0 = s[:, :, 0].reshape(G, L)
-    mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], ts0, vads[0])
-    same = (vads[1] == vads[0]) and (ref_mic == 0 or vads[0] == 'ivad')
-    mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], ts0, vads[1])
+    # masks at the reference mic (step 1, tango.py:338-342: ts = that channel's time signal) and at channel 0 (step 2,
+    # tango.py:391-394: ts = s[node][0])
+    Yh = Y.numpy() if 'crnn' in vads else None
+    mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], s[:, :, ref_mic].reshape(G, L), vads[0], mods[0],
+                   None if Yh is None else Yh[..., ref_mic])
+    if vads[1] != 'crnn':                                                      # a DNN step-2 mask needs z: after step 1
+        same = (vads[1] == vads[0]) and ref_mic == 0
+        mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], s[:, :, 0].reshape(G, L), vads[1])
     # step 1 (tango.py:357-376)
     if oracle_sigs:                                                            # statistics from the oracle images (tango.py:343-345)
         Rss, _ = eng.cov_masked(S, np.ones_like(mz))
@@ -86,7 +106,16 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
         w_loc, _ = eng.gevd_mwf_r1_pending(M)
     z_y, z_s, z_n = eng.apply(Y, w_loc), eng.apply(S, w_loc), eng.apply(N, w_loc)
     zn = eng.noise_residual(Y, z_y)
-    out = dict(masks_z=mz, mask_w=mw, z_y=z_y.numpy(), z_s=z_s.numpy(), z_n=z_n.numpy(), zn=zn.numpy())
+    out = dict(masks_z=mz, z_y=z_y.numpy(), z_s=z_s.numpy(), z_n=z_n.numpy(), zn=zn.numpy())
+    if vads[1] == 'crnn':
+        if mods[1] is None:                                                    # same predicted mask as at step 1 (tango.py:388-389)
+            mw = mz
+        else:                                                                  # CRNN([|Y_k,0| ; |z_j|, j != k]) (tango.py:387-394)
+            from ..dnn.crnn import get_z_for_mask
+            rows = np.stack([np.stack([get_z_for_mask(out['z_y'][r], out['zn'][r], k, K, z_sigs) for k in range(K)])
+                             for r in range(R)]) if K > 1 else None
+            mw = _get_mask(eng, None, None, None, 'crnn', mods[1], Yh[..., 0], rows)
+    out['mask_w'] = mw
     # exchange + step 2 (tango.py:378-450)
     if mask_for_z == 'local':
         eng.cov_masked(Y, mw, z_y, z_y, mask_remote=True)
@@ -97,8 +126,8 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
         if mask_for_z == 'distant':                                            # to the same covariance kernel unmasked
             zs_rows, zn_rows = zy * mw, zy * (1 - mw)
         elif mask_for_z == 'compressed':
-            if vads[0] == 'ivad':
-                raise NotImplementedError("mask_for_z='compressed' with 'ivad': the reference passes no time signal there (tango.py:403) and fails")
+            if vads[0] in ('ivad', 'crnn'):
+                raise NotImplementedError("mask_for_z='compressed' needs a TF mask type at step 1 (the reference passes neither a time signal nor z to get_mask there, tango.py:403)")
             mc = eng.tf_mask(out['z_s'], out['z_n'], type=vads[0]).numpy()
             zs_rows, zn_rows = zy * mc, zy * (1 - mc)
         elif mask_for_z == 'use_oracle_refs':
@@ -120,7 +149,9 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
     batched layout is uniform, so every node runs as a one-node shard (`disco_set_node_shard(k, 1)`) of a K-node context
     with ITS OWN mic count; the remote rows of step 2 are the z of all K nodes, exactly the node-sharded data flow.
     Returns per-node lists of (T, F) arrays."""
-    vads = _mask_names(vads)
+    vads = _mask_names(vads, [1, 1])
+    if 'crnn' in vads:
+        raise NotImplementedError('DNN masks with ragged channel counts: run the nodes through disco_amd.dnn.inloop')
     MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous')
     if mask_for_z not in MODES:
         raise NotImplementedError(f'mask_for_z must be one of {MODES}')
@@ -144,10 +175,9 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
             T, F = eng.T, eng.F
             Y, S, N = (eng.stft(a[None]).reshape(1, 1, T, F, M) for a in (y[k], s[k], n[k]))
             Sh, Nh = S.numpy(), N.numpy()
-            ts0 = s[k][0][None]
-            mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], ts0, vads[0])
-            same = (vads[1] == vads[0]) and (ref_mic == 0 or vads[0] == 'ivad')
-            mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], ts0, vads[1])
+            mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], s[k][ref_mic][None], vads[0])
+            same = (vads[1] == vads[0]) and ref_mic == 0
+            mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], s[k][0][None], vads[1])
             if oracle_sigs:
                 Rss, _ = eng.cov_masked(S, np.ones_like(mz))
                 _, Rnn = eng.cov_masked(N, np.zeros_like(mz))
@@ -204,7 +234,7 @@ def offline_tango(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_sigs='zs
     names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
     yb, sb, nb = _as_batch(y), _as_batch(s), _as_batch(n)
     if yb is None or sb is None or nb is None:
-        d = _offline_tango_ragged(y, s, n, vads, mask_for_z)
+        d = _offline_tango_ragged(y, s, n, vads, mask_for_z)                   # (DNN masks: uniform nodes only)
         return tuple([np.ascontiguousarray(v.T) for v in d[nm]] for nm in names)
     d = offline_tango_batched(yb, sb, nb, vads=vads, mods=mods, mask_for_z=mask_for_z, z_sigs=z_sigs)
     K = d['yf'].shape[1]

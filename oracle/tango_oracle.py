@@ -109,7 +109,7 @@ def offline_tango_vec(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_fft=
     # ---- step 1 (tango.py:326-376)
     for k in range(K):
         r = ref_mics[k]
-        m = masks[0][k] if masks is not None else _oracle_mask(S[k][r], N[k][r], vads[0], s[k][0], n_fft, hop)
+        m = masks[0][k] if masks is not None else _oracle_mask(S[k][r], N[k][r], vads[0], s[k][r], n_fft, hop)
         out['masks_z'][k] = m
         if oracle_sigs:                                                            # tango.py:343-345
             s_hat, n_hat = S[k], N[k]
@@ -221,7 +221,7 @@ def offline_tango_literal(y, s, n, vads=('irm1', 'irm1'), mask_for_z='local', n_
             Sk.append(so.stft(s[k][c], n_fft, hop, pad_mode))
             Nk.append(so.stft(n[k][c], n_fft, hop, pad_mode))
             if c == ref_mics[k]:
-                mask_z = _oracle_mask(Sk[c], Nk[c], vads[0], s[k][0], n_fft, hop)
+                mask_z = _oracle_mask(Sk[c], Nk[c], vads[0], s[k][c], n_fft, hop)   # ts = s_ (tango.py:340-341)
                 masks_z[k] = mask_z
             sh.append(mask_z * Yk[c])
             nh.append((1 - mask_z) * Yk[c])

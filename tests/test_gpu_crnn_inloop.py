@@ -62,3 +62,38 @@ def test_crnn_in_loop_vs_oracle(K, M, two_models):
             assert np.abs(ref_mw - mw[r]).max() < 2e-3          # |z| carries the (bounded) step-1 mask differences
         else:
             assert np.array_equal(mw, mz)                        # tango.py:388-389
+
+
+@pytest.mark.parametrize('two_models', [True, False])
+def test_offline_tango_with_crnn_masks(two_models):
+    """The reference call surface with vads='crnn' and models in `mods` (tango.py:209-215, 387-394): the masks it returns are
+    the networks' predictions, and every other output equals the float64 oracle fed with those masks."""
+    import torch
+    from disco_amd.speech_enhancement.tango import offline_tango
+    from oracle import tango_oracle as to
+    K, M, L = 3, 2, 20000
+    y, s, n, _ = synth.make_room_numpy(12, K=K, M=M, L=L)
+    dev = torch.device('cuda', 0)
+    model_z = _rand_model(1, 1, dev)
+    model_w = _rand_model(K, 2, dev) if two_models else None
+    res = offline_tango(list(y), list(s), list(n), vads=['crnn', 'crnn'], mods=[model_z, model_w])
+    names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
+    mz, mw = res[7], res[8]
+    o = to.offline_tango_vec(y, s, n, masks=([m.astype(np.float64) for m in mz], [m.astype(np.float64) for m in mw]),
+                             precision='f64', solver='eigh')
+    ref = to.as_reference_tuple(o)
+    for nm, got, want in zip(names[:7], res[:7], ref[:7]):
+        for k in range(K):
+            assert pc.relerr(got[k], want[k]) < 1e-3, (nm, k, pc.relerr(got[k], want[k]))
+    cpu_z = _rand_model(1, 1, 'cpu').double()
+    mag = np.stack([np.abs(o['Y'][k][0]).T for k in range(K)])[:, None]
+    ref_mz = cpu_z.predict_masks(torch.from_numpy(mag)).numpy()
+    assert max(np.abs(ref_mz[k].T - mz[k]).max() for k in range(K)) < 2e-4
+    if two_models:
+        cpu_w = _rand_model(K, 2, 'cpu').double()
+        zmag = [np.abs(o['z_y'][j]).T for j in range(K)]
+        inp = np.stack([np.stack([np.abs(o['Y'][k][0]).T] + [zmag[j] for j in range(K) if j != k]) for k in range(K)])
+        ref_mw = cpu_w.predict_masks(torch.from_numpy(inp)).numpy()
+        assert max(np.abs(ref_mw[k].T - mw[k]).max() for k in range(K)) < 2e-3
+    else:
+        assert all(np.array_equal(mw[k], mz[k]) for k in range(K))

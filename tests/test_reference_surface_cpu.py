@@ -58,8 +58,10 @@ def test_offline_tango_argument_errors():
     y = np.zeros((2, 2, 4096), np.float32)
     with pytest.raises(ValueError):
         offline_tango(y, y, y, vads=['bad1', 'irm1'])
+    with pytest.raises(ValueError):
+        offline_tango(y, y, y, vads=['crnn', 'crnn'])            # DNN masks need models in `mods`
     with pytest.raises(NotImplementedError):
-        offline_tango(y, y, y, vads=['crnn', 'crnn'])
+        offline_tango(y, y, y, vads=['rnn', 'rnn'])              # dnn/models/heymann.py is not shipped by the reference
     a = [np.ones((2, 3, 4)), 2 * np.ones((2, 3, 4))]
     z = [5 * np.ones((3, 4)), 7 * np.ones((3, 4))]
     c = concatenate_signals(a, z, 0)
