@@ -56,6 +56,7 @@ PROTOTYPES = {
     'disco_step2_apply_istft_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_tango_enhance': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'disco_mask_ivad': (_int, [_vp, _vp, _i64, _vp, _vp]),
+    'disco_rir_convolve': (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _int, _vp]),
     'disco_pair_stats': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp]),
     'disco_band_stats': (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
     'disco_online_mwf': (_int, [_vp, _vp, _vp, _vp, _int, _f, _f, _int, _f, _vp, _vp, _vp]),

@@ -10,6 +10,7 @@
 
 #include "../../include/disco_hip.h"
 #include "k_apply.h"
+#include "k_conv.h"
 #include "k_cov.h"
 #include "k_fused.h"
 #include "k_solve.h"
@@ -34,6 +35,9 @@ struct disco_ctx {
     size_t scratch2_bytes;
     int loc_chunks, loc_M;           // geometry of the step-1 partials kept in `scratch` for that re-use
     int pending_skiploc;             // the pending step-2 partials (scratch2) lack their leading loc_M x loc_M block
+    c32* d_tw_conv;                  // 1024-point twiddles of disco_rir_convolve (== d_tw when n_fft is 1024), lazy
+    void* conv_ws;                   // its spectra workspace, lazy
+    size_t conv_ws_bytes;
     int k0, Kl;                      // node shard: this context holds nodes [k0, k0 + Kl) of every room (default 0, K)
     char err[512];
 };
@@ -115,6 +119,9 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->loc_chunks = 0;
     ctx->loc_M = 0;
     ctx->pending_skiploc = 0;
+    ctx->d_tw_conv = nullptr;
+    ctx->conv_ws = nullptr;
+    ctx->conv_ws_bytes = 0;
     ctx->err[0] = 0;
     const int N = cfg->n_fft;
     std::vector<float> win(N);
@@ -146,6 +153,8 @@ extern "C" void disco_destroy(disco_ctx* ctx) {
     if (ctx->own_ws) (void)hipFree(ctx->own_ws);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    if (ctx->d_tw_conv && ctx->d_tw_conv != ctx->d_tw) (void)hipFree(ctx->d_tw_conv);
+    if (ctx->conv_ws) (void)hipFree(ctx->conv_ws);
     delete ctx;
 }
 
@@ -1004,4 +1013,56 @@ extern "C" int disco_mask_ivad(disco_ctx* ctx, const float* s_ref, int64_t n_sig
     hipLaunchKernelGGL(k_vad_mask, dim3((unsigned)n_sig), dim3(VAD_THREADS), 0, (hipStream_t)s, s_ref, mask, c.length, ctx->T, ctx->F,
                        c.n_fft, c.hop, 0.001f, 0.99f, 2);
     return check_launch(ctx, "k_vad_mask");
+}
+
+// ---- RIR convolution, the step before the path -----------------------------------------------------------
+
+extern "C" int disco_rir_convolve(disco_ctx* ctx, const float* dry, const float* rir, int64_t n_sig, int n_ch, int dry_len,
+                                  int rir_len, float* out, int out_len, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!dry || !rir || !out || n_sig < 1 || n_ch < 1 || dry_len < 1 || rir_len < 1 || out_len < 1)
+        return fail(ctx, DISCO_E_ARG, "disco_rir_convolve: bad argument");
+    const int P = (rir_len + CV_B - 1) / CV_B;
+    if (P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_rir_convolve: impulse responses longer than 8192 taps");
+    const int nb = (out_len + CV_B - 1) / CV_B;
+    if (n_sig * n_ch > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_rir_convolve: batch too large");
+    hipStream_t st = (hipStream_t)s;
+    if (!ctx->d_tw_conv) {
+        if (ctx->cfg.n_fft == CV_N) {
+            ctx->d_tw_conv = ctx->d_tw;
+        } else {
+            std::vector<c32> tw(CV_N);
+            const double two_pi = 6.283185307179586476925286766559;
+            for (int i = 0; i < CV_N; ++i) {
+                tw[i].x = (float)std::cos(two_pi * i / CV_N);
+                tw[i].y = (float)(-std::sin(two_pi * i / CV_N));
+            }
+            HIPCHK(ctx, hipMalloc((void**)&ctx->d_tw_conv, CV_N * sizeof(c32)));
+            HIPCHK(ctx, hipMemcpy(ctx->d_tw_conv, tw.data(), CV_N * sizeof(c32), hipMemcpyHostToDevice));
+        }
+    }
+    const size_t x_bytes = (size_t)n_sig * nb * CV_F * sizeof(c32);
+    const size_t h_bytes = (size_t)n_sig * n_ch * P * CV_F * sizeof(c32);
+    const size_t need = align_up(x_bytes) + h_bytes;
+    if (ctx->conv_ws_bytes < need) {
+        if (ctx->conv_ws) HIPCHK(ctx, hipFree(ctx->conv_ws));
+        ctx->conv_ws = nullptr;
+        ctx->conv_ws_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->conv_ws, need));
+        ctx->conv_ws_bytes = need;
+    }
+    c32* X = (c32*)ctx->conv_ws;
+    c32* H = (c32*)((char*)ctx->conv_ws + align_up(x_bytes));
+    const long long nx = (long long)n_sig * nb, nh = (long long)n_sig * n_ch * P;
+    auto grid_of = [](long long items) { return dim3((unsigned)std::min<long long>((items + CV_WAVES - 1) / CV_WAVES, 1 << 20)); };
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_spectra<true>), grid_of(nx), dim3(64 * CV_WAVES), 0, st, dry, (long long)dry_len, nb, nx, X,
+                       ctx->d_tw_conv);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_spectra<false>), grid_of(nh), dim3(64 * CV_WAVES), 0, st, rir, (long long)rir_len, P, nh, H,
+                       ctx->d_tw_conv);
+    const dim3 grid((unsigned)(n_sig * n_ch));
+    if (P <= 8)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mac_ifft<8>), grid, dim3(64 * CV_WAVES), 0, st, X, H, out, ctx->d_tw_conv, n_ch, nb, P, out_len);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mac_ifft<16>), grid, dim3(64 * CV_WAVES), 0, st, X, H, out, ctx->d_tw_conv, n_ch, nb, P, out_len);
+    return check_launch(ctx, "k_conv_mac_ifft");
 }

@@ -139,6 +139,19 @@ class Engine:
         self._chk(self.lib.disco_mask_ivad(self.ctx, ps, n_sig, m.ptr, self.stream))
         return m
 
+    # ---- the step before the path (gen_disco/convolve_signals.py:160-163)
+    def rir_convolve(self, dry, rir, out_len=None):
+        """dry (n_sig, Ld), rir (n_sig, n_ch, Lh) float32 -> (n_sig, n_ch, out_len) = np.convolve(dry_i, rir_ic)[:out_len]."""
+        n_sig, Ld = dry.shape
+        n_sig2, n_ch, Lh = rir.shape
+        assert n_sig == n_sig2
+        out_len = Ld if out_len is None else out_len
+        pd, kd = self.to_device(dry, np.float32)
+        pr, kr = self.to_device(rir, np.float32)
+        out = self.empty((n_sig, n_ch, out_len), np.float32)
+        self._chk(self.lib.disco_rir_convolve(self.ctx, pd, pr, n_sig, n_ch, Ld, Lh, out.ptr, out_len, self.stream))
+        return out
+
     # ---- evaluation metrics (SURVEY 8f-3; disco_theque/metrics.py)
     def pair_stats(self, a, b, start=0, stop=None):
         """a, b (n_sig, L) float32 -> (n_sig, 8) float64 moments of a[:, start:stop], b[:, start:stop]

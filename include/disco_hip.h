@@ -251,6 +251,14 @@ int disco_pair_stats(disco_ctx* ctx, const float* a, const float* b, int64_t n_s
 int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, int64_t len, int start, int stop,
                      const double* b, const double* a, int n_bands, double* stats, disco_stream s);
 
+/* ---- the step before the path: reverberation of dry signals ------------------------------------
+ * out[i][c][0:out_len] = np.convolve(dry[i], rir[i][c])[:out_len]  (zero beyond dry_len + rir_len - 1), the operation of
+ * dataset_generation/gen_disco/convolve_signals.py:160-163 (and of pyroomacoustics' room.simulate, :94-97), batched:
+ * dry [n_sig][dry_len], rir [n_sig][n_ch][rir_len] -> out [n_sig][n_ch][out_len].  rir_len <= 8192.
+ * Partitioned overlap-save with 1024-point wave FFTs; the spectra workspace lives in the context. */
+int disco_rir_convolve(disco_ctx* ctx, const float* dry, const float* rir, int64_t n_sig, int n_ch,
+                       int dry_len, int rir_len, float* out, int out_len, disco_stream s);
+
 #ifdef __cplusplus
 }
 #endif

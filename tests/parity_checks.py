@@ -379,6 +379,30 @@ def check_ivad(make_engine, golden_dir):
     return errs
 
 
+def check_rir_convolve(make_engine, n_sig=2, n_ch=3, Ld=3000, Lh=700, out_len=None, seed=3, tol=2e-6):
+    """disco_rir_convolve == np.convolve(dry, rir)[:out_len] (the reference's own line, gen_disco/convolve_signals.py:160-163),
+    float64 on the host side of the comparison."""
+    rng = np.random.default_rng(seed)
+    dry = rng.standard_normal((n_sig, Ld)).astype(np.float32)
+    dry[:, :Ld // 7] = 0.0                                              # leading silence, as the dataset's targets have
+    t = np.arange(Lh)
+    rir = (rng.standard_normal((n_sig, n_ch, Lh)) * np.exp(-6.9 * t / Lh)).astype(np.float32)
+    rir[:, :, 5] += 1.0
+    out_len = Ld if out_len is None else out_len
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    got = eng.rir_convolve(dry, rir, out_len).numpy()
+    err = 0.0
+    for i in range(n_sig):
+        for c in range(n_ch):
+            full = np.convolve(dry[i].astype(np.float64), rir[i, c].astype(np.float64))
+            want = np.zeros(out_len)
+            m = min(out_len, len(full))
+            want[:m] = full[:m]
+            err = max(err, float(np.max(np.abs(got[i, c] - want)) / np.max(np.abs(want))))
+    assert err < tol, err
+    return err
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

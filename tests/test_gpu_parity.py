@@ -73,6 +73,12 @@ def test_metrics(make_engine, golden_dir, start):
     pc.check_metrics(make_engine, golden_dir, start=start)
 
 
+@pytest.mark.parametrize('n_sig,n_ch,Ld,Lh,out_len', [(3, 4, 20000, 4096, None), (2, 16, 160000, 4096, None), (2, 2, 5000, 8192, 14000),
+                                                      (1, 1, 700, 100, 513), (5, 3, 9000, 5000, 9000)])
+def test_rir_convolve(make_engine, n_sig, n_ch, Ld, Lh, out_len):
+    pc.check_rir_convolve(make_engine, n_sig=n_sig, n_ch=n_ch, Ld=Ld, Lh=Lh, out_len=out_len)
+
+
 def test_ivad(make_engine, golden_dir):
     pc.check_ivad(make_engine, golden_dir)
 

@@ -71,6 +71,11 @@ def test_emu_ivad(make_engine, golden_dir):
     print(pc.check_ivad(make_engine, golden_dir))
 
 
+@pytest.mark.parametrize('Ld,Lh,out_len', [(1500, 300, None), (1100, 1030, 2600)])
+def test_emu_rir_convolve(make_engine, Ld, Lh, out_len):
+    print(pc.check_rir_convolve(make_engine, n_sig=2, n_ch=2, Ld=Ld, Lh=Lh, out_len=out_len))
+
+
 def test_emu_node_sharded(make_engine):
     print(pc.check_node_sharded(make_engine, R=1, K=2, M=2, L=4096, world=2))
 
