@@ -8,6 +8,7 @@ clipping / importance-weight arithmetic of the reference is applied to those.
     snr, delta_snr, sd        metrics.py:9-61       variance of the NON-ZERO samples, as the reference
     fw_snr, fw_sd             metrics.py:63-128, 211-279   (third-octave Butterworth bank, clip, band-importance weights)
     si_sdr                    metrics.py:342-391
+    si_bss                    metrics.py:282-340      (SI-SDR / SI-SIR / SI-SAR against n_src references)
     third_octave_filterbank   sigproc_utils.py:90-116
 
 `start` / `stop` select the scored span; the reference scores [fs : min_len] (tango.py:541-593), i.e. start = 16000.
@@ -80,6 +81,32 @@ def si_sdr(reference, estimation, start=0, stop=None):
     e_ref, e_est, dot = st[:, 2], st[:, 5], st[:, 6]
     proj = dot * dot / e_ref                                       # |alpha ref|^2
     return (10 * np.log10(proj / (e_est - proj))).reshape(lead)
+
+
+def si_bss(estimated_signal, targets, j, scaling=True, start=0, stop=None):
+    """metrics.py:282-340, batched: estimated_signal (..., L), targets (n_src, ..., L) -> (sisdr, sisir, sisar), each (...).
+    Everything the reference computes is a function of the Gram matrix of (estimate, targets); its entries are the cross
+    moments `disco_pair_stats` returns, so no residual signal is ever formed."""
+    e2, lead = _flat(estimated_signal)
+    tg = [_flat(t)[0] for t in targets]
+    n_src = len(tg)
+    eng = _engine()
+    dot = lambda a, b: eng.pair_stats(a, b, start, stop).numpy()[:, 6]
+    Rss = np.empty((e2.shape[0], n_src, n_src))
+    for p in range(n_src):
+        for q in range(p, n_src):
+            Rss[:, p, q] = Rss[:, q, p] = dot(tg[p], tg[q])
+    r_e = np.stack([dot(tg[p], e2) for p in range(n_src)], axis=1)            # targets^T estimate
+    ee = eng.pair_stats(e2, e2, start, stop).numpy()[:, 2]
+    a = r_e[:, j] / Rss[:, j, j] if scaling else np.ones(e2.shape[0])
+    Sss = a * a * Rss[:, j, j]
+    Snn = ee - 2 * a * r_e[:, j] + Sss                                        # |est - a s_j|^2
+    Rsr = r_e - a[:, None] * Rss[:, :, j]                                     # targets^T e_res
+    b = np.linalg.solve(Rss, Rsr[..., None])[..., 0]
+    interf = np.einsum('np,np->n', b, Rsr)                                    # |targets b|^2 = b^T Rss b = b^T Rsr
+    artif = Snn - interf                                                      # |e_res - e_interf|^2
+    f = lambda x: (10 * np.log10(x)).reshape(lead)
+    return f(Sss / Snn), f(Sss / interf), f(Sss / artif)
 
 
 def band_importance(fs):

@@ -7,6 +7,7 @@ Evaluation metrics that directly follow the hot path, restated 
     disco_theque/metrics.py:63-128   fw_snr     third-octave IIR bank -> per-band SNR -> clip [-15, 25] dB -> importance weights
     disco_theque/metrics.py:211-279  fw_sd      same bank on (s_out, s_in), clip [0, 25] dB
     disco_theque/metrics.py:342-391  si_sdr
+    disco_theque/metrics.py:282-340  si_bss     (SI-SDR / SI-SIR / SI-SAR of one estimate against n_src references)
     disco_theque/sigproc_utils.py:90-116  third_octave_filterbank (scipy.signal.butter band-pass per band, 'ba' form)
 Pinned by tests/golden/metrics_ref.npz = the reference's own metrics.py executed by tests/golden/make_golden_metrics.py.
 
@@ -110,3 +111,23 @@ def si_sdr(reference, estimation):
     proj = alpha * reference
     noise = estimation - proj
     return 10 * np.log10(np.sum(proj ** 2, axis=-1) / np.sum(noise ** 2, axis=-1))
+
+
+def si_bss(estimated_signal, targets, j, scaling=True):
+    """metrics.py:282-340: estimated_signal (n_samples,), targets (n_samples, n_src) -> (sisdr, sisir, sisar)."""
+    import math
+    Rss = np.dot(targets.transpose(), targets)
+    this_s = targets[:, j]
+    a = np.dot(this_s, estimated_signal) / Rss[j, j] if scaling else 1
+    e_true = a * this_s
+    e_res = estimated_signal - e_true
+    Sss = (e_true ** 2).sum()
+    Snn = (e_res ** 2).sum()
+    sisdr = 10 * math.log10(Sss / Snn)
+    Rsr = np.dot(targets.transpose(), e_res)
+    b = np.linalg.solve(Rss, Rsr)
+    e_interf = np.dot(targets, b)
+    e_artif = e_res - e_interf
+    sisir = 10 * math.log10(Sss / (e_interf ** 2).sum())
+    sisar = 10 * math.log10(Sss / (e_artif ** 2).sum())
+    return sisdr, sisir, sisar

@@ -38,7 +38,7 @@ def main():
     n_case, L = 4, 24000
     out = {'fs': np.array(fs)}
     S_in, N_in, S_out, N_out = [], [], [], []
-    res = {k: [] for k in ('snr_in', 'delta_snr', 'sd', 'fw_snr', 'fw_snr_mean', 'fw_sd', 'fw_sd_mean', 'si_sdr')}
+    res = {k: [] for k in ('snr_in', 'delta_snr', 'sd', 'fw_snr', 'fw_snr_mean', 'fw_sd', 'fw_sd_mean', 'si_sdr', 'si_bss')}
     for c in range(n_case):
         # coloured "speech" with a leading silence (exact zeros: the non-zero-sample rule matters) + coloured noise
         bs, as_ = [1.0, -0.6], [1.0, -1.2, 0.52]
@@ -59,6 +59,8 @@ def main():
         fq, fm, _ = ref.fw_sd(s_out, s_in, fs)
         res['fw_sd'].append(fq), res['fw_sd_mean'].append(fm)
         res['si_sdr'].append(ref.si_sdr(s_in.astype(np.float64), (s_out + n_out).astype(np.float64)))
+        res['si_bss'].append(ref.si_bss((s_out + n_out).astype(np.float64),
+                                        np.stack([s_in, n_in], 1).astype(np.float64), 0))
     out.update(s_in=np.stack(S_in), n_in=np.stack(N_in), s_out=np.stack(S_out), n_out=np.stack(N_out), F=np.asarray(F))
     out.update({k: np.asarray(v) for k, v in res.items()})
     np.savez_compressed(os.path.join(HERE, 'metrics_ref.npz'), **out)

@@ -333,6 +333,7 @@ def check_metrics(make_engine, golden_dir, L_cut=None, start=0):
                'sd': gm.sd(s_out, s_in, start=start), 'si_sdr': gm.si_sdr(s_in, s_out + n_out, start=start)}
         got['fw_snr'], got['fw_snr_mean'], F = gm.fw_snr(s_out, n_out, fs, start=start)
         got['fw_sd'], got['fw_sd_mean'], _ = gm.fw_sd(s_out, s_in, fs, start=start)
+        got['si_bss'] = np.stack(gm.si_bss(s_out + n_out, [s_in, n_in], 0, start=start), axis=-1)
     finally:
         gm._engine = saved
     errs = {}
@@ -340,7 +341,9 @@ def check_metrics(make_engine, golden_dir, L_cut=None, start=0):
         a, b, x, y = s_in[c, start:], n_in[c, start:], s_out[c, start:], n_out[c, start:]
         want = {'snr_in': mo.snr(a, b), 'delta_snr': mo.delta_snr(x, y, a, b), 'sd': mo.sd(x, a),
                 'si_sdr': mo.si_sdr(a, (s_out + n_out)[c, start:]), 'fw_snr': mo.fw_snr(x, y, fs)[0],
-                'fw_snr_mean': mo.fw_snr(x, y, fs)[1], 'fw_sd': mo.fw_sd(x, a, fs)[0], 'fw_sd_mean': mo.fw_sd(x, a, fs)[1]}
+                'fw_snr_mean': mo.fw_snr(x, y, fs)[1], 'fw_sd': mo.fw_sd(x, a, fs)[0], 'fw_sd_mean': mo.fw_sd(x, a, fs)[1],
+                'si_bss': np.array(mo.si_bss((s_out + n_out)[c, start:].astype(np.float64),
+                                             np.stack([a, b], 1).astype(np.float64), 0))}
         for k, v in want.items():
             assert np.all(np.isfinite(v)) and np.all(np.isfinite(np.asarray(got[k])[c])), (k, v, np.asarray(got[k])[c])
             errs[k] = max(errs.get(k, 0.0), float(np.max(np.abs(np.asarray(got[k])[c] - v))))
