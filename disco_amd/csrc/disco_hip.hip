@@ -494,11 +494,15 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     DISCO_FOR_MKR(X_)
 #undef X_
     if (!launched) {
+        const int tiles = (ctx->F + 63) / 64;
+        int t_chunks = (int)std::min<long long>(std::max<long long>(1, (8192 + G * tiles - 1) / (G * tiles)), std::max(1, ctx->T / 8));
+        while (G * tiles * t_chunks > 0x7fffffffLL && t_chunks > 1) t_chunks >>= 1;
+        const dim3 grid_m((unsigned)(G * tiles * t_chunks));
         switch (M) {
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_m<M_>), grid, block, 0, (hipStream_t)s, (const c32*)X, (const c32*)Z, \
-                           (const c32*)w, (c32*)out, KR, c.nodes, ctx->T, ctx->F, conj_w, bpn, ctx->Kl, ctx->k0);        \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_m<M_>), grid_m, dim3(64), 0, (hipStream_t)s, (const c32*)X, (const c32*)Z, \
+                           (const c32*)w, (c32*)out, KR, c.nodes, ctx->T, ctx->F, conj_w, tiles, t_chunks, ctx->Kl, ctx->k0); \
         break;
             C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8)
 #undef C_

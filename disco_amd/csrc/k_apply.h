@@ -42,25 +42,37 @@ __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const 
     }
 }
 
-// Shapes outside the (M, KR) template table (P > 8): M stays a template parameter so that the node's own M-vector is ONE
-// unrolled, vectorised load; the remote count KR is a run-time value walked by a fully unrolled, wave-uniformly
-// predicated loop (at most 15 remote rows, P <= 16).
+// Shapes outside the (M, KR) template table (P > 8).  With P up to 16 the filter of a bin is as large as the data it
+// multiplies, so re-reading it per (t, f) element (the flat mapping above) doubles the L1/L2 traffic: here a lane owns one
+// BIN for a run of frames and keeps the bin's filter in registers.  M is a template parameter (the node's own M-vector is
+// one unrolled, vectorised load); the remote count KR is a run-time value walked by a fully unrolled, wave-uniformly
+// predicated loop (at most 15 remote rows).  One wave per workgroup: 64 consecutive bins x frames [t0, t1).
 template <int M>
-__global__ __launch_bounds__(256) void k_apply_m(const c32* __restrict__ X, const c32* __restrict__ Z,
-                                                  const c32* __restrict__ w, c32* __restrict__ out, int KR,
-                                                  int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0) {
+__global__ __launch_bounds__(64) void k_apply_m(const c32* __restrict__ X, const c32* __restrict__ Z,
+                                                 const c32* __restrict__ w, c32* __restrict__ out, int KR,
+                                                 int K, int T, int F, int conj_w, int tiles, int t_chunks, int Kl, int k0) {
     const int P = M + KR;
-    const long long g = blockIdx.x / blocks_per_node;
-    const int b = (int)(blockIdx.x % blocks_per_node);
+    const int per_node = tiles * t_chunks;
+    const long long g = blockIdx.x / per_node;
+    const int rem = (int)(blockIdx.x % per_node);
+    const int tile = rem / t_chunks, tc = rem % t_chunks;
+    const int f = tile * 64 + (int)threadIdx.x;
+    if (f >= F) return;
+    const int t_len = (T + t_chunks - 1) / t_chunks;
+    const int t0 = tc * t_len, t1 = min(T, t0 + t_len);
     const long long r = g / Kl;
     const int k = k0 + (int)(g % Kl);
     const long long TF = (long long)T * F;
     const float sgn = conj_w ? -1.f : 1.f;
-    const c32* wg = w + g * F * (long long)P;
+    const c32* wf = w + (g * F + f) * (long long)P;
+    c32 wl[M], wr[15];
+#pragma unroll
+    for (int i = 0; i < M; ++i) wl[i] = make_float2(wf[i].x, sgn * wf[i].y);
+#pragma unroll
+    for (int jj = 0; jj < 15; ++jj) wr[jj] = jj < KR ? make_float2(wf[M + jj].x, sgn * wf[M + jj].y) : make_float2(0.f, 0.f);
     const c32* Zr = Z ? Z + (r * K) * TF : nullptr;
-    for (long long tf = (long long)b * blockDim.x + threadIdx.x; tf < TF; tf += (long long)blocks_per_node * blockDim.x) {
-        const int f = (int)(tf % F);
-        const c32* wf = wg + (long long)f * P;
+    for (int t = t0; t < t1; ++t) {
+        const long long tf = (long long)t * F + f;
         const c32* xp = X + (g * TF + tf) * M;
         c32 x[M];
 #pragma unroll
@@ -68,18 +80,16 @@ __global__ __launch_bounds__(256) void k_apply_m(const c32* __restrict__ X, cons
         float ar = 0.f, ai = 0.f;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            const c32 ww = make_float2(wf[i].x, sgn * wf[i].y);
-            ar = fmaf(ww.x, x[i].x, fmaf(-ww.y, x[i].y, ar));
-            ai = fmaf(ww.x, x[i].y, fmaf(ww.y, x[i].x, ai));
+            ar = fmaf(wl[i].x, x[i].x, fmaf(-wl[i].y, x[i].y, ar));
+            ai = fmaf(wl[i].x, x[i].y, fmaf(wl[i].y, x[i].x, ai));
         }
 #pragma unroll
         for (int jj = 0; jj < 15; ++jj) {
             if (jj < KR) {
                 const int j = jj < k ? jj : jj + 1;
                 const c32 z = Zr[j * TF + tf];
-                const c32 ww = make_float2(wf[M + jj].x, sgn * wf[M + jj].y);
-                ar = fmaf(ww.x, z.x, fmaf(-ww.y, z.y, ar));
-                ai = fmaf(ww.x, z.y, fmaf(ww.y, z.x, ai));
+                ar = fmaf(wr[jj].x, z.x, fmaf(-wr[jj].y, z.y, ar));
+                ai = fmaf(wr[jj].x, z.y, fmaf(wr[jj].y, z.x, ai));
             }
         }
         out[g * TF + tf] = make_float2(ar, ai);
