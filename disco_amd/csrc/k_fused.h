@@ -238,6 +238,10 @@ namespace disco {
 
 // frame pairs per workgroup are a launch parameter (`pairs`): 2*pairs - 1 hop segments per workgroup
 
+#ifndef DISCO_AI_PREFETCH
+#define DISCO_AI_PREFETCH 1
+#endif
+
 template <int N, int M, int K>
 struct alignas(16) ApplyIstftShared {
     c32 buf[K][fft_buf_len<N>()];
@@ -245,8 +249,9 @@ struct alignas(16) ApplyIstftShared {
     c32 wl[K][N / 2 + 1][M];
 };
 
+// 2 waves per SIMD is what the 68 kB of LDS allow; stated so that the allocator keeps the prefetch within 256 registers
 template <int N, int M, int K>
-__global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float* __restrict__ out,
+__global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_apply_istft(Step2Args a, float* __restrict__ out,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
                                                                int L, int blocks_per_room, int pairs) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2, EH = E / 2, NJ = EH + 1, P = M + K - 1;
@@ -278,6 +283,25 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float
 #pragma unroll
     for (int e = 0; e < EH; ++e) carry[e] = 0.f;
     float* og = out + g * (long long)L;
+    constexpr bool PF = DISCO_AI_PREFETCH && M <= 4 && K <= 4;     // larger shapes have no registers to spare for it
+    // The kernel runs 2 waves per SIMD (LDS- and register-bound) and measured 32 % VALU-busy: latency-bound.  The frame
+    // pair's spectra are therefore fetched one pair AHEAD, raw and unconditionally (frame index clamped), into registers
+    // that are dead during the inverse FFT, and pinned (DISCO_CONSUME) before the pair's output stores are issued.
+    c32 xr[PF ? 2 : 1][PF ? NJ : 1][M];
+    auto fetch_pair = [&](int tA_) {
+        if constexpr (!PF) return;
+#pragma unroll
+        for (int fr = 0; fr < (PF ? 2 : 0); ++fr) {
+            const long long tf0 = (long long)min(tA_ + fr, T - 1) * F;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = (j < EH) ? lane + 64 * j : F - 1;
+#pragma unroll
+                for (int i = 0; i < M; ++i) xr[fr][j][i] = Xg[(tf0 + f) * M + i];
+            }
+        }
+    };
+    fetch_pair(s0);
     __syncthreads();
     for (int pr = 0; pr < pairs; ++pr) {
         const int tA = s0 + 2 * pr;
@@ -288,13 +312,16 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float
             const int t = tA + fr;
             const bool tv = t < T;
             const long long tf0 = (long long)(tv ? t : T - 1) * F;
+            (void)tf0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int f = (j < EH) ? lane + 64 * j : F - 1;
                 c32 x[M];
 #pragma unroll
                 for (int i = 0; i < M; ++i) {
-                    const c32 v = Xg[(tf0 + f) * M + i];
+                    c32 v;
+                    if constexpr (PF) v = xr[PF ? fr : 0][PF ? j : 0][i];
+                    else v = Xg[(tf0 + f) * M + i];
                     x[i] = tv ? v : make_float2(0.f, 0.f);
                 }
                 c32 wl[M];
@@ -344,6 +371,7 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float
         c32 v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = buf[fft_pad<N>(lane + 64 * e)];
+        fetch_pair(tA + 2);                               // next pair, in flight during the FFT (harmless clamp at the end)
         fft_wave<N>(v, wtw, buf, lane);
         // time frames: gA[n] = win[n] Re(conj(out))/N = win[n] v.x / N ; gB[n] = -win[n] v.y / N ;  n = lane + 64 e
         const float inv = 1.0f / N;
@@ -352,6 +380,17 @@ __global__ __launch_bounds__(64 * K) void k_step2_apply_istft(Step2Args a, float
         for (int e = 0; e < E; ++e) {
             gA[e] = v[e].x * (w[e] * inv);
             gB[e] = -v[e].y * (w[e] * inv);
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int fr = 0; fr < 2; ++fr)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        DISCO_CONSUME(xr[PF ? fr : 0][PF ? j : 0][i].x);
+                        DISCO_CONSUME(xr[PF ? fr : 0][PF ? j : 0][i].y);
+                    }
         }
         // ---- overlap-add: segment (tA-1) = carry + gA[lo], segment tA = gA[hi] + gB[lo], carry <- gB[hi]
 #pragma unroll
