@@ -88,6 +88,8 @@ def main():
     ap.add_argument('--online-every', type=int, default=0,
                     help='> 0: time the ONLINE pipeline (SURVEY 8f-2) with a filter update every this many frames instead of '
                          'the batch path (not the headline metric; stage timing / roofline are skipped)')
+    ap.add_argument('--iters', type=int, default=1,
+                    help='> 1: the DANSE-style iterated scheme (BASELINE configs[4]; disco_tango_enhance_iterated, staged kernels)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--pmc-calibrate', action='store_true', help='also run a 4 GiB device copy (known bytes) for PMC calibration')
@@ -140,6 +142,10 @@ def main():
             eng._chk(lib.disco_tango_online(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), 0.95, args.online_every,
                                             1e-3, out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
             return
+        if args.iters > 1:
+            eng._chk(lib.disco_tango_enhance_iterated(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), args.iters,
+                                                      out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
+            return
         eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
                                          None, None, ws.data_ptr(), ws.numel(), None))
 
@@ -169,7 +175,7 @@ def main():
 
     # ---- per-stage timing with HIP events on the launch stream (rank 0, N=1), for the roofline object
     roofline, stages = None, None
-    if rank == 0 and not args.no_stage_timing and args.mask == 'oracle' and args.online_every == 0:
+    if rank == 0 and not args.no_stage_timing and args.mask == 'oracle' and args.online_every == 0 and args.iters == 1:
         X = torch.empty((R, K, T, F, M), dtype=torch.complex64, device=dev)
         z = torch.empty((R, K, T, F), dtype=torch.complex64, device=dev)
         yf = torch.empty_like(z)
@@ -255,7 +261,8 @@ def main():
             'x_realtime': x_rt,
             'config': {'workload': f'{cfg_name}: {R} rooms/GPU x {K} nodes x {M} mics, 16 kHz, L={Ls}, '
                                    f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced'
-                                   + (f', ONLINE mode lambda=0.95 update_every={args.online_every}' if args.online_every else ''),
+                                   + (f', ONLINE mode lambda=0.95 update_every={args.online_every}' if args.online_every else '')
+                                   + (f', {args.iters} step-2 iterations (DANSE-style)' if args.iters > 1 else ''),
                        'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
                        'parallelism': f'rooms sharded over {world} GPU(s), no data-path collective'},
             'roofline': roofline, 'cpu_baseline': cpu, 'stages': stages,

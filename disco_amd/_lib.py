@@ -59,6 +59,7 @@ PROTOTYPES = {
     'disco_rir_convolve': (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _int, _vp]),
     'disco_pair_stats': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp]),
     'disco_band_stats': (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
+    'disco_tango_enhance_iterated': (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     'disco_online_mwf': (_int, [_vp, _vp, _vp, _vp, _int, _f, _f, _int, _f, _vp, _vp, _vp]),
     'disco_tango_online': (_int, [_vp, _vp, _vp, _vp, _f, _int, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -1070,3 +1070,44 @@ extern "C" int disco_rir_convolve(disco_ctx* ctx, const float* dry, const float*
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mac_ifft<16>), grid, dim3(64 * CV_WAVES), 0, st, X, H, out, ctx->d_tw_conv, n_ch, nb, P, out_len);
     return check_launch(ctx, "k_conv_mac_ifft");
 }
+
+// ---- iterated (DANSE-style) continuation -------------------------------------------------------------------------------
+
+extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, int iters,
+                                            float* out, disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes,
+                                            disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!y || !mask_z || !mask_w || !out || iters < 1) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance_iterated: bad argument");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance_iterated: node shard active");
+    const disco_cfg& c = ctx->cfg;
+    const WsLayout l = ws_layout(ctx);
+    char* ws = nullptr;
+    int rc = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance_iterated");
+    if (rc) return rc;
+    disco_c32* X = (disco_c32*)(ws + l.X);
+    disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
+    disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
+    disco_c32* w_loc = (disco_c32*)(ws + l.w);
+    disco_c32* w_glo = (disco_c32*)(ws + l.w2);
+    const int64_t G = (int64_t)c.rooms * c.nodes;
+    const int M = c.mics, P2 = c.mics + c.nodes - 1;
+    int chunks = 1;
+    if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
+    if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s))) return rc;
+    if ((rc = disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s))) return rc;
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = disco_cov_masked(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, nullptr, nullptr, s))) return rc;
+        if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s))) return rc;
+        if (it + 1 < iters) {
+            const long long nb = (long long)G * ctx->F;
+            hipLaunchKernelGGL(k_filter_head, dim3((unsigned)std::min<long long>((nb * M + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)s,
+                               (const c32*)w_glo, (c32*)w_loc, nb, M, P2);
+            if ((rc = check_launch(ctx, "k_filter_head"))) return rc;
+            // yf of this iteration is not needed; the next one needs the re-compressed z (computed from the OLD z's filter
+            // only through w_glo's local part, so z can be overwritten in place)
+            if ((rc = disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s))) return rc;
+        }
+    }
+    if ((rc = disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s))) return rc;
+    return disco_istft(ctx, yo, G, out, s);
+}

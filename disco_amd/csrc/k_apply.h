@@ -96,6 +96,14 @@ __global__ __launch_bounds__(64) void k_apply_m(const c32* __restrict__ X, const
     }
 }
 
+// w_loc[g][f][0:M] <- w_glo[g][f][0:M]  (the local part of a P-entry filter; iterated scheme)
+__global__ void k_filter_head(const c32* __restrict__ w_glo, c32* __restrict__ w_loc, long long n_bins, int M, int P) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_bins * M; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / M;
+        w_loc[i] = w_glo[b * P + (int)(i % M)];
+    }
+}
+
 // zn = Y[ref] - z  (tango.py:376)
 __global__ void k_noise_residual(const c32* __restrict__ X, const c32* __restrict__ z, c32* __restrict__ zn,
                                  long long n, int M, int ref) {

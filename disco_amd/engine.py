@@ -354,24 +354,17 @@ class Engine:
     def tango_enhance_iterated(self, y, mask_z, mask_w=None, iters=2):
         """DANSE-style continuation of the two-step scheme (BASELINE.json configs[4]; not in the reference): step 2 is
         run `iters` times, each time with z_k <- w_glo,k[:M]^H y_k.  iters=1 is exactly offline_tango's y branch.
-        Staged kernels (z materialised).  Returns (out (R,K,L), yf (R,K,T,F))."""
-        mask_w = mask_z if mask_w is None else mask_w
-        R, K, M = self.R, self.K, self.M
-        X = self.stft(y.reshape(R * K, M, self.Lsamp) if hasattr(y, 'reshape') else y).reshape(R, K, self.T, self.F, M)
-        self.cov_masked(X, mask_z, Rss_out=False)
-        w, _ = self.gevd_mwf_r1_pending(M)
-        z = self.apply(X, w)
-        yf = z
-        for it in range(iters):
-            if K > 1:
-                self.cov_masked(X, mask_w, z, z, mask_remote=True, Rss_out=False)
-            else:
-                self.cov_masked(X, mask_w, Rss_out=False)
-            w_glo, _ = self.gevd_mwf_r1_pending(M + K - 1)
-            yf = self.apply(X, w_glo, Z=z if K > 1 else None)
-            if it + 1 < iters:
-                z = self.apply(X, np.ascontiguousarray(w_glo.numpy()[..., :M]))
-        return self.istft(yf.reshape(R * K, self.T, self.F)).reshape(R, K, self.Lsamp), yf
+        Staged kernels (z materialised), one C call (disco_tango_enhance_iterated).  Returns (out (R,K,L), yf (R,K,T,F))."""
+        py, ky = self.to_device(y, np.float32)
+        pmz, kmz = self.to_device(mask_z, np.float32)
+        if mask_w is None or mask_w is mask_z:
+            pmw, kmw = pmz, kmz
+        else:
+            pmw, kmw = self.to_device(mask_w, np.float32)
+        out = self.empty((self.R, self.K, self.Lsamp), np.float32)
+        yf = self.empty((self.R, self.K, self.T, self.F), np.complex64)
+        self._chk(self.lib.disco_tango_enhance_iterated(self.ctx, py, pmz, pmw, iters, out.ptr, None, yf.ptr, None, 0, self.stream))
+        return out, yf
 
     # ---- whole path
     def workspace_bytes(self):

@@ -207,6 +207,14 @@ int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, con
                         float* out, disco_c32* z_y, disco_c32* yf,
                         void* workspace, size_t workspace_bytes, disco_stream s);
 
+/* DANSE-style continuation of the two-step scheme (BASELINE.json configs[4]; NOT in the reference, which is strictly
+ * two-step, tango.py:1-7): step 2 is run `iters` times, and between two runs every node re-compresses with the local part
+ * of its new global filter, z_k <- w_glo,k[0:M]^H y_k.  iters = 1 gives exactly disco_tango_enhance's outputs.  Staged
+ * kernels (z materialised), any P = M + K - 1 <= 16.  Arguments as disco_tango_enhance; z_y returns the LAST z. */
+int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, int iters,
+                                 float* out, disco_c32* z_y, disco_c32* yf,
+                                 void* workspace, size_t workspace_bytes, disco_stream s);
+
 /* 'ivad' mask -- get_mask(..., mask_type='ivad', ts=s[node][0]) (tango.py:217-221): vad_oracle_batch (sigproc_utils.py:12-55:
  * window power test against 0.001 * the 0.99-quantile of the centred signal's instantaneous power, win = n_fft, hop) sampled
  * every hop and tiled over frequency; frames beyond ceil(L / hop) are 0.
