@@ -406,6 +406,23 @@ def check_rir_convolve(make_engine, n_sig=2, n_ch=3, Ld=3000, Lh=700, out_len=No
     return err
 
 
+def check_iterated(make_engine, K=2, M=2, L=2304, iters=2, tol=1e-4):
+    """disco_tango_enhance_iterated (DANSE-style extra step-2 iterations, BASELINE configs[4]) against the oracle's
+    restatement of the same definition; iters = 1 must reproduce the plain two-step path."""
+    from disco_amd import synth
+    from oracle import tango_oracle as to
+    y, s, n = synth.make_rooms_numpy(1, K=K, M=M, L=L)
+    eng = make_engine(rooms=1, nodes=K, mics=M, length=L)
+    m = eng.mask_oracle(s[0, :, 0], n[0, :, 0]).reshape(1, K, eng.T, eng.F).numpy()
+    errs = {}
+    for it in (1, iters):
+        out, yf = eng.tango_enhance_iterated(y, m, iters=it)
+        o = to.offline_tango_vec(y[0], s[0], n[0], vads=['irm1', 'irm1'], precision='f64', solver='eigh', extra_iters=it - 1)
+        errs[it] = max(relerr(yf.numpy()[0, k].T, o['yf'][k]) for k in range(K))
+        assert errs[it] < tol, errs
+    return errs
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

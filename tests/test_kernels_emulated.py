@@ -76,6 +76,10 @@ def test_emu_rir_convolve(make_engine, Ld, Lh, out_len):
     print(pc.check_rir_convolve(make_engine, n_sig=2, n_ch=2, Ld=Ld, Lh=Lh, out_len=out_len))
 
 
+def test_emu_iterated(make_engine):
+    print(pc.check_iterated(make_engine, K=2, M=1, L=1792, iters=2))
+
+
 def test_emu_node_sharded(make_engine):
     print(pc.check_node_sharded(make_engine, R=1, K=2, M=2, L=4096, world=2))
 
