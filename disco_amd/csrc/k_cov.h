@@ -156,30 +156,53 @@ __device__ __forceinline__ void cov_big_walk(const CovArgs& a, int M, int KR, lo
     const int k = a.k0 + (int)(g % a.Kl);
     const c32* Xg = a.X + (g * T * (long long)F) * M;
     const float* mg = a.mask + g * T * (long long)F;
+    // The kernel runs 2 waves per SIMD (2 x 34 complex accumulators per lane): the next frame's rows are requested one
+    // iteration ahead, raw and unconditionally (clamped frame index), so that a wave always has a frame in flight.
+    // (SAMEZ only: the second set of remote rows would not fit the register budget.)
+    c32 xr[CB_PMAX], xq[CB_PMAX];
+    float mr = 0.f;
+    auto fetch = [&](int tu_, c32* xs_, c32* xn_, float& m_) {
+        const int t_ = min(tu_ + t_off, t1 - 1);
+        const long long tf_ = (long long)(t_ < t0 ? t0 : t_) * F + f;
+        m_ = mg[tf_];
+#pragma unroll
+        for (int i = 0; i < CB_PMAX; ++i) {
+            if (i < M) {
+                xs_[i] = Xg[tf_ * M + i];
+                if (!SAMEZ) xn_[i] = xs_[i];
+            } else if (i < P) {
+                const int jj = i - M;
+                const int j = jj < k ? jj : jj + 1;
+                const long long zo = ((r * K + j) * T) * (long long)F + tf_;
+                xs_[i] = a.Zs[zo];
+                if (!SAMEZ) xn_[i] = a.Zn[zo];
+            } else {
+                xs_[i] = make_float2(0.f, 0.f);
+                if (!SAMEZ) xn_[i] = make_float2(0.f, 0.f);
+            }
+        }
+    };
+    if (SAMEZ) fetch(t0, xr, xq, mr);
     for (int tu = t0; tu < t1; tu += t_step) {
         const int t = tu + t_off;
         const bool ok = live && t < t1;
-        const long long tf = (long long)(ok ? t : t0) * F + f;
-        const float m = ok ? mg[tf] : 0.f, mc = ok ? 1.f - m : 0.f;
+        c32 xc[CB_PMAX], xd[CB_PMAX];
+        float mraw;
+        if (SAMEZ) {
+#pragma unroll
+            for (int i = 0; i < CB_PMAX; ++i) xc[i] = xr[i];
+            mraw = mr;
+            fetch(tu + t_step, xr, xq, mr);                 // next frame (harmless clamp at the end of the chunk)
+        } else {
+            fetch(tu, xc, xd, mraw);
+        }
+        const float m = ok ? mraw : 0.f, mc = ok ? 1.f - mraw : 0.f;
         const float gs = a.mask_remote ? m : (ok ? 1.f : 0.f), gn = a.mask_remote ? mc : (ok ? 1.f : 0.f);
         c32 vs[CB_PMAX], vn[CB_PMAX];
 #pragma unroll
         for (int i = 0; i < CB_PMAX; ++i) {
-            c32 xs = make_float2(0.f, 0.f), xn = make_float2(0.f, 0.f);
-            float ws = 0.f, wn = 0.f;
-            if (i < M) {
-                xs = xn = Xg[tf * M + i];
-                ws = m;
-                wn = mc;
-            } else if (i < P) {
-                const int jj = i - M;
-                const int j = jj < k ? jj : jj + 1;
-                const long long zo = ((r * K + j) * T) * (long long)F + tf;
-                xs = a.Zs[zo];
-                xn = SAMEZ ? xs : a.Zn[zo];
-                ws = gs;
-                wn = gn;
-            }
+            const c32 xs = xc[i], xn = SAMEZ ? xc[i] : xd[i];
+            const float ws = i < M ? m : (i < P ? gs : 0.f), wn = i < M ? mc : (i < P ? gn : 0.f);
             vs[i] = make_float2(ws * xs.x, ws * xs.y);
             vn[i] = make_float2(wn * xn.x, wn * xn.y);
         }
