@@ -57,6 +57,7 @@ PROTOTYPES = {
     'disco_tango_enhance': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'disco_mask_ivad': (_int, [_vp, _vp, _i64, _vp, _vp]),
     'disco_rir_convolve': (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _int, _vp]),
+    'disco_ism_rir': (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f, _f, _vp, _int, _vp]),
     'disco_pair_stats': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp]),
     'disco_band_stats': (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
     'disco_tango_enhance_iterated': (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),

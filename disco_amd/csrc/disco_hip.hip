@@ -13,6 +13,7 @@
 #include "k_conv.h"
 #include "k_cov.h"
 #include "k_fused.h"
+#include "k_ism.h"
 #include "k_solve.h"
 #include "k_metrics.h"
 #include "k_online.h"
@@ -1110,4 +1111,22 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     }
     if ((rc = disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s))) return rc;
     return disco_istft(ctx, yo, G, out, s);
+}
+
+// ---- image-source RIR generator --------------------------------------------------------------------------
+
+extern "C" int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorption, const float* src, const float* mic,
+                             int64_t n_room, int n_src, int n_mic, int max_order, float fs, float c_sound, float* rir, int rir_len,
+                             disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    if (!room_dims || !absorption || !src || !mic || !rir || n_room < 1 || n_src < 1 || n_mic < 1 || max_order < 0 || !(fs > 0.f) ||
+        !(c_sound > 0.f) || rir_len < 1)
+        return fail(ctx, DISCO_E_ARG, "disco_ism_rir: bad argument");
+    if (rir_len > ISM_MAX_LEN) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_ism_rir: responses longer than 8192 taps");
+    if (max_order > 64) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_ism_rir: max_order > 64");
+    const long long n = (long long)n_room * n_src * n_mic;
+    if (n > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_ism_rir: batch too large");
+    hipLaunchKernelGGL(k_ism_rir, dim3((unsigned)n), dim3(ISM_THREADS), 0, (hipStream_t)s, room_dims, absorption, src, mic, n_src, n_mic,
+                       max_order, fs, c_sound, rir, rir_len);
+    return check_launch(ctx, "k_ism_rir");
 }

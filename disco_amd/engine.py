@@ -152,6 +152,19 @@ class Engine:
         self._chk(self.lib.disco_rir_convolve(self.ctx, pd, pr, n_sig, n_ch, Ld, Lh, out.ptr, out_len, self.stream))
         return out
 
+    def ism_rir(self, room_dims, absorption, src, mic, max_order=20, fs=16000.0, c_sound=343.0, rir_len=4096):
+        """Shoebox image-source RIRs: room_dims (n_room, 3), absorption (n_room,), src (n_room, S, 3), mic (n_room, Q, 3)
+        -> rir (n_room, S, Q, rir_len)   [pra.ShoeBox(...).compute_rir(), convolve_signals.py:243-246, 94-95]"""
+        n_room = room_dims.shape[0]
+        S, Q = src.shape[1], mic.shape[1]
+        pd, kd = self.to_device(room_dims, np.float32)
+        pa, ka = self.to_device(absorption, np.float32)
+        ps, ks = self.to_device(src, np.float32)
+        pm, km = self.to_device(mic, np.float32)
+        out = self.empty((n_room, S, Q, rir_len), np.float32)
+        self._chk(self.lib.disco_ism_rir(self.ctx, pd, pa, ps, pm, n_room, S, Q, max_order, fs, c_sound, out.ptr, rir_len, self.stream))
+        return out
+
     # ---- evaluation metrics (SURVEY 8f-3; disco_theque/metrics.py)
     def pair_stats(self, a, b, start=0, stop=None):
         """a, b (n_sig, L) float32 -> (n_sig, 8) float64 moments of a[:, start:stop], b[:, start:stop]

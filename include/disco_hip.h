@@ -267,6 +267,17 @@ int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, int64_t len,
 int disco_rir_convolve(disco_ctx* ctx, const float* dry, const float* rir, int64_t n_sig, int n_ch,
                        int dry_len, int rir_len, float* out, int out_len, disco_stream s);
 
+/* Shoebox image-source room impulse responses -- what the reference takes from pyroomacoustics
+ * (dataset_generation/gen_disco/convolve_signals.py:243-246 pra.ShoeBox(dims, fs, max_order=20, absorption); :94-95
+ * image_source_model + compute_rir).  Third-party, absent, unpinned: restated from Allen & Berkley (1979) with that
+ * package's documented conventions (images with |nx|+|ny|+|nz| <= max_order, sqrt(1 - absorption) per reflection,
+ * 1 / (4 pi d), 81-tap Hann-windowed sinc fractional delays, response shifted by 40 samples).
+ * room_dims [n_room][3] (m), absorption [n_room], src [n_room][n_src][3], mic [n_room][n_mic][3]
+ *   -> rir [n_room][n_src][n_mic][rir_len] (truncated at rir_len <= 8192).  Feeds disco_rir_convolve directly. */
+int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorption, const float* src, const float* mic,
+                  int64_t n_room, int n_src, int n_mic, int max_order, float fs, float c_sound,
+                  float* rir, int rir_len, disco_stream s);
+
 #ifdef __cplusplus
 }
 #endif

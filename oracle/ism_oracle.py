@@ -1,0 +1,37 @@
+"""TEST INFRASTRUCTURE (CPU oracle) -- only tests/ may use it.
+
+Shoebox image-source room impulse responses, float64: the generator the reference takes from
+pyroomacoustics (dataset_generation/gen_disco/convolve_signals.py:243-246 `pra.ShoeBox(..., max_order=20, absorption=alpha)`,
+:94-95 `image_source_model` / `compute_rir`).  pyroomacoustics is third-party, absent and unpinned: PARITY UNPINNED.  The
+algorithm is Allen & Berkley (1979) with the package's documented conventions (L1-bounded image order, sqrt(1 - absorption)
+per reflection, 1 / (4 pi d), 81-tap Hann-windowed sinc fractional delay, response shifted by 40 samples); this file and
+csrc/k_ism.h state the same formulas independently (vectorised NumPy vs per-image HIP).
+"""
+import numpy as np
+
+FDL, FDL2 = 81, 40
+
+
+def ism_rir(dims, absorption, src, mic, max_order, fs, c_sound, Lh):
+    """dims (3,), src (3,), mic (3,) -> rir (Lh,) float64."""
+    dims, src, mic = (np.asarray(a, np.float64) for a in (dims, src, mic))
+    n = np.arange(-max_order, max_order + 1)
+    nx, ny, nz = np.meshgrid(n, n, n, indexing='ij')
+    order = np.abs(nx) + np.abs(ny) + np.abs(nz)
+    keep = order <= max_order
+    N = np.stack([nx[keep], ny[keep], nz[keep]], 1)
+    order = order[keep]
+    img = N * dims + np.where(N % 2 != 0, dims - src, src)
+    d = np.linalg.norm(img - mic, axis=1)
+    tau = d / c_sound * fs
+    ip = np.floor(tau).astype(np.int64)
+    fp = tau - ip
+    amp = np.sqrt(1.0 - absorption) ** order / (4 * np.pi * d)
+    k = np.arange(-FDL2, FDL2 + 1)
+    win = np.hanning(FDL)
+    taps = amp[:, None] * win[None] * np.sinc(k[None] - fp[:, None])
+    idx = ip[:, None] + k[None] + FDL2
+    h = np.zeros(Lh)
+    ok = (idx >= 0) & (idx < Lh) & (ip[:, None] < Lh)
+    np.add.at(h, idx[ok], taps[ok])
+    return h

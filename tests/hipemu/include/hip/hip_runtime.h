@@ -164,6 +164,22 @@ static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
 
 static inline int atomicAdd(int* p, int v) { return __sync_fetch_and_add(p, v); }
+static inline float atomicAdd(float* p, float v) {
+    unsigned* up = reinterpret_cast<unsigned*>(p);
+    unsigned old = *up, seen;
+    do {
+        seen = old;
+        float f;
+        std::memcpy(&f, &seen, 4);
+        f += v;
+        unsigned nu;
+        std::memcpy(&nu, &f, 4);
+        old = __sync_val_compare_and_swap(up, seen, nu);
+    } while (old != seen);
+    float r;
+    std::memcpy(&r, &old, 4);
+    return r;
+}
 static inline unsigned __float_as_uint(float f) {
     unsigned u;
     std::memcpy(&u, &f, 4);

@@ -423,6 +423,31 @@ def check_iterated(make_engine, K=2, M=2, L=2304, iters=2, tol=1e-4):
     return errs
 
 
+def check_ism_rir(make_engine, n_room=2, S=2, Q=3, max_order=5, rir_len=2048, seed=4, tol=5e-6):
+    """disco_ism_rir against the float64 restatement of the same published algorithm (oracle/ism_oracle.py); pyroomacoustics
+    itself is absent, so this is consistency of two independent statements of the formulas, not reference parity."""
+    from oracle import ism_oracle as io
+    rng = np.random.default_rng(seed)
+    dims = np.stack([rng.uniform(3, 8, n_room), rng.uniform(3, 5, n_room), rng.uniform(2.5, 3, n_room)], 1).astype(np.float32)
+    absorb = rng.uniform(0.2, 0.6, n_room).astype(np.float32)
+    src = (rng.uniform(0.3, 0.7, (n_room, S, 3)) * dims[:, None]).astype(np.float32)
+    mic = (rng.uniform(0.2, 0.8, (n_room, Q, 3)) * dims[:, None]).astype(np.float32)
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    got = eng.ism_rir(dims, absorb, src, mic, max_order=max_order, rir_len=rir_len).numpy()
+    assert np.all(np.isfinite(got))
+    err = 0.0
+    for r in range(n_room):
+        for s in range(S):
+            for q in range(Q):
+                want = io.ism_rir(dims[r], float(absorb[r]), src[r, s], mic[r, q], max_order, 16000.0, 343.0, rir_len)
+                err = max(err, float(np.max(np.abs(got[r, s, q] - want)) / np.max(np.abs(want))))
+    assert err < tol, err
+    # the direct path is the largest tap and sits at round(d / c * fs) + 40
+    d = np.linalg.norm(src[0, 0] - mic[0, 0])
+    assert abs(int(np.argmax(np.abs(got[0, 0, 0]))) - (int(round(d / 343.0 * 16000.0)) + 40)) <= 1
+    return err
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

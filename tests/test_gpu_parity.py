@@ -79,6 +79,11 @@ def test_rir_convolve(make_engine, n_sig, n_ch, Ld, Lh, out_len):
     pc.check_rir_convolve(make_engine, n_sig=n_sig, n_ch=n_ch, Ld=Ld, Lh=Lh, out_len=out_len)
 
 
+@pytest.mark.parametrize('max_order,rir_len', [(6, 4096), (20, 8192)])
+def test_ism_rir(make_engine, max_order, rir_len):
+    pc.check_ism_rir(make_engine, n_room=2, S=2, Q=2, max_order=max_order, rir_len=rir_len)
+
+
 def test_ivad(make_engine, golden_dir):
     pc.check_ivad(make_engine, golden_dir)
 
