@@ -130,14 +130,22 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     }
     __syncthreads();
 
-    // ---- Cholesky, one column per step; every lane keeps the (real) diagonal in registers
+    // ---- Cholesky, one column per step; every lane keeps the (real) diagonal in registers.
+    // Breakdown: the covariances arrive as float32, so a pivot below ~1e-7 of its diagonal entry is rounding noise (a
+    // numerically singular Rnn: coherent noise at low frequencies, silent channels).  The reference's LAPACK pencil solver
+    // returns finite numbers there (huge generalized eigenvalues, clamped to 1e6 by internal_formulas.py:59-60); here the
+    // pivot is floored and the column below it zeroed, which bounds every later quantity instead of amplifying noise by
+    // 1/sqrt(pivot) per breakdown.  Well-conditioned pencils never take this branch.
     double dd[P], rdd[P];
 #pragma unroll
     for (int c = 0; c < P; ++c) {
-        double d2 = Lm[SG::lt(c, c)].x;
+        const double a_cc = Lm[SG::lt(c, c)].x;
+        double d2 = a_cc;
 #pragma unroll
         for (int k = 0; k < c; ++k) d2 -= Lm[SG::lt(c, k)].x * Lm[SG::lt(c, k)].x + Lm[SG::lt(c, k)].y * Lm[SG::lt(c, k)].y;
-        const double d2c = fmax(d2, 1e-300);
+        const double fl = fmax(1e-7 * a_cc, 1e-30);
+        const bool brk = !(d2 >= fl);                   // also true for NaN
+        const double d2c = brk ? fl : d2;
         const double rd = rsqrt64(d2c);                 // 1 / L[c][c]
         dd[c] = d2c * rd;                               //     L[c][c]
         rdd[c] = rd;
@@ -145,7 +153,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
             c64 s = Lm[SG::lt(j, c)];
 #pragma unroll
             for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lm[SG::lt(j, k)], Lm[SG::lt(c, k)]));
-            Lm[SG::lt(j, c)] = zscale(s, rd);
+            Lm[SG::lt(j, c)] = brk ? make_double2(0.0, 0.0) : zscale(s, rd);
         }
         __syncthreads();
     }

@@ -448,6 +448,34 @@ def check_ism_rir(make_engine, n_room=2, S=2, Q=3, max_order=5, rir_len=2048, se
     return err
 
 
+def check_solver_singular_noise(make_engine):
+    """Numerically singular Rnn (coherent noise, silent channels): the solver must stay finite and bounded, and where the
+    problem is still well posed (co-rank 1: one infinite generalized eigenvalue, clamped to 1e6 by the reference) it must
+    agree with the reference's formulation (oracle intern_filter = scipy.linalg.eig path, internal_formulas.py:56-73)."""
+    from oracle import mwf_oracle as mo
+    rng = np.random.default_rng(0)
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    errs = {}
+    for P in (4, 7):
+        for rank in (1, 2, P - 1):
+            A = rng.standard_normal((P, rank)) + 1j * rng.standard_normal((P, rank))
+            Rnn = (A @ A.conj().T).astype(np.complex64)
+            B = rng.standard_normal((P, P + 2)) + 1j * rng.standard_normal((P, P + 2))
+            Rss = (B @ B.conj().T / (P + 2)).astype(np.complex64)
+            w, t1 = eng.gevd_mwf_r1(Rss[None], Rnn[None])
+            w = w.numpy()[0]
+            assert np.all(np.isfinite(w)) and np.abs(w).max() < 1e3, (P, rank, w)
+            if rank == P - 1:
+                wr, _ = mo.intern_filter(Rss, Rnn, mu=1, type='gevd', rank=1)
+                errs[(P, rank)] = relerr(w, wr)
+                assert errs[(P, rank)] < 1e-4, errs
+    # an all-zero noise matrix and a silent channel
+    for Rnn in (np.zeros((4, 4), np.complex64), np.diag([1, 0, 1, 1]).astype(np.complex64)):
+        w, _ = eng.gevd_mwf_r1(np.eye(4, dtype=np.complex64)[None], Rnn[None])
+        assert np.all(np.isfinite(w.numpy()))
+    return errs
+
+
 def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     """Node-sharded driver (z exchanged by an all-gather between the steps) == the single-GPU path, and == the oracle.
     The 'all-gather' here is a plain concatenation of the shards' z, run shard after shard in one process."""

@@ -84,6 +84,10 @@ def test_ism_rir(make_engine, max_order, rir_len):
     pc.check_ism_rir(make_engine, n_room=2, S=2, Q=2, max_order=max_order, rir_len=rir_len)
 
 
+def test_solver_singular_noise(make_engine):
+    pc.check_solver_singular_noise(make_engine)
+
+
 def test_ivad(make_engine, golden_dir):
     pc.check_ivad(make_engine, golden_dir)
 

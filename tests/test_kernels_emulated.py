@@ -84,6 +84,10 @@ def test_emu_ism_rir(make_engine):
     print(pc.check_ism_rir(make_engine, n_room=1, S=1, Q=2, max_order=3, rir_len=1024))
 
 
+def test_emu_solver_singular_noise(make_engine):
+    print(pc.check_solver_singular_noise(make_engine))
+
+
 def test_emu_node_sharded(make_engine):
     print(pc.check_node_sharded(make_engine, R=1, K=2, M=2, L=4096, world=2))
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The whole chain on the GPU, scored: dry signals + RIRs -> disco_rir_convolve -> mixtures at 0-6 dB -> two-step MWF
+"""The whole chain on the GPU, scored: shoebox rooms -> disco_ism_rir -> dry signals -> disco_rir_convolve -> mixtures at 0-6 dB -> two-step MWF
 (reference-output mode: yf, sf, nf) -> iSTFT -> the reference's metrics (disco_amd.metrics) -> z data set on disk.
 What the reference does across gen_disco/convolve_signals.py, speech_enhancement/tango.py:main and get_z_signals.py:main,
 on synthetic rooms (SURVEY 8d recipe).  Usage: tools/end_to_end_demo.py [rooms] [out_dir]"""
@@ -25,23 +25,23 @@ K, M, L, FS = 4, 4, 160000, 16000
 dev = 'cuda'
 torch.manual_seed(0)
 t0 = time.perf_counter()
-# ---- rooms: geometry-driven direct path + exponentially decaying tail (disco_amd/synth.py recipe), dry signals
-beta = np.empty(R); dist = np.empty((R, 2, K, M)); delay = np.empty((R, 2, K, M), np.int64); snr_db = np.empty(R)
+# ---- rooms: shoebox geometry of disco_amd/synth.py (SURVEY 8d ranges), RIRs by the image-source generator on the GPU
+# (absorption from Sabine's formula for the drawn RT60, as gen_disco/room_setups.py does for its alpha)
+dims = np.empty((R, 3), np.float32); absorb = np.empty(R, np.float32); snr_db = np.empty(R)
+srcs = np.empty((R, 2, 3), np.float32); mics = np.empty((R, K * M, 3), np.float32)
 for r in range(R):
     rng = np.random.default_rng(1234 + r)
-    beta[r], dist[r], delay[r] = synth._rir_params(rng, K, M)
+    d3, beta, mic_pos, src_pos = synth._geometry(rng, K, M)
+    dims[r], srcs[r], mics[r] = d3, src_pos, mic_pos.reshape(K * M, 3)
+    vol, surf = d3.prod(), 2 * (d3[0] * d3[1] + d3[0] * d3[2] + d3[1] * d3[2])
+    absorb[r] = min(0.95, 0.161 * vol / (surf * beta))
     snr_db[r] = rng.uniform(0, 6)
-tt = torch.arange(synth.RIR_TAPS, device=dev, dtype=torch.float32)
-rel = tt.view(1, 1, 1, 1, -1) - torch.tensor(delay, device=dev).unsqueeze(-1)
-rir = synth.TAIL_GAIN * torch.randn((R, 2, K, M, synth.RIR_TAPS), device=dev)
-rir = rir * torch.exp(-6.9 * rel.clamp(min=0) / (torch.tensor(beta, device=dev, dtype=torch.float32).view(R, 1, 1, 1, 1) * FS)) * (rel > 0)
-rir.scatter_(-1, torch.tensor(delay, device=dev).clamp(max=synth.RIR_TAPS - 1).unsqueeze(-1),
-             (1.0 / torch.tensor(dist, device=dev, dtype=torch.float32)).unsqueeze(-1))
+eng0 = get_engine(rooms=1, nodes=1, mics=1, length=1024)
+rir = torch.from_numpy(eng0.ism_rir(dims, absorb, srcs, mics, max_order=20, rir_len=synth.RIR_TAPS).numpy()).to(dev)   # (R, 2, K*M, taps)
 dry = torch.randn((R, 2, L), device=dev)
 dry[:, 0] *= np.sqrt(synth.TARGET_VAR)
 dry[:, 0, :FS] = 0                                                        # 1 s leading silence of the target
 # ---- reverberation: every (room, source) against its K*M impulse responses
-eng0 = get_engine(rooms=1, nodes=1, mics=1, length=1024)
 img = torch.empty((R * 2, K * M, L), device=dev)
 p = lambda t: t.data_ptr()
 eng0._chk(eng0.lib.disco_rir_convolve(eng0.ctx, p(dry.reshape(R * 2, L)), p(rir.reshape(R * 2, K * M, synth.RIR_TAPS).contiguous()),
