@@ -52,7 +52,7 @@ def test_emu_step2_fused(make_engine, K, M):
 
 
 def test_emu_step2_reuse(make_engine):
-    print(pc.check_step2_reuse(make_engine, R=1, K=3, M=2, L=4096))
+    print(pc.check_step2_reuse(make_engine, R=1, K=3, M=2, L=2304))
 
 
 def test_emu_online_golden(make_engine, golden_dir):
@@ -60,7 +60,7 @@ def test_emu_online_golden(make_engine, golden_dir):
 
 
 def test_emu_online_mwf(make_engine):
-    print(pc.check_online_mwf(make_engine, R=1, K=2, M=2, L=1536, update_every=3))
+    print(pc.check_online_mwf(make_engine, R=1, K=2, M=2, L=1280, update_every=3))
 
 
 def test_emu_metrics(make_engine, golden_dir):
