@@ -1,0 +1,49 @@
+"""The product never touches the oracle or a CPU fallback: `oracle/` is test infrastructure (only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import it), and the HIP test emulator under tests/hipemu is never loaded by the package."""
+import ast
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _imports(path):
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            for a in node.names:
+                yield a.name
+        elif isinstance(node, ast.ImportFrom):
+            yield ('.' * node.level) + (node.module or '')
+
+
+def test_package_never_imports_the_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, 'disco_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                p = os.path.join(root, f)
+                for mod in _imports(p):
+                    if mod == 'oracle' or mod.startswith('oracle.') or 'hipemu' in mod or mod.startswith('tests'):
+                        bad.append((os.path.relpath(p, REPO), mod))
+    assert not bad, bad
+
+
+def test_oracle_users_are_the_allowed_ones():
+    """bench.py imports the oracle only inside cpu_baseline(); __graft_entry__ only inside smoke()/build()."""
+    src = open(os.path.join(REPO, 'bench.py')).read()
+    tree = ast.parse(src)
+    for node in tree.body:                                         # no module-level oracle import
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            assert 'oracle' not in ast.dump(node)
+    users = [n.name for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and 'oracle' in ast.get_source_segment(src, n)
+             and re.search(r'from oracle|import oracle', ast.get_source_segment(src, n))]
+    assert users == ['cpu_baseline'], users
+
+
+def test_kernel_sources_have_no_cuda_or_portability_shims():
+    csrc = os.path.join(REPO, 'disco_amd', 'csrc')
+    for f in os.listdir(csrc):
+        txt = open(os.path.join(csrc, f)).read()
+        for token in ('__HIP_PLATFORM_AMD__', '__CUDACC__', 'cuda_runtime', 'hipify', '#include <cuda'):
+            assert token not in txt, (f, token)
