@@ -269,6 +269,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                    # rank 0 may still be in its per-stage timing: leave together
         dist.destroy_process_group()
 
 
