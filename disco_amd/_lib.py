@@ -49,6 +49,7 @@ PROTOTYPES = {
     'disco_gevd_mwf_r1_pending': (_int, [_vp, _f, _vp, _vp, _vp]),
     'disco_apply': (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     'disco_noise_residual': (_int, [_vp, _vp, _vp, _vp, _vp]),
+    'disco_filter_head': (_int, [_vp, _vp, _int, _vp, _vp]),
     'disco_stft_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_cov_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_cov_fused_reuse': (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

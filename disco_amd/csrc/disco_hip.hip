@@ -1113,6 +1113,19 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     return disco_istft(ctx, yo, G, out, s);
 }
 
+// Local part of a P-entry filter (the iterated scheme's re-compression filter); honours the node shard, so the node-sharded
+// driver can run the DANSE-style iterations with one all-gather of z per iteration.
+extern "C" int disco_filter_head(disco_ctx* ctx, const disco_c32* w_glo, int P, disco_c32* w_loc, disco_stream s) {
+    if (!ctx) return DISCO_E_ARG;
+    const disco_cfg& c = ctx->cfg;
+    if (!w_glo || !w_loc) return fail(ctx, DISCO_E_ARG, "disco_filter_head: null argument");
+    if (P < c.mics) return fail(ctx, DISCO_E_ARG, "disco_filter_head: P < M");
+    const long long nb = (long long)c.rooms * ctx->Kl * ctx->F;
+    hipLaunchKernelGGL(k_filter_head, dim3((unsigned)std::min<long long>((nb * c.mics + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)s,
+                       (const c32*)w_glo, (c32*)w_loc, nb, c.mics, P);
+    return check_launch(ctx, "k_filter_head");
+}
+
 // ---- image-source RIR generator --------------------------------------------------------------------------
 
 extern "C" int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorption, const float* src, const float* mic,

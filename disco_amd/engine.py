@@ -297,15 +297,28 @@ class Engine:
                                                      t1.ptr if want_t1 else None, self.stream))
         return w, t1
 
-    def apply(self, X, w, Z=None, conj=True):
-        """out = w^H [X ; Z_-k] (conj=True) or w^T [...]   [tango.py:369-374, 445-450]"""
+    def apply(self, X, w, Z=None, conj=True, out=None):
+        """out = w^H [X ; Z_-k] (conj=True) or w^T [...]   [tango.py:369-374, 445-450]
+        out: optional caller-owned (R, Kl, T, F) complex64 device array (DevBuf or torch tensor) to write into."""
         P = self.M + (self.K - 1 if Z is not None else 0)
         px, kx = self.to_device(X, np.complex64)
         pz, kz = self.to_device(Z, np.complex64)
         pw, kw = self.to_device(w, np.complex64)
-        out = self.empty((self.R, self.Kl, self.T, self.F), np.complex64)
-        self._chk(self.lib.disco_apply(self.ctx, px, pz, pw, P, int(bool(conj)), out.ptr, self.stream))
+        if out is None:
+            out = self.empty((self.R, self.Kl, self.T, self.F), np.complex64)
+        else:
+            assert tuple(out.shape) == (self.R, self.Kl, self.T, self.F) and not isinstance(out, np.ndarray)
+        po, ko = self.to_device(out, np.complex64)
+        self._chk(self.lib.disco_apply(self.ctx, px, pz, pw, P, int(bool(conj)), po, self.stream))
         return out
+
+    def filter_head(self, w_glo):
+        """w_glo (R, Kl, F, P) -> its local part (R, Kl, F, M): the re-compression filter of the iterated scheme."""
+        P = int(w_glo.shape[-1])
+        pw, kw = self.to_device(w_glo, np.complex64)
+        w_loc = self.empty((self.R, self.Kl, self.F, self.M), np.complex64)
+        self._chk(self.lib.disco_filter_head(self.ctx, pw, P, w_loc.ptr, self.stream))
+        return w_loc
 
     def noise_residual(self, X, z):
         px, kx = self.to_device(X, np.complex64)

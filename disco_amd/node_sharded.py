@@ -1,6 +1,11 @@
 """Node-sharded two-step MWF: the nodes of a room live on different GPUs and the compressed signals z are exchanged with
 ONE all-gather between the two steps -- the communication DISCO's distributed algorithm actually performs
 (tango.py:378-386; SURVEY.md 8e "finer sharding").  Rank q of W holds nodes [q*K/W, (q+1)*K/W) of every room.
+The DANSE-style iterated scheme (BASELINE configs[4]) adds one more all-gather per extra iteration.
+
+Two drivers over the same staged entry points: `tango_enhance_node_sharded` (numpy host, any all-gather callable) and
+`tango_enhance_node_sharded_torch` (device-resident torch tensors, z gathered on the GPUs by torch.distributed --
+backend 'nccl' = RCCL over xGMI -- with no host round trip).
 
 The default deployment shards ROOMS (all nodes of a room on one GPU, no data-path collective, z exchanged on chip);
 this mode exists for rooms whose nodes do not fit / are produced on different devices.  xGMI is point-to-point, so for
@@ -16,30 +21,78 @@ def node_range(rank, world, K):
     return rank * kl, kl
 
 
-def tango_enhance_node_sharded(eng, y_local, mask_z_local, mask_w_local, all_gather_z):
+def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=None):
+    """Shared data flow.  z_out / yf_out: caller-owned device arrays for this rank's z / yf (or None: DevBuf);
+    gather(z_local) -> z of ALL nodes (R, K, T, F), numpy or device array."""
+    if iters < 1:
+        raise ValueError('iters must be >= 1')
+    R, Kl, M = eng.R, eng.Kl, eng.M
+    if hasattr(y_local, 'data_ptr'):
+        y_sig = y_local.reshape(R * Kl, M, eng.Lsamp)
+        assert y_sig.is_contiguous()
+    else:
+        y_sig = np.ascontiguousarray(y_local, dtype=np.float32).reshape(R * Kl, M, eng.Lsamp)
+    X = eng.stft(y_sig).reshape(R, Kl, eng.T, eng.F, M)
+    # step 1, local (tango.py:326-376)
+    eng.cov_masked(X, mask_z_local, Rss_out=False)
+    w_loc, _ = eng.gevd_mwf_r1_pending(M)
+    z_all = w_glo = None
+    for it in range(iters):
+        z_loc = eng.apply(X, w_loc, out=z_out)
+        # the exchange (tango.py:378-386): one all-gather of the compressed signals
+        z_all = gather(z_loc)
+        assert tuple(z_all.shape) == (R, eng.K, eng.T, eng.F)
+        # step 2, local again (tango.py:411-450)
+        if eng.K > 1:
+            eng.cov_masked(X, mask_w_local, z_all, z_all, mask_remote=True, Rss_out=False)
+        else:
+            eng.cov_masked(X, mask_w_local, Rss_out=False)
+        w_glo, _ = eng.gevd_mwf_r1_pending(M + eng.K - 1)
+        if it + 1 < iters:
+            # DANSE-style continuation (disco_tango_enhance_iterated): re-compress with the local part of the new filter
+            w_loc = eng.filter_head(w_glo)
+    yf = eng.apply(X, w_glo, Z=z_all if eng.K > 1 else None, out=yf_out)
+    out = eng.istft(yf.reshape(R * Kl, eng.T, eng.F)).reshape(R, Kl, eng.Lsamp)
+    return out, yf, z_all
+
+
+def tango_enhance_node_sharded(eng, y_local, mask_z_local, mask_w_local, all_gather_z, iters=1):
     """eng: Engine(rooms=R, nodes=K, ...) on which `set_node_shard(k0, Kl)` has been called.
     y_local (R, Kl, M, L), masks (R, Kl, T, F) -- this rank's nodes.
     all_gather_z: callable taking this rank's z as a numpy (R, Kl, T, F) complex64 array and returning the z of ALL nodes,
     (R, K, T, F), in global node order (torch.distributed all_gather over RCCL in production, gloo in the CPU test).
-    Returns (out_local (R, Kl, L) DevBuf, yf_local DevBuf, z_all numpy)."""
-    R, Kl, M = eng.R, eng.Kl, eng.M
-    X = eng.stft(np.ascontiguousarray(y_local, dtype=np.float32).reshape(R * Kl, M, eng.Lsamp)).reshape(R, Kl, eng.T, eng.F, M)
-    # step 1, local (tango.py:326-376)
-    eng.cov_masked(X, mask_z_local, Rss_out=False)
-    w_loc, _ = eng.gevd_mwf_r1_pending(M)
-    z_loc = eng.apply(X, w_loc)
-    # the exchange (tango.py:378-386): one all-gather of the compressed signals
-    z_all = np.ascontiguousarray(all_gather_z(z_loc.numpy()), dtype=np.complex64)
-    assert z_all.shape == (R, eng.K, eng.T, eng.F)
-    # step 2, local again (tango.py:411-450)
-    if eng.K > 1:
-        eng.cov_masked(X, mask_w_local, z_all, z_all, mask_remote=True, Rss_out=False)
-    else:
-        eng.cov_masked(X, mask_w_local, Rss_out=False)
-    w_glo, _ = eng.gevd_mwf_r1_pending(M + eng.K - 1)
-    yf = eng.apply(X, w_glo, Z=z_all if eng.K > 1 else None)
-    out = eng.istft(yf.reshape(R * Kl, eng.T, eng.F)).reshape(R, Kl, eng.Lsamp)
-    return out, yf, z_all
+    iters > 1: the iterated scheme of disco_tango_enhance_iterated, one all-gather per iteration.
+    Returns (out_local (R, Kl, L) DevBuf, yf_local DevBuf, z_all numpy -- the LAST exchanged z)."""
+    def gather(z_loc):
+        return np.ascontiguousarray(all_gather_z(z_loc.numpy()), dtype=np.complex64)
+    return _run(eng, y_local, mask_z_local, mask_w_local, iters, None, gather)
+
+
+def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, group=None, iters=1):
+    """Device-resident variant: y_local (R, Kl, M, L) float32 and the masks (R, Kl, T, F) float32 are contiguous torch tensors
+    on this rank's GPU; z stays on the GPUs and is all-gathered by torch.distributed over `group` (RCCL over xGMI; every
+    rank holds the same number of nodes, rank order == node order).  The library launches on the null stream, which is
+    torch's default stream, so the collective is ordered after the kernels that produce z and before those that read it.
+    Per all-gather a rank sends R * Kl * T * F * 8 bytes to each peer (1.29 MB per (room, node) at C3).
+    Returns (out_local DevBuf (R, Kl, L), yf_local torch (R, Kl, T, F) complex64, z_all torch (R, K, T, F) complex64)."""
+    import torch
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    R, Kl, K = eng.R, eng.Kl, eng.K
+    if Kl * W != K:
+        raise ValueError(f'{W} ranks x {Kl} nodes per rank != {K} nodes')
+    dev = y_local.device
+    shape = (R, Kl, eng.T, eng.F)
+    z_loc = torch.empty(shape, dtype=torch.complex64, device=dev)
+    yf = torch.empty(shape, dtype=torch.complex64, device=dev)
+    parts = torch.empty((W,) + shape, dtype=torch.complex64, device=dev)
+
+    def gather(z):
+        # concatenated-along-dim-0 form: the one every backend (RCCL, gloo) accepts
+        dist.all_gather_into_tensor(torch.view_as_real(parts).view(W * R, Kl, eng.T, eng.F, 2), torch.view_as_real(z), group=group)
+        # (W, R, Kl, T, F) -> (R, W*Kl, T, F): one on-device transpose copy (HBM speed, far below the link time)
+        return parts.permute(1, 0, 2, 3, 4).reshape(R, K, eng.T, eng.F).contiguous()
+    return _run(eng, y_local, mask_z_local, mask_w_local, iters, z_loc, gather, yf_out=yf)
 
 
 def torch_all_gather(world):

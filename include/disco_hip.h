@@ -215,6 +215,11 @@ int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, const float* ma
                                  float* out, disco_c32* z_y, disco_c32* yf,
                                  void* workspace, size_t workspace_bytes, disco_stream s);
 
+/* w_loc[..][f][0:M] = w_glo[..][f][0:M]: the local part of every node's P-entry global filter -- the re-compression filter
+ * of the iterated scheme above, exposed so that a node-sharded run (disco_set_node_shard) can iterate with one all-gather
+ * of z per iteration.  w_glo [R][K][F][P] -> w_loc [R][K][F][M]  (K = the shard's node count when a shard is active). */
+int disco_filter_head(disco_ctx* ctx, const disco_c32* w_glo, int P, disco_c32* w_loc, disco_stream s);
+
 /* 'ivad' mask -- get_mask(..., mask_type='ivad', ts=s[node][0]) (tango.py:217-221): vad_oracle_batch (sigproc_utils.py:12-55:
  * window power test against 0.001 * the 0.99-quantile of the centred signal's instantaneous power, win = n_fft, hop) sampled
  * every hop and tiled over frequency; frames beyond ceil(L / hop) are 0.

@@ -44,7 +44,7 @@ def test_two_rank_room_sharding_and_timing_contract():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = _collect(procs, q, world, 120)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -63,6 +63,32 @@ def test_split_rooms_balanced():
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         sizes = [b - a for a, b in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _collect(procs, q, world, timeout=600):
+    """Results of all ranks; fails at once (instead of waiting out the timeout) when a rank dies."""
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=1.0))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f'rank(s) failed (exit codes {dead}) or timed out')
+    return sorted(res)
+
+
+def _prebuild_emu():
+    """Build the emulated test library once in the parent, so the two ranks never compile it concurrently."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_build
+    emu_build.build_emu()
 
 
 # ---- node-sharded mode: the z all-gather between the two steps (tango.py:378-386) over a real process group ------------
@@ -95,15 +121,75 @@ def _node_worker(rank, world, port, q):
 def test_node_sharded_all_gather_two_ranks():
     """Two gloo ranks, one node each: step 1 local, all-gather of z, step 2 local -- both ranks match the float64 oracle
     (every rank sees ALL z after the gather; its own filtered output covers its own node)."""
+    _prebuild_emu()
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_node_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in range(world))
+    res = _collect(procs, q, world)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     for rank, err_z, err_yf in res:
         assert err_z < 1e-5 and err_yf < 1e-5, (rank, err_z, err_yf)
+
+
+def _node_worker_torch(rank, world, port, q):
+    """The device-resident driver (torch tensors in, torch.distributed all_gather_into_tensor for z), 2 iterations: on the
+    emulated build 'device' memory is host memory, so CPU tensors + gloo exercise the same code RCCL runs on the GPUs."""
+    import numpy as np
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dd.init('gloo', rank, world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_build
+    from disco_amd import synth
+    from disco_amd.engine import Engine
+    from disco_amd.node_sharded import node_range, tango_enhance_node_sharded_torch
+    from oracle import tango_oracle as to
+    R, K, M, L = 2, 2, 2, 1280
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    k0, kl = node_range(rank, world, K)
+    eng = Engine(rooms=R, nodes=K, mics=M, length=L, lib=emu_build.load_emu())
+    eng.set_node_shard(k0, kl)
+    res = {}
+    for iters in (1, 2):
+        os_ = [to.offline_tango_vec(y[r], s[r], n[r], vads=['irm1', 'irm1'], precision='f64', solver='eigh', extra_iters=iters - 1)
+               for r in range(R)]
+        mask = np.stack([np.stack([o['masks_z'][k].T for k in range(k0, k0 + kl)]) for o in os_]).astype(np.float32)
+        yt = torch.from_numpy(np.ascontiguousarray(y[:, k0:k0 + kl]))
+        mt = torch.from_numpy(mask)
+        out, yf, z_all = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=iters)
+        assert isinstance(yf, torch.Tensor) and isinstance(z_all, torch.Tensor) and z_all.shape == (R, K, eng.T, eng.F)
+        yf = yf.numpy()
+        err = max(float(np.linalg.norm(yf[r, i].T - os_[r]['yf'][k0 + i]) / np.linalg.norm(os_[r]['yf'][k0 + i]))
+                  for r in range(R) for i in range(kl))
+        # every rank must hold the same gathered z, in global node order
+        chk = torch.view_as_real(z_all).double().sum(dim=(0, 2, 3)).contiguous()
+        ref = chk.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(chk, ref)
+        res[iters] = err
+    q.put((rank, res[1], res[2]))
+    dist.destroy_process_group()
+
+
+def test_node_sharded_device_resident_iterated_two_ranks():
+    """tango_enhance_node_sharded_torch with 1 and 2 step-2 iterations (one all-gather each) on two gloo ranks against the
+    float64 oracle of the same definition (offline_tango_vec(extra_iters=...))."""
+    _prebuild_emu()
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_node_worker_torch, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, world)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, e1, e2 in res:
+        assert e1 < 1e-5 and e2 < 1e-4, (rank, e1, e2)
