@@ -49,6 +49,55 @@ def kernel_alg_bytes(M, K, F, H):
     }
 
 
+_WORKER = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+room, K, M, L, start_at = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+from disco_amd import synth
+from oracle import tango_oracle as to
+y, s, n, _ = synth.make_room_numpy(room, K=K, M=M, L=L)
+late = time.time() > start_at
+while time.time() < start_at:
+    time.sleep(0.005)
+t0 = time.time()
+to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+print(t0, time.time(), int(late))
+"""
+
+
+def cpu_vectorised_all_cores(K, M, L, hop=256, lead_seconds=20.0, limit_seconds=90.0):
+    """the vectorised oracle on every host core at once -- one single-threaded process per core, one room
+    each, all released at the same wall-clock instant; rate = rooms done / (last finish - common start).  Plain
+    subprocesses with a hard time limit: a reported baseline must never be able to hang or fail the bench."""
+    import subprocess
+    procs = os.cpu_count() or 1
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    start_at = time.time() + lead_seconds
+    ps = []
+    try:
+        for r in range(procs):
+            ps.append(subprocess.Popen([sys.executable, '-c', _WORKER, REPO, str(r), str(K), str(M), str(L), repr(start_at)],
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True))
+        ends, late = [], 0
+        for p in ps:
+            out, _ = p.communicate(timeout=max(1.0, start_at + limit_seconds - time.time()))
+            t0, t1, lt = out.split()
+            ends.append(float(t1))
+            late += int(lt)
+        if late:
+            return {'error': f'{late} of {procs} workers were not ready at the common start'}
+        wall = max(ends) - start_at
+    except Exception as e:
+        for p in ps:
+            if p.poll() is None:
+                p.kill()
+        return {'error': repr(e)}
+    T = 1 + L // hop
+    return {'value': procs * K * T / wall, 'unit': 'node-frames/s', 'cores': procs, 'seconds': round(wall, 2),
+            'what': f'{procs} processes x 1 room each (OMP_NUM_THREADS=1), released together, '
+                    'oracle/tango_oracle.py:offline_tango_vec'}
+
+
 def cpu_baseline(K, M, L, seconds_hint=25.0):
     """The reference's CPU path (literal loop nest, oracle/tango_oracle.py:offline_tango_literal -- pinned
     bit-exact against the reference's own code) on ONE room of the same workload, one host core."""
@@ -67,6 +116,7 @@ def cpu_baseline(K, M, L, seconds_hint=25.0):
     return {'value': K * T / dt, 'unit': 'node-frames/s', 'cores': 1, 'kind': 'port',
             'vectorised_numpy': {'value': K * T / dtv, 'unit': 'node-frames/s', 'seconds': round(dtv, 2),
                                  'what': 'oracle/tango_oracle.py:offline_tango_vec (float64, einsum covariances, batched eigh), same room'},
+            'vectorised_numpy_all_cores': cpu_vectorised_all_cores(K, M, L),
             'sample': f'1 room ({K} nodes x {M} mics, {L} samples = {K * T} node-frames), literal reference loop nest '
                       f'(tango.py:326-457 restated, bit-exact vs reference), STFTs included, {dt:.1f} s on 1 of '
                       f'{os.cpu_count()} host cores',
