@@ -6,11 +6,14 @@
 // (disco_amd/lib/libdisco_hip.so) is built by hipcc for gfx950 only and the Python package refuses to run
 // without it.  Only tests/emu_build.py compiles against this header, into tests/_emu/.
 //
-// Model: one OS thread per GPU thread of a block; blocks run one after another; __syncthreads() is a
-// pthread barrier; a wave is 64 consecutive threads; shuffles go through a per-wave slot array;
-// `__shared__` becomes `static` (valid because blocks are serialised).  gcc, -pthread.
+// Model: every GPU thread of a block is a user-level fiber (ucontext) of one OS thread, switched only at barriers and
+// shuffles; __syncthreads() / wave barriers are generation-counting barriers over the live fibers; a wave is 64
+// consecutive threads; shuffles go through a per-wave slot array; blocks are handed out to one OS thread per host core
+// and `__shared__` becomes `static thread_local` (one LDS image per OS thread).  gcc, -pthread.
 #pragma once
-#include <pthread.h>
+#include <ucontext.h>
+
+#include <atomic>
 
 #include <cmath>
 #include <cstdint>
@@ -25,7 +28,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
@@ -52,54 +55,160 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 
 namespace hipemu {
+// A barrier of fibers: trips when every LIVE participant has arrived (threads that returned no longer count, as on the GPU).
+struct Bar {
+    int alive = 0, count = 0;
+    unsigned gen = 0;
+};
 struct WaveState {
-    pthread_barrier_t bar;
+    Bar bar;
     uint64_t slot[64];
-    int n;
+    int n;                       // lanes of this wave (valid shuffle sources)
 };
 struct BlockState {
-    pthread_barrier_t bar;
+    Bar bar;
     std::vector<WaveState> waves;
 };
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+    Bar* wait_bar = nullptr;     // barrier the fiber sleeps on (runnable when its generation moves on)
+    unsigned wait_gen = 0;
+    uint3 tidx;
+};
+struct Worker {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    BlockState bs;
+    unsigned cur = 0;
+    const std::function<void()>* fn = nullptr;
+    ~Worker() {
+        for (auto& f : fibers) std::free(f.stack);
+    }
+};
+constexpr size_t kStackBytes = 256 * 1024;
 inline thread_local uint3 t_threadIdx, t_blockIdx;
 inline thread_local dim3 t_blockDim, t_gridDim;
 inline thread_local BlockState* t_block = nullptr;
 inline thread_local WaveState* t_wave = nullptr;
 inline thread_local int t_lane = 0;
+inline thread_local Worker* t_worker = nullptr;
 
+inline void fiber_main() {
+    Worker* w = t_worker;
+    Fiber& f = w->fibers[w->cur];
+    (*w->fn)();
+    f.done = true;               // uc_link returns to the scheduler
+}
+
+inline void bar_wait(Bar& b) {
+    Worker* w = t_worker;
+    const unsigned g = b.gen;
+    if (++b.count >= b.alive) {
+        b.count = 0;
+        ++b.gen;
+        return;
+    }
+    Fiber& f = w->fibers[w->cur];
+    f.wait_bar = &b;
+    f.wait_gen = g;
+    swapcontext(&f.ctx, &w->sched);
+}
+
+// Runs one block: every GPU thread is a fiber of THIS OS thread, switched at barriers / shuffles only.
+inline void run_block(Worker& w, dim3 block, unsigned nthreads) {
+    BlockState& bs = w.bs;
+    const unsigned nwaves = (nthreads + 63) / 64;
+    bs.bar = Bar{};
+    bs.bar.alive = (int)nthreads;
+    bs.waves.resize(nwaves);
+    for (unsigned v = 0; v < nwaves; ++v) {
+        bs.waves[v].n = (int)std::min(64u, nthreads - 64 * v);
+        bs.waves[v].bar = Bar{};
+        bs.waves[v].bar.alive = bs.waves[v].n;
+    }
+    if (w.fibers.size() < nthreads) w.fibers.resize(nthreads);
+    for (unsigned t = 0; t < nthreads; ++t) {
+        Fiber& f = w.fibers[t];
+        if (!f.stack) f.stack = (char*)std::malloc(kStackBytes);
+        f.done = false;
+        f.wait_bar = nullptr;
+        f.tidx = uint3{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStackBytes;
+        f.ctx.uc_link = &w.sched;
+        makecontext(&f.ctx, (void (*)())fiber_main, 0);
+    }
+    unsigned remaining = nthreads;
+    while (remaining) {
+        bool progressed = false;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            Fiber& f = w.fibers[t];
+            if (f.done) continue;
+            if (f.wait_bar) {
+                if (f.wait_bar->gen == f.wait_gen) continue;      // still asleep
+                f.wait_bar = nullptr;
+            }
+            progressed = true;
+            w.cur = t;
+            t_threadIdx = f.tidx;
+            t_wave = &bs.waves[t / 64];
+            t_lane = (int)(t % 64);
+            swapcontext(&w.sched, &f.ctx);
+            if (f.done) {
+                // a thread that returned no longer takes part in barriers: release the ones it would have completed
+                --remaining;
+                Bar* bars[2] = {&bs.bar, &bs.waves[t / 64].bar};
+                for (Bar* b : bars) {
+                    --b->alive;
+                    if (b->alive > 0 && b->count >= b->alive) {
+                        b->count = 0;
+                        ++b->gen;
+                    }
+                }
+            }
+        }
+        if (!progressed) {
+            std::fprintf(stderr, "hipemu: deadlock -- %u thread(s) of a block wait on a barrier the others never reach\n", remaining);
+            std::abort();
+        }
+    }
+}
+
+// Blocks are independent: they are handed out to one OS thread per host core (`__shared__` is thread_local static storage,
+// so every OS thread has its own LDS image, reused block after block).
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
     const unsigned nthreads = block.x * block.y * block.z;
-    BlockState bs;
-    pthread_barrier_init(&bs.bar, nullptr, nthreads);
-    const unsigned nwaves = (nthreads + 63) / 64;
-    bs.waves.resize(nwaves);
-    for (unsigned w = 0; w < nwaves; ++w) {
-        bs.waves[w].n = (int)std::min(64u, nthreads - 64 * w);
-        pthread_barrier_init(&bs.waves[w].bar, nullptr, bs.waves[w].n);
-    }
-    auto body = [&](unsigned tid) {
-        t_block = &bs;
-        t_wave = &bs.waves[tid / 64];
-        t_lane = (int)(tid % 64);
+    const unsigned long long nblocks = (unsigned long long)grid.x * grid.y * grid.z;
+    if (!nthreads || !nblocks) return;
+    std::atomic<unsigned long long> next{0};
+    auto work = [&]() {
+        thread_local Worker worker;
+        Worker& w = worker;
+        t_worker = &w;
+        t_block = &w.bs;
         t_blockDim = block;
         t_gridDim = grid;
-        t_threadIdx.x = tid % block.x;
-        t_threadIdx.y = (tid / block.x) % block.y;
-        t_threadIdx.z = tid / (block.x * block.y);
-        for (unsigned bz = 0; bz < grid.z; ++bz)
-            for (unsigned by = 0; by < grid.y; ++by)
-                for (unsigned bx = 0; bx < grid.x; ++bx) {
-                    t_blockIdx = uint3{bx, by, bz};
-                    fn();
-                    pthread_barrier_wait(&bs.bar);      // block boundary: `static` LDS is reused by the next block
-                }
+        w.fn = &fn;
+        for (;;) {
+            const unsigned long long b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            t_blockIdx = uint3{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((unsigned long long)grid.x * grid.y))};
+            run_block(w, block, nthreads);
+        }
     };
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nworkers = (unsigned)std::min<unsigned long long>(hw ? hw : 1, nblocks);
+    if (nworkers <= 1) {
+        work();
+        return;
+    }
     std::vector<std::thread> th;
-    th.reserve(nthreads);
-    for (unsigned t = 0; t < nthreads; ++t) th.emplace_back(body, t);
+    th.reserve(nworkers);
+    for (unsigned t = 0; t < nworkers; ++t) th.emplace_back(work);
     for (auto& t : th) t.join();
-    pthread_barrier_destroy(&bs.bar);
-    for (auto& w : bs.waves) pthread_barrier_destroy(&w.bar);
 }
 
 template <class T>
@@ -108,9 +217,9 @@ inline T shfl_abs(T v, int src_abs) {
     uint64_t bits = 0;
     std::memcpy(&bits, &v, sizeof(T));
     t_wave->slot[t_lane] = bits;
-    pthread_barrier_wait(&t_wave->bar);
+    bar_wait(t_wave->bar);
     uint64_t r = t_wave->slot[(src_abs >= 0 && src_abs < t_wave->n) ? src_abs : t_lane];
-    pthread_barrier_wait(&t_wave->bar);
+    bar_wait(t_wave->bar);
     T out;
     std::memcpy(&out, &r, sizeof(T));
     return out;
@@ -126,7 +235,7 @@ inline T shfl_abs(T v, int src_abs) {
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
 
-static inline void __syncthreads() { pthread_barrier_wait(&hipemu::t_block->bar); }
+static inline void __syncthreads() { hipemu::bar_wait(hipemu::t_block->bar); }
 
 template <class T>
 static inline T __shfl(T v, int src, int width = 64) {
@@ -159,7 +268,7 @@ static inline int __all(int pred) {
 }
 
 // wave-level fences used by the kernels: the scheduling barrier becomes a real 64-thread rendezvous here
-static inline void __builtin_amdgcn_wave_barrier() { pthread_barrier_wait(&hipemu::t_wave->bar); }
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::bar_wait(hipemu::t_wave->bar); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
 
