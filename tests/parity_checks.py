@@ -557,3 +557,64 @@ def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-
     assert errs['mask'] < 2e-5 and errs['mask_max'] < 5e-3, errs
     assert errs['z_y'] < tol and errs['yf'] < tol and errs['out'] < tol, errs
     return errs
+
+
+def check_iterated_outputs(make_engine, K, M, L, n_fft, iters, tol=1e-4):
+    """disco_tango_enhance_iterated: STFT-domain AND time-domain outputs against the oracle's restatement of the same
+    definition (offline_tango_vec(extra_iters=...)); iters = 1 must be the plain two-step path."""
+    from disco_amd import synth
+    from oracle import stft_oracle as so
+    from oracle import tango_oracle as to
+    y, s, n = synth.make_rooms_numpy(1, K=K, M=M, L=L)
+    eng = make_engine(rooms=1, nodes=K, mics=M, length=L, n_fft=n_fft)
+    m = eng.mask_oracle(s[0, :, 0], n[0, :, 0]).reshape(1, K, eng.T, eng.F)
+    out, yf = eng.tango_enhance_iterated(y, m, iters=iters)
+    o = to.offline_tango_vec(y[0], s[0], n[0], vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh',
+                             extra_iters=iters - 1)
+    for k in range(K):
+        assert relerr(yf.numpy()[0, k].T, o['yf'][k]) < tol
+        ref = so.istft(o['yf'][k], L, n_fft, n_fft // 2, work_dtype=np.float64)
+        assert relerr(out.numpy()[0, k], ref) < tol
+    # iters = 1 must be the plain two-step path
+    out1, _ = eng.tango_enhance_iterated(y, m, iters=1)
+    out_ref, _, _ = eng.tango_enhance(y, m)
+    assert relerr(out1.numpy(), out_ref.numpy()) < 1e-5
+    return True
+
+
+def check_reference_golden_scene(make_engine, golden_dir, scene):
+    """HIP path against outputs of the REFERENCE'S OWN offline_tango (tests/golden/tango_ref_<scene>.npz)."""
+    import os
+    g = np.load(os.path.join(golden_dir, f'tango_ref_{scene}.npz'))
+    K = int(g['K'])
+    y = np.stack([g[f'y{k}'] for k in range(K)])[None]
+    s = np.stack([g[f's{k}'] for k in range(K)])[None]
+    n = np.stack([g[f'n{k}'] for k in range(K)])[None]
+    R, K, M, L = y.shape
+    eng = make_engine(rooms=1, nodes=K, mics=M, length=L)
+    m = eng.mask_oracle(s[0, :, 0], n[0, :, 0]).reshape(1, K, eng.T, eng.F)
+    out, z, yf = eng.tango_enhance(y, m)
+    for k in range(K):
+        assert np.abs(m.numpy()[0, k].T - g[f'masks_z{k}']).max() < 1e-3
+        assert relerr(z.numpy()[0, k].T, g[f'z_y{k}']) < 1e-2
+        assert relerr(yf.numpy()[0, k].T, g[f'yf{k}']) < 1e-2
+
+
+def check_size_independent_properties(make_engine, R, K, M, L):
+    """(i) iSTFT(STFT(x)) == x; (ii) the MWF output scales linearly with a common input gain (masks unchanged);
+    (iii) batch independence: room r of a batch equals the same room processed alone, bit for bit."""
+    from disco_amd import synth
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L)
+    T, F = eng.T, eng.F
+    m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F)
+    out, z, yf = eng.tango_enhance(y, m)
+    out2, z2, yf2 = eng.tango_enhance(2.0 * y, m)
+    assert relerr(out2.numpy(), 2.0 * out.numpy()) < 1e-5            # (ii)
+    eng1 = make_engine(rooms=1, nodes=K, mics=M, length=L)
+    o1, _, _ = eng1.tango_enhance(y[R // 2:R // 2 + 1], m.numpy()[R // 2:R // 2 + 1])
+    assert np.array_equal(o1.numpy()[0], out.numpy()[R // 2])                 # (iii) bit-identical
+    X = eng.stft(y.reshape(R * K, M, L))
+    xr = eng.istft(eng.stft(y[:, :, 0].reshape(R * K, 1, L)).reshape(R * K, T, F)).numpy()
+    assert np.abs(xr - y[:, :, 0].reshape(R * K, L)).max() < 1e-5 * np.abs(y).max() + 1e-6   # (i)
+    assert np.all(np.isfinite(out.numpy()))

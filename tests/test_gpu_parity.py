@@ -163,22 +163,7 @@ def test_iterated_danse_extension(make_engine, K, M, L, n_fft, iters):
     """BASELINE.json configs[4] (C5): DANSE-style extra iterations of step 2.  This is an EXTENSION: the reference is
     strictly two-step (tango.py:1-2), so there is no reference parity; the check is against the oracle's restatement
     of the same definition (z_k <- w_glo,k[:M]^H y_k)."""
-    from oracle import stft_oracle as so
-    from oracle import tango_oracle as to
-    y, s, n = synth.make_rooms_numpy(1, K=K, M=M, L=L)
-    eng = make_engine(rooms=1, nodes=K, mics=M, length=L, n_fft=n_fft)
-    m = eng.mask_oracle(s[0, :, 0], n[0, :, 0]).reshape(1, K, eng.T, eng.F)
-    out, yf = eng.tango_enhance_iterated(y, m, iters=iters)
-    o = to.offline_tango_vec(y[0], s[0], n[0], vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh',
-                             extra_iters=iters - 1)
-    for k in range(K):
-        assert pc.relerr(yf.numpy()[0, k].T, o['yf'][k]) < 1e-4
-        ref = so.istft(o['yf'][k], L, n_fft, n_fft // 2, work_dtype=np.float64)
-        assert pc.relerr(out.numpy()[0, k], ref) < 1e-4
-    # iters = 1 must be the plain two-step path
-    out1, _ = eng.tango_enhance_iterated(y, m, iters=1)
-    out_ref, _, _ = eng.tango_enhance(y, m)
-    assert pc.relerr(out1.numpy(), out_ref.numpy()) < 1e-5
+    print(pc.check_iterated_outputs(make_engine, K, M, L, n_fft, iters))
 
 
 @pytest.mark.parametrize('scene', ['k2m2', 'k4m4'])
@@ -187,19 +172,7 @@ def test_tango_vs_reference_golden(make_engine, golden_dir, scene):
     The golden scenes are tiny and badly conditioned: the reference's complex64 arithmetic is itself only
     reproducible to ~1e-3 on them (tests/test_oracle_golden.py), so the bound here is 1e-2 and the tight
     bound is the oracle comparison above."""
-    g = np.load(os.path.join(golden_dir, f'tango_ref_{scene}.npz'))
-    K = int(g['K'])
-    y = np.stack([g[f'y{k}'] for k in range(K)])[None]
-    s = np.stack([g[f's{k}'] for k in range(K)])[None]
-    n = np.stack([g[f'n{k}'] for k in range(K)])[None]
-    R, K, M, L = y.shape
-    eng = make_engine(rooms=1, nodes=K, mics=M, length=L)
-    m = eng.mask_oracle(s[0, :, 0], n[0, :, 0]).reshape(1, K, eng.T, eng.F)
-    out, z, yf = eng.tango_enhance(y, m)
-    for k in range(K):
-        assert np.abs(m.numpy()[0, k].T - g[f'masks_z{k}']).max() < 1e-3
-        assert pc.relerr(z.numpy()[0, k].T, g[f'z_y{k}']) < 1e-2
-        assert pc.relerr(yf.numpy()[0, k].T, g[f'yf{k}']) < 1e-2
+    pc.check_reference_golden_scene(make_engine, golden_dir, scene)
 
 
 def test_full_size_properties(make_engine):
@@ -207,18 +180,4 @@ def test_full_size_properties(make_engine):
     -- apply(X, w) is linear in X; (ii) iSTFT(STFT(x)) == x; (iii) the MWF output is invariant to a common
     gain on the inputs (w^H y scales linearly, masks unchanged); (iv) batch independence: room r of a batch
     equals the same room processed alone."""
-    R, K, M, L = 6, 4, 4, 160000
-    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
-    eng = make_engine(rooms=R, nodes=K, mics=M, length=L)
-    T, F = eng.T, eng.F
-    m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F)
-    out, z, yf = eng.tango_enhance(y, m)
-    out2, z2, yf2 = eng.tango_enhance(2.0 * y, m)
-    assert pc.relerr(out2.numpy(), 2.0 * out.numpy()) < 1e-5            # (iii)
-    eng1 = make_engine(rooms=1, nodes=K, mics=M, length=L)
-    o1, _, _ = eng1.tango_enhance(y[3:4], m.numpy()[3:4])
-    assert np.array_equal(o1.numpy()[0], out.numpy()[3])                 # (iv) bit-identical
-    X = eng.stft(y.reshape(R * K, M, L))
-    xr = eng.istft(eng.stft(y[:, :, 0].reshape(R * K, 1, L)).reshape(R * K, T, F)).numpy()
-    assert np.abs(xr - y[:, :, 0].reshape(R * K, L)).max() < 1e-5 * np.abs(y).max() + 1e-6   # (ii)
-    assert np.all(np.isfinite(out.numpy()))
+    pc.check_size_independent_properties(make_engine, R=6, K=4, M=4, L=160000)

@@ -1,0 +1,73 @@
+"""The GPU parity cases of tests/test_gpu_parity.py at the SAME shapes (node / microphone counts, FFT sizes, iteration
+counts, golden scenes of the reference) but shorter signals (and 2 x 8 instead of 8 x 8 for the P > 8 kernels: the emulated float64 Jacobi solver is slow), on the hipemu build of the unmodified kernel sources: the
+branches a shape selects (templated mic counts, the P > 8 kernels, 1024-point FFT, fused vs staged step 2) are then
+checked on every CPU run, not only at round end on the MI355X.  Test tooling only -- see test_kernels_emulated.py."""
+import pytest
+
+import emu_build
+import parity_checks as pc
+from disco_amd import synth
+from disco_amd.engine import Engine
+
+
+@pytest.fixture(scope='module')
+def make_engine():
+    lib = emu_build.load_emu()
+
+    def mk(**cfg):
+        return Engine(lib=lib, **cfg)
+    return mk
+
+
+@pytest.mark.parametrize('R,K,M,same_z,mask_remote', [(2, 2, 2, True, True), (3, 3, 2, False, False), (2, 4, 4, True, True),
+                                                      (2, 2, 7, False, True)])
+def test_emu_cov_solve_apply_gpu_shapes(make_engine, R, K, M, same_z, mask_remote):
+    print(pc.check_cov_solve_apply(make_engine, R=R, K=K, M=M, L=3072, same_z=same_z, mask_remote=mask_remote))
+
+
+@pytest.mark.parametrize('R,K,M,L,n_fft', [(3, 4, 4, 24000, 512), (2, 2, 3, 30000, 512), (2, 1, 8, 20000, 512), (2, 2, 2, 25000, 1024)])
+def test_emu_stft_cov_fused_gpu_shapes(make_engine, R, K, M, L, n_fft):
+    print(pc.check_stft_cov_fused(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft))
+
+
+@pytest.mark.parametrize('R,K,M', [(3, 4, 4), (2, 3, 2), (1, 5, 4), (2, 8, 1), (2, 2, 7)])
+def test_emu_step2_fused_gpu_shapes(make_engine, R, K, M):
+    print(pc.check_step2_fused(make_engine, R=R, K=K, M=M, L=3072))
+
+
+@pytest.mark.parametrize('R,K,M', [(3, 4, 4), (1, 5, 3), (2, 3, 5)])
+def test_emu_step2_reuse_gpu_shapes(make_engine, R, K, M):
+    print(pc.check_step2_reuse(make_engine, R=R, K=K, M=M, L=3072))
+
+
+@pytest.mark.parametrize('K,M,world', [(4, 4, 2), (4, 2, 4), (6, 2, 3)])
+def test_emu_node_sharded_gpu_shapes(make_engine, K, M, world):
+    print(pc.check_node_sharded(make_engine, R=1, K=K, M=M, L=4096, world=world))
+
+
+@pytest.mark.parametrize('K,M,L,n_fft,staged', [(4, 4, 16384, 512, False), (4, 4, 16384, 512, True), (1, 4, 16384, 512, False),
+                                                (2, 3, 20000, 512, False), (2, 2, 20480, 1024, False), (3, 2, 12000, 512, True),
+                                                (2, 8, 16384, 1024, False)])
+def test_emu_tango_end_to_end_gpu_shapes(make_engine, K, M, L, n_fft, staged):
+    y, s, n = synth.make_rooms_numpy(1 if M > 4 else 2, K=K, M=M, L=L)      # M = 8, K = 2: the P = 9 > 8 kernels
+    print(pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, staged_step2=staged))
+
+
+@pytest.mark.parametrize('K,M,L,n_fft,iters', [(3, 2, 8192, 512, 2), (2, 8, 16384, 1024, 2), (2, 2, 8192, 512, 3)])
+def test_emu_iterated_gpu_shapes(make_engine, K, M, L, n_fft, iters):
+    pc.check_iterated_outputs(make_engine, K, M, L, n_fft, iters)
+
+
+@pytest.mark.parametrize('scene', ['k2m2', 'k4m4'])
+def test_emu_tango_vs_reference_golden(make_engine, golden_dir, scene):
+    """The kernel sources against outputs of the REFERENCE'S OWN offline_tango (tests/golden/tango_ref_*.npz)."""
+    pc.check_reference_golden_scene(make_engine, golden_dir, scene)
+
+
+def test_emu_size_independent_properties(make_engine):
+    pc.check_size_independent_properties(make_engine, R=3, K=4, M=4, L=12288)
+
+
+@pytest.mark.parametrize('R,K,M,L,n_fft,U', [(1, 4, 4, 1280, 512, 1), (2, 3, 2, 6144, 512, 4), (1, 2, 2, 8192, 1024, 2)])
+def test_emu_online_mwf_gpu_shapes(make_engine, R, K, M, L, n_fft, U):
+    print(pc.check_online_mwf(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft, update_every=U))
