@@ -71,3 +71,19 @@ def test_emu_size_independent_properties(make_engine):
 @pytest.mark.parametrize('R,K,M,L,n_fft,U', [(1, 4, 4, 1280, 512, 1), (2, 3, 2, 6144, 512, 4), (1, 2, 2, 8192, 1024, 2)])
 def test_emu_online_mwf_gpu_shapes(make_engine, R, K, M, L, n_fft, U):
     print(pc.check_online_mwf(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft, update_every=U))
+
+
+# ---- edge lengths (the reference pads with librosa's centre mode: one sample is a legal 'constant'-padded signal, reflect
+#      padding needs more than n_fft/2 samples and is refused at disco_create with an error string otherwise) ----------------
+@pytest.mark.parametrize('n_fft', [512, 1024])
+def test_emu_edge_lengths(make_engine, n_fft):
+    from disco_amd.engine import DiscoError
+    h = n_fft // 2
+    for L in (1, 2, 100, h - 1, h, h + 1, n_fft, n_fft + 1, 2 * n_fft + 17):
+        pc.check_stft(make_engine, n_sig=2, chans=2, L=L, n_fft=n_fft, pad_mode='constant')
+    for L in (h + 1, n_fft, n_fft + 1, 3 * h, 2 * n_fft + 17):
+        pc.check_stft(make_engine, n_sig=1, chans=3, L=L, n_fft=n_fft, pad_mode='reflect')
+        pc.check_istft(make_engine, n_sig=2, L=L, n_fft=n_fft)
+    for L in (1, h):
+        with pytest.raises(DiscoError, match='reflect padding needs length'):
+            make_engine(rooms=1, nodes=1, mics=1, length=L, n_fft=n_fft, pad_mode='reflect')
