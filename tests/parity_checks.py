@@ -618,3 +618,41 @@ def check_size_independent_properties(make_engine, R, K, M, L):
     xr = eng.istft(eng.stft(y[:, :, 0].reshape(R * K, 1, L)).reshape(R * K, T, F)).numpy()
     assert np.abs(xr - y[:, :, 0].reshape(R * K, L)).max() < 1e-5 * np.abs(y).max() + 1e-6   # (i)
     assert np.all(np.isfinite(out.numpy()))
+
+
+def check_node_sharded_torch_one_rank(make_engine, device, backend, K=3, M=2, L=8192, iters=2):
+    """tango_enhance_node_sharded_torch on a ONE-rank process group (the shard holds all K nodes; the all-gather is RCCL's /
+    gloo's own single-rank path) against disco_tango_enhance_iterated on the same device: same staged kernels, so the
+    outputs agree to rounding.  Exercises torch tensors as caller-owned z / yf buffers and disco_filter_head."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from disco_amd import synth
+    from disco_amd.node_sharded import tango_enhance_node_sharded_torch
+    R = 2
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    full = make_engine(rooms=R, nodes=K, mics=M, length=L)
+    mask = full.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, full.T, full.F).numpy()
+    own_group = not dist.is_initialized()
+    if own_group:
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group(backend, init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        errs = {}
+        for it in (1, iters):
+            out_ref, yf_ref = full.tango_enhance_iterated(y, mask, iters=it)
+            eng = make_engine(rooms=R, nodes=K, mics=M, length=L)
+            eng.set_node_shard(0, K)
+            yt = torch.from_numpy(y).to(device)
+            mt = torch.from_numpy(mask).to(device)
+            out, yf, z_all = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=it)
+            assert yf.device.type == torch.device(device).type and tuple(z_all.shape) == (R, K, eng.T, eng.F)
+            errs[it] = (relerr(yf.cpu().numpy(), yf_ref.numpy()), relerr(out.numpy(), out_ref.numpy()))
+            assert max(errs[it]) < 1e-5, errs
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    return errs

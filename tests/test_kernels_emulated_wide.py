@@ -87,3 +87,8 @@ def test_emu_edge_lengths(make_engine, n_fft):
     for L in (1, h):
         with pytest.raises(DiscoError, match='reflect padding needs length'):
             make_engine(rooms=1, nodes=1, mics=1, length=L, n_fft=n_fft, pad_mode='reflect')
+
+
+def test_emu_node_sharded_torch_one_rank(make_engine):
+    """Same check as the GPU suite's (one-rank group), here with CPU tensors over gloo on the emulated build."""
+    print(pc.check_node_sharded_torch_one_rank(make_engine, 'cpu', 'gloo', K=3, M=2, L=4096, iters=2))
