@@ -35,6 +35,9 @@ PROTOTYPES = {
     'disco_n_freq': (_int, [_vp]),
     'disco_workspace_bytes': (_sz, [_vp]),
     'disco_set_node_shard': (_int, [_vp, _int, _int]),
+    'disco_set_tuning': (_int, [_vp, _int, _int, _int, _int]),
+    'disco_stage_timing': (_int, [_vp, _int]),
+    'disco_stage_report': (_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int), _int]),
     'disco_dev_alloc': (_int, [_vp, _sz, C.POINTER(_vp)]),
     'disco_dev_free': (_int, [_vp, _vp]),
     'disco_h2d': (_int, [_vp, _vp, _vp, _sz, _vp]),

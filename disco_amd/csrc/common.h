@@ -54,6 +54,20 @@ __device__ __forceinline__ c64 zscale(c64 a, double s) { return make_double2(a.x
 #define DISCO_CONSUME(x) asm volatile("" : "+v"(x))
 #endif
 
+// Code-motion fence for long unrolled straight-line code: memory accesses are not moved across it by any stage of
+// hipcc (instruction selection linearises a basic block with every independent LDS load first -- all P^2/2 entries of a
+// triangular factor, 4 registers each -- and only a memory-clobbering statement pins loads behind it; the scheduler
+// barrier then keeps the arithmetic of one row from drifting into the next).  No instruction is emitted.
+#if defined(__clang__)
+#define DISCO_SCHED_FENCE()                       \
+    do {                                          \
+        asm volatile("" ::: "memory");            \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+#else
+#define DISCO_SCHED_FENCE() asm volatile("" ::: "memory")
+#endif
+
 // The wave index as a PROVABLY wave-uniform value: anything derived from threadIdx is divergent to hipcc, which
 // then wraps every access guarded by a per-wave condition in exec-mask branches (one per load).
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

@@ -40,6 +40,14 @@ struct disco_ctx {
     void* conv_ws;                   // its spectra workspace, lazy
     size_t conv_ws_bytes;
     int k0, Kl;                      // node shard: this context holds nodes [k0, k0 + Kl) of every room (default 0, K)
+    int tune_runw, tune_cov_chunks, tune_step2_chunks, tune_pairs;   // disco_set_tuning overrides (0 = batch-size heuristic)
+    // per-stage hipEvent timers of the whole-path entry points (disco_stage_timing / disco_stage_report)
+    struct StageRec {
+        char name[32];
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    };
+    bool stage_on;
+    std::vector<StageRec> stages;
     char err[512];
 };
 
@@ -68,7 +76,76 @@ static int check_launch(disco_ctx* ctx, const char* what) {
     return 0;
 }
 
-extern "C" const char* disco_version(void) { return "disco_hip 0.1.0 (gfx950)"; }
+// Every entry point runs on the context's own device, whatever the calling thread's current device is, and leaves the
+// caller's current device as it found it (two contexts on two GPUs in one process; a host such as torch switching devices).
+struct DevGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DevGuard(int device) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != device) {
+            ok = hipSetDevice(device) == hipSuccess;
+            prev = cur;
+        }
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+#define DISCO_ENTER(ctx)                                                                             \
+    if (!(ctx)) return DISCO_E_ARG;                                                                  \
+    DevGuard dev_guard_((ctx)->cfg.device);                                                          \
+    if (!dev_guard_.ok) return fail((ctx), DISCO_E_HIP_BASE, "hipSetDevice(cfg.device) failed")
+
+// ---- per-stage timers ---------------------------------------------------------------------------------------------------
+// STAGE(ctx, s, "name", call): when disco_stage_timing(ctx, 1) is in force, brackets `call` (one or more launches on stream
+// s) with two hipEvents recorded on that stream; otherwise just evaluates it.  Nothing is synchronised here.
+static void stage_clear(disco_ctx* ctx) {
+    for (auto& st : ctx->stages)
+        for (auto& e : st.evs) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    ctx->stages.clear();
+}
+struct StageScope {
+    disco_ctx* ctx;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char* name;
+    StageScope(disco_ctx* c, disco_stream s, const char* n) : ctx(c), st((hipStream_t)s), name(n) {
+        if (!ctx->stage_on) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            e0 = e1 = nullptr;
+            return;
+        }
+        (void)hipEventRecord(e0, st);
+    }
+    ~StageScope() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, st);
+        for (auto& r : ctx->stages)
+            if (!strncmp(r.name, name, sizeof(r.name))) {
+                r.evs.emplace_back(e0, e1);
+                return;
+            }
+        disco_ctx::StageRec r;
+        snprintf(r.name, sizeof(r.name), "%s", name);
+        r.evs.emplace_back(e0, e1);
+        ctx->stages.push_back(std::move(r));
+    }
+};
+#define STAGE(ctx, s, name, call) ([&]() { StageScope stage_scope_((ctx), (s), (name)); return (call); }())
+
+// (tests/hipemu compiles these sources with g++ for logic tests and defines HIPEMU: the string must not claim a GPU there)
+#ifdef HIPEMU
+extern "C" const char* disco_version(void) { return "disco_hip 0.2.0 (hipemu host TEST build, not a product)"; }
+#else
+extern "C" const char* disco_version(void) { return "disco_hip 0.2.0 (gfx950)"; }
+#endif
 
 extern "C" const char* disco_last_error(const disco_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
 
@@ -115,6 +192,8 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->pending_P = 0;
     ctx->k0 = 0;
     ctx->Kl = cfg->nodes;
+    ctx->tune_runw = ctx->tune_cov_chunks = ctx->tune_step2_chunks = ctx->tune_pairs = 0;
+    ctx->stage_on = false;
     ctx->scratch2 = nullptr;
     ctx->scratch2_bytes = 0;
     ctx->loc_chunks = 0;
@@ -133,7 +212,8 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
         tw[i].x = (float)std::cos(two_pi * i / N);
         tw[i].y = (float)(-std::sin(two_pi * i / N));
     }
-    hipError_t e = hipSetDevice(cfg->device);
+    DevGuard dev_guard_(cfg->device);                     // the caller's current device is restored on return
+    hipError_t e = dev_guard_.ok ? hipSuccess : hipErrorInvalidValue;
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_win, N * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tw, N * sizeof(c32));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_win, win.data(), N * sizeof(float), hipMemcpyHostToDevice);
@@ -149,6 +229,8 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
 
 extern "C" void disco_destroy(disco_ctx* ctx) {
     if (!ctx) return;
+    DevGuard dev_guard_(ctx->cfg.device);
+    stage_clear(ctx);
     if (ctx->d_win) (void)hipFree(ctx->d_win);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->own_ws) (void)hipFree(ctx->own_ws);
@@ -160,12 +242,55 @@ extern "C" void disco_destroy(disco_ctx* ctx) {
 }
 
 extern "C" int disco_set_node_shard(disco_ctx* ctx, int first_node, int node_count) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (first_node < 0 || node_count < 1 || first_node + node_count > ctx->cfg.nodes)
         return fail(ctx, DISCO_E_ARG, "disco_set_node_shard: shard outside [0, nodes)");
     ctx->k0 = first_node;
     ctx->Kl = node_count;
     ctx->pending_chunks = 0;
+    return 0;
+}
+
+extern "C" int disco_stage_timing(disco_ctx* ctx, int enable) {
+    DISCO_ENTER(ctx);
+    stage_clear(ctx);
+    ctx->stage_on = enable != 0;
+    return 0;
+}
+
+extern "C" int disco_stage_report(disco_ctx* ctx, char* names, float* total_ms, int* launches, int max_stages) {
+    DISCO_ENTER(ctx);
+    if (max_stages < 0 || (max_stages > 0 && (!names || !total_ms || !launches)))
+        return fail(ctx, DISCO_E_ARG, "disco_stage_report: bad argument");
+    int n = 0;
+    for (auto& st : ctx->stages) {
+        if (n >= max_stages) break;
+        float ms = 0.f;
+        for (auto& e : st.evs) {
+            float d = 0.f;
+            HIPCHK(ctx, hipEventSynchronize(e.second));
+            HIPCHK(ctx, hipEventElapsedTime(&d, e.first, e.second));
+            ms += d;
+        }
+        snprintf(names + 32 * n, 32, "%s", st.name);
+        total_ms[n] = ms;
+        launches[n] = (int)st.evs.size();
+        ++n;
+    }
+    return n;
+}
+
+extern "C" int disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, int step2_chunks, int istft_pairs) {
+    DISCO_ENTER(ctx);
+    if (stft_frames_per_wave < 0 || stft_frames_per_wave > 1024 || cov_chunks < 0 || step2_chunks < 0 || istft_pairs < 0 ||
+        istft_pairs == 1 || istft_pairs > 4096)
+        return fail(ctx, DISCO_E_ARG, "disco_set_tuning: need 0 <= stft_frames_per_wave <= 1024, chunks >= 0, istft_pairs 0 or 2..4096");
+    ctx->tune_runw = stft_frames_per_wave;
+    ctx->tune_cov_chunks = cov_chunks;
+    ctx->tune_step2_chunks = step2_chunks;
+    ctx->tune_pairs = istft_pairs;
+    ctx->pending_chunks = 0;           // partial sums of another geometry must not be re-used
+    ctx->loc_M = 0;
     return 0;
 }
 
@@ -180,7 +305,7 @@ extern "C" int disco_dev_alloc(disco_ctx* ctx, size_t bytes, void** dptr) {
     return 0;
 }
 extern "C" int disco_dev_free(disco_ctx* ctx, void* dptr) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     HIPCHK(ctx, hipFree(dptr));
     return 0;
 }
@@ -195,7 +320,7 @@ extern "C" int disco_d2h(disco_ctx* ctx, void* dst, const void* src, size_t byte
     return 0;
 }
 extern "C" int disco_sync(disco_ctx* ctx, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize((hipStream_t)s));
     return 0;
 }
@@ -222,7 +347,7 @@ static bool launch_stft(int chp, dim3 grid, hipStream_t st, const float* x, c32*
 }
 
 extern "C" int disco_stft(disco_ctx* ctx, const float* x, int64_t n_sig, int chans, disco_c32* X, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!x || !X || n_sig < 1 || chans < 1) return fail(ctx, DISCO_E_ARG, "disco_stft: bad argument");
     if (chans > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft: more than 8 channels per signal group");
     const int runs = stft_runs(ctx->T);
@@ -241,7 +366,7 @@ extern "C" int disco_stft(disco_ctx* ctx, const float* x, int64_t n_sig, int cha
 
 extern "C" int disco_mask_oracle(disco_ctx* ctx, const float* s_ref, const float* n_ref, int64_t n_sig, float* mask,
                                  disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!s_ref || !n_ref || !mask || n_sig < 1) return fail(ctx, DISCO_E_ARG, "disco_mask_oracle: bad argument");
     const disco_cfg& c = ctx->cfg;
     if (c.mask_type < DISCO_MASK_IRM || c.mask_type > DISCO_MASK_IAM)
@@ -252,6 +377,7 @@ extern "C" int disco_mask_oracle(disco_ctx* ctx, const float* s_ref, const float
         return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mask_oracle: batch too large for one launch");
     const float thr = powf(10.f, c.mask_bin_thr_db / 10.f);                 // math_utils.py db2lin (power)
     const dim3 grid((unsigned)stft_blocks(n_items));
+    StageScope stage_scope_(ctx, s, "mask_oracle");
     if (c.n_fft == 512)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_oracle<512>), grid, dim3(64 * STFT_WAVES), 0,
                            (hipStream_t)s, s_ref, n_ref, mask, ctx->d_win, ctx->d_tw, c.length, ctx->T, c.pad_mode,
@@ -265,7 +391,7 @@ extern "C" int disco_mask_oracle(disco_ctx* ctx, const float* s_ref, const float
 
 extern "C" int disco_tf_mask(disco_ctx* ctx, const disco_c32* S, const disco_c32* N, int64_t n_elem, int mask_type,
                              int mask_pow, float bin_thr_db, float* mask, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!S || !N || !mask || n_elem < 1 || mask_pow < 0) return fail(ctx, DISCO_E_ARG, "disco_tf_mask: bad argument");
     if (mask_type < DISCO_MASK_IRM || mask_type > DISCO_MASK_IAM) return fail(ctx, DISCO_E_ARG, "disco_tf_mask: unknown mask type");
     const unsigned grid = (unsigned)std::min<long long>((n_elem + 255) / 256, 8192);
@@ -275,7 +401,7 @@ extern "C" int disco_tf_mask(disco_ctx* ctx, const disco_c32* S, const disco_c32
 }
 
 extern "C" int disco_istft(disco_ctx* ctx, const disco_c32* Z, int64_t n_sig, float* out, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!Z || !out || n_sig < 1) return fail(ctx, DISCO_E_ARG, "disco_istft: bad argument");
     const disco_cfg& c = ctx->cfg;
     const int n_seg = (c.length + c.hop - 1) / c.hop;
@@ -309,6 +435,7 @@ static int cov_chunks(const disco_ctx* ctx) {
     const long long g = (long long)ctx->cfg.rooms * ctx->cfg.nodes;
     long long c = (2048 + g - 1) / g;
     if (c > 8) c = 8;
+    if (ctx->tune_cov_chunks > 0) c = ctx->tune_cov_chunks;
     if (c > ctx->T) c = ctx->T;
     if (c < 1) c = 1;
     return (int)c;
@@ -402,7 +529,7 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
 extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs,
                                 const disco_c32* Zn, int mask_remote, int P, disco_c32* Rss, disco_c32* Rnn,
                                 disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if ((Rss == nullptr) != (Rnn == nullptr)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Rss and Rnn must both be given or both be NULL");
     int chunks = 1;
     int rc = cov_partials(ctx, X, mask, Zs, Zn, mask_remote, P, &chunks, s);
@@ -437,7 +564,7 @@ static int solve_dispatch(disco_ctx* ctx, const SolveSrc& src, int64_t n_prob, i
 
 extern "C" int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const disco_c32* Rnn, int64_t n_prob, int P,
                                  float mu, disco_c32* w, disco_c32* t1, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!Rss || !Rnn || !w || n_prob < 1) return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1: bad argument");
     SolveSrc src;
     src.Rss = (const c32*)Rss;
@@ -453,7 +580,7 @@ extern "C" int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const dis
 }
 
 extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w, disco_c32* t1, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!w) return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1_pending: null argument");
     if (ctx->pending_chunks < 1 || !ctx->scratch)
         return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1_pending: no covariance call has left partial sums in this context");
@@ -472,7 +599,7 @@ extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w,
 
 extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, int P, int conj_w,
                            disco_c32* out, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, KR = P - M;
     if (!X || !w || !out) return fail(ctx, DISCO_E_ARG, "disco_apply: null argument");
@@ -514,7 +641,7 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
 }
 
 extern "C" int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const disco_c32* z, disco_c32* zn, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!X || !z || !zn) return fail(ctx, DISCO_E_ARG, "disco_noise_residual: null argument");
     const disco_cfg& c = ctx->cfg;
     const long long n = (long long)c.rooms * ctx->Kl * ctx->T * ctx->F;
@@ -563,26 +690,27 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
     const int M = c.mics;
     if (M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: more than 8 mics per node");
     if (c.n_fft == 1024 && M > 6) {        // staged form of the same two operations
-        int rc0 = disco_stft(ctx, y, (int64_t)c.rooms * c.nodes, M, X, s);
+        int rc0 = STAGE(ctx, s, "stft", disco_stft(ctx, y, (int64_t)c.rooms * c.nodes, M, X, s));
         if (rc0) return rc0;
-        return cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s);
+        return STAGE(ctx, s, "cov1", cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s));
     }
     const long long G = (long long)c.rooms * c.nodes;
     // frames per wave: as long as possible (<= 80) while leaving >= ~2048 workgroups for the chip
     const long long chunks_wanted = std::max<long long>(1, (2048 + G - 1) / G);
     int runw = (int)((ctx->T + STFT_WAVES * chunks_wanted - 1) / (STFT_WAVES * chunks_wanted));
     runw = std::min(80, std::max(8, runw));
+    if (ctx->tune_runw > 0) runw = ctx->tune_runw;
     const int chunks = (ctx->T + STFT_WAVES * runw - 1) / (STFT_WAVES * runw);
     const int NP = M * (M + 1) / 2;
     int rc = ensure_scratch(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
     if (rc) return rc;
     if (G * chunks > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: batch too large");
     const dim3 grid((unsigned)(G * chunks));
-    const bool ok = c.n_fft == 512
+    const bool ok = STAGE(ctx, s, "stft_cov1", c.n_fft == 512
         ? launch_stft_cov<512>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
                                ctx->T, c.pad_mode, chunks, runw)
         : launch_stft_cov<1024>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
-                                ctx->T, c.pad_mode, chunks, runw);
+                                ctx->T, c.pad_mode, chunks, runw));
     if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: unsupported mic count");
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
@@ -595,7 +723,7 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
 
 extern "C" int disco_stft_cov_fused(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, disco_c32* Rss,
                                     disco_c32* Rnn, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if ((Rss == nullptr) != (Rnn == nullptr)) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: Rss and Rnn must both be given or both be NULL");
     int chunks = 1;
     int rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s);
@@ -610,6 +738,7 @@ static int step2_chunks(const disco_ctx* ctx, int tiles_plus_1) {
     const long long base = (long long)ctx->cfg.rooms * tiles_plus_1;
     long long c = (4096 + base - 1) / base;
     if (c > 8) c = 8;
+    if (ctx->tune_step2_chunks > 0) c = ctx->tune_step2_chunks;
     if (c > ctx->T) c = ctx->T;
     if (c < 1) c = 1;
     return (int)c;
@@ -681,7 +810,7 @@ static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* m
 
 extern "C" int disco_step2_cov_fused_reuse(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
                                            disco_c32* z_out, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (ctx->loc_M != ctx->cfg.mics || ctx->cfg.nodes < 2 || ctx->Kl != ctx->cfg.nodes)
         return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused_reuse: no step-1 partial sums of disco_stft_cov_fused are held by this context");
     int chunks = 1;
@@ -689,7 +818,7 @@ extern "C" int disco_step2_cov_fused_reuse(disco_ctx* ctx, const disco_c32* X, c
 }
 extern "C" int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
                                      disco_c32* z_out, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if ((Rss == nullptr) != (Rnn == nullptr)) return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused: Rss and Rnn must both be given or both be NULL");
     int chunks = 1;
     int rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_out, &chunks, s);
@@ -699,7 +828,7 @@ extern "C" int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const f
 
 extern "C" int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc, const disco_c32* w_glo,
                                        disco_c32* z_out, disco_c32* yf, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!X || !w_loc || !w_glo || !yf) return fail(ctx, DISCO_E_ARG, "disco_step2_apply_fused: null argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
@@ -746,7 +875,7 @@ static bool launch_apply_istft(const Step2Args& a, float* out, const float* win,
 
 extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc,
                                              const disco_c32* w_glo, float* out, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!X || !w_loc || !w_glo || !out) return fail(ctx, DISCO_E_ARG, "disco_step2_apply_istft_fused: null argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
@@ -769,6 +898,7 @@ extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X,
     const long long bpr_wanted = std::max<long long>(1, (2048 + c.rooms - 1) / c.rooms);
     int pairs = (int)(((n_seg + bpr_wanted - 1) / bpr_wanted + 2) / 2);
     pairs = std::min(64, std::max(4, pairs));
+    if (ctx->tune_pairs > 0) pairs = ctx->tune_pairs;
     const int bpr = (n_seg + 2 * pairs - 2) / (2 * pairs - 1);
     const long long nblk = (long long)c.rooms * bpr;
     if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_step2_apply_istft_fused: batch too large");
@@ -848,7 +978,7 @@ static int acquire_ws(disco_ctx* ctx, void* workspace, size_t workspace_bytes, c
 
 extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
                                    disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: null argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: node shard active, drive the staged calls around an all-gather of z");
     const disco_cfg& c = ctx->cfg;
@@ -868,19 +998,19 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     // step 1 (tango.py:326-376): STFT + covariance in one pass, solve straight from the partial sums
     int chunks1 = 1;
     if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks1, s))) return rc;
-    if ((rc = solve_from_partials(ctx, chunks1, M, w, s))) return rc;
-    if ((rc = disco_apply(ctx, X, nullptr, w, M, 1, z, s))) return rc;
+    if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks1, M, w, s)))) return rc;
+    if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w, M, 1, z, s)))) return rc;
     if (c.nodes == 1 && mask_w == mask_z) {
         // single node, same mask: step 2 would rebuild the very same statistics from the very same inputs
         // (P = M, nothing to append), so w_glo == w_loc and yf == z_y bit for bit (config C2).
         if (yf) HIPCHK(ctx, hipMemcpyAsync(yf, z, (size_t)G * ctx->T * ctx->F * sizeof(c32), hipMemcpyDeviceToDevice, (hipStream_t)s));
-        return disco_istft(ctx, z, G, out, s);
+        return STAGE(ctx, s, "istft", disco_istft(ctx, z, G, out, s));
     }
     // exchange + step 2 (tango.py:378-450), mask_for_z = 'local'
-    if ((rc = disco_cov_masked(ctx, X, mask_w, z, z, 1, P2, nullptr, nullptr, s))) return rc;     // partial sums stay pending
-    if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w, nullptr, s))) return rc;
-    if ((rc = disco_apply(ctx, X, z, w, P2, 1, yo, s))) return rc;
-    return disco_istft(ctx, yo, G, out, s);
+    if ((rc = STAGE(ctx, s, "cov2", disco_cov_masked(ctx, X, mask_w, z, z, 1, P2, nullptr, nullptr, s)))) return rc;     // partial sums stay pending
+    if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w, nullptr, s)))) return rc;
+    if ((rc = STAGE(ctx, s, "apply2", disco_apply(ctx, X, z, w, P2, 1, yo, s)))) return rc;
+    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
 }
 
 // The same path with step 2 on the in-register z exchange (default whenever all nodes of a room share the GPU).
@@ -896,21 +1026,21 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
     int rc;
     int chunks = 1;
     if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
-    if ((rc = solve_from_partials(ctx, chunks, M, w_loc, s))) return rc;
+    if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks, M, w_loc, s)))) return rc;
     // same mask array in both steps (oracle masks; a DNN mask re-used, tango.py:388-389): the leading M x M block of the
     // step-2 covariances IS the step-1 covariance still held as partial sums -> not recomputed
     if (mask_w == mask_z && ctx->loc_M == M && c.nodes > 1)
-        rc = disco_step2_cov_fused_reuse(ctx, X, mask_w, w_loc, z_y, s);
+        rc = STAGE(ctx, s, "step2_cov", disco_step2_cov_fused_reuse(ctx, X, mask_w, w_loc, z_y, s));
     else
-        rc = step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s);
+        rc = STAGE(ctx, s, "step2_cov", step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s));
     if (rc) return rc;
-    if ((rc = solve_from_partials(ctx, chunks, P2, w_glo, s))) return rc;
+    if ((rc = STAGE(ctx, s, "solve2", solve_from_partials(ctx, chunks, P2, w_glo, s)))) return rc;
     if (!yf && c.n_fft == 512) {           // yf not asked for: filter + iSTFT in one pass, yf stays on chip
-        rc = disco_step2_apply_istft_fused(ctx, X, w_loc, w_glo, out, s);
+        rc = STAGE(ctx, s, "step2_apply_istft", disco_step2_apply_istft_fused(ctx, X, w_loc, w_glo, out, s));
         if (rc != DISCO_E_UNSUPPORTED) return rc;
     }
-    if ((rc = disco_step2_apply_fused(ctx, X, w_loc, w_glo, nullptr, yo, s))) return rc;
-    return disco_istft(ctx, yo, G, out, s);
+    if ((rc = STAGE(ctx, s, "step2_apply", disco_step2_apply_fused(ctx, X, w_loc, w_glo, nullptr, yo, s)))) return rc;
+    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
 }
 
 // ---- online / adaptive mode ------------------------------------------------------------------------------
@@ -918,7 +1048,7 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
 extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const float* mask, int P,
                                 float lambda_cor, float mu, int update_every, float init_diag, disco_c32* out,
                                 disco_c32* w_last, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     const disco_cfg& c = ctx->cfg;
     if (!X || !mask || !out) return fail(ctx, DISCO_E_ARG, "disco_online_mwf: null argument");
     if (P != c.mics && P != c.mics + c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_online_mwf: P must be mics or mics + nodes - 1");
@@ -959,7 +1089,7 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
 extern "C" int disco_tango_online(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float lambda_cor,
                                   int update_every, float init_diag, float* out, disco_c32* z_y, disco_c32* yf,
                                   void* workspace, size_t workspace_bytes, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_online: null argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_online: node shard active, drive disco_online_mwf around an all-gather of z");
     const disco_cfg& c = ctx->cfg;
@@ -971,21 +1101,21 @@ extern "C" int disco_tango_online(disco_ctx* ctx, const float* y, const float* m
     disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
     disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
     const int64_t G = (int64_t)c.rooms * c.nodes;
-    if ((rc = disco_stft(ctx, y, G, c.mics, X, s))) return rc;
-    if ((rc = disco_online_mwf(ctx, X, nullptr, mask_z, c.mics, lambda_cor, c.mu, update_every, init_diag, z, nullptr, s))) return rc;
+    if ((rc = STAGE(ctx, s, "stft", disco_stft(ctx, y, G, c.mics, X, s)))) return rc;
+    if ((rc = STAGE(ctx, s, "online1", disco_online_mwf(ctx, X, nullptr, mask_z, c.mics, lambda_cor, c.mu, update_every, init_diag, z, nullptr, s)))) return rc;
     if (c.nodes == 1 && mask_w == mask_z) {             // nothing to append: step 2 would repeat step 1
         if (yf) HIPCHK(ctx, hipMemcpyAsync(yf, z, (size_t)G * ctx->T * ctx->F * sizeof(c32), hipMemcpyDeviceToDevice, (hipStream_t)s));
         return disco_istft(ctx, z, G, out, s);
     }
-    if ((rc = disco_online_mwf(ctx, X, z, mask_w, c.mics + c.nodes - 1, lambda_cor, c.mu, update_every, init_diag, yo, nullptr, s))) return rc;
-    return disco_istft(ctx, yo, G, out, s);
+    if ((rc = STAGE(ctx, s, "online2", disco_online_mwf(ctx, X, z, mask_w, c.mics + c.nodes - 1, lambda_cor, c.mu, update_every, init_diag, yo, nullptr, s)))) return rc;
+    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
 }
 
 // ---- evaluation metrics ----------------------------------------------------------------------------------
 
 extern "C" int disco_pair_stats(disco_ctx* ctx, const float* a, const float* b, int64_t n_sig, int64_t len, int start, int stop,
                                 double* stats, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!a || !b || !stats || n_sig < 1 || len < 1) return fail(ctx, DISCO_E_ARG, "disco_pair_stats: bad argument");
     if (start < 0 || stop > len || stop < start) return fail(ctx, DISCO_E_ARG, "disco_pair_stats: need 0 <= start <= stop <= len");
     if (n_sig > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_pair_stats: batch too large");
@@ -995,7 +1125,7 @@ extern "C" int disco_pair_stats(disco_ctx* ctx, const float* a, const float* b, 
 
 extern "C" int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, int64_t len, int start, int stop,
                                 const double* b, const double* a, int n_bands, double* stats, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!x || !b || !a || !stats || n_sig < 1 || len < 1) return fail(ctx, DISCO_E_ARG, "disco_band_stats: bad argument");
     if (start < 0 || stop > len || stop < start) return fail(ctx, DISCO_E_ARG, "disco_band_stats: need 0 <= start <= stop <= len");
     if (n_bands < 1 || n_bands > METRIC_THREADS) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_band_stats: 1 <= n_bands <= 256");
@@ -1010,7 +1140,7 @@ extern "C" int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, i
 // ---- 'ivad' mask (tango.py:217-221 + sigproc_utils.py:12-55) ---------------------------------------------------------------
 
 extern "C" int disco_mask_ivad(disco_ctx* ctx, const float* s_ref, int64_t n_sig, float* mask, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!s_ref || !mask || n_sig < 1) return fail(ctx, DISCO_E_ARG, "disco_mask_ivad: bad argument");
     const disco_cfg& c = ctx->cfg;
     if ((c.length + c.hop - 1) / c.hop > VAD_MAX_SEG) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mask_ivad: signal longer than 4096 hops");
@@ -1024,7 +1154,7 @@ extern "C" int disco_mask_ivad(disco_ctx* ctx, const float* s_ref, int64_t n_sig
 
 extern "C" int disco_rir_convolve(disco_ctx* ctx, const float* dry, const float* rir, int64_t n_sig, int n_ch, int dry_len,
                                   int rir_len, float* out, int out_len, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!dry || !rir || !out || n_sig < 1 || n_ch < 1 || dry_len < 1 || rir_len < 1 || out_len < 1)
         return fail(ctx, DISCO_E_ARG, "disco_rir_convolve: bad argument");
     const int P = (rir_len + CV_B - 1) / CV_B;
@@ -1077,7 +1207,7 @@ extern "C" int disco_rir_convolve(disco_ctx* ctx, const float* dry, const float*
 extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, int iters,
                                             float* out, disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes,
                                             disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!y || !mask_z || !mask_w || !out || iters < 1) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance_iterated: bad argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance_iterated: node shard active");
     const disco_cfg& c = ctx->cfg;
@@ -1094,11 +1224,11 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     const int M = c.mics, P2 = c.mics + c.nodes - 1;
     int chunks = 1;
     if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
-    if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s))) return rc;
-    if ((rc = disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s))) return rc;
+    if ((rc = STAGE(ctx, s, "solve1", disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s)))) return rc;
+    if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
     for (int it = 0; it < iters; ++it) {
-        if ((rc = disco_cov_masked(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, nullptr, nullptr, s))) return rc;
-        if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s))) return rc;
+        if ((rc = STAGE(ctx, s, "cov2", disco_cov_masked(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, nullptr, nullptr, s)))) return rc;
+        if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s)))) return rc;
         if (it + 1 < iters) {
             const long long nb = (long long)G * ctx->F;
             hipLaunchKernelGGL(k_filter_head, dim3((unsigned)std::min<long long>((nb * M + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)s,
@@ -1106,17 +1236,17 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
             if ((rc = check_launch(ctx, "k_filter_head"))) return rc;
             // yf of this iteration is not needed; the next one needs the re-compressed z (computed from the OLD z's filter
             // only through w_glo's local part, so z can be overwritten in place)
-            if ((rc = disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s))) return rc;
+            if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
         }
     }
-    if ((rc = disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s))) return rc;
-    return disco_istft(ctx, yo, G, out, s);
+    if ((rc = STAGE(ctx, s, "apply2", disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s)))) return rc;
+    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
 }
 
 // Local part of a P-entry filter (the iterated scheme's re-compression filter); honours the node shard, so the node-sharded
 // driver can run the DANSE-style iterations with one all-gather of z per iteration.
 extern "C" int disco_filter_head(disco_ctx* ctx, const disco_c32* w_glo, int P, disco_c32* w_loc, disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     const disco_cfg& c = ctx->cfg;
     if (!w_glo || !w_loc) return fail(ctx, DISCO_E_ARG, "disco_filter_head: null argument");
     if (P < c.mics) return fail(ctx, DISCO_E_ARG, "disco_filter_head: P < M");
@@ -1131,7 +1261,7 @@ extern "C" int disco_filter_head(disco_ctx* ctx, const disco_c32* w_glo, int P, 
 extern "C" int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorption, const float* src, const float* mic,
                              int64_t n_room, int n_src, int n_mic, int max_order, float fs, float c_sound, float* rir, int rir_len,
                              disco_stream s) {
-    if (!ctx) return DISCO_E_ARG;
+    DISCO_ENTER(ctx);
     if (!room_dims || !absorption || !src || !mic || !rir || n_room < 1 || n_src < 1 || n_mic < 1 || max_order < 0 || !(fs > 0.f) ||
         !(c_sound > 0.f) || rir_len < 1)
         return fail(ctx, DISCO_E_ARG, "disco_ism_rir: bad argument");

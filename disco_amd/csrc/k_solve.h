@@ -10,9 +10,8 @@
 //
 // Mapping: a group of G = 4 / 8 / 16 lanes owns one problem, lane j owns column j.  Everything is float64:
 // cooperative Cholesky through LDS, two forward substitutions (column j of L^-1 Rxx, then column j of C),
-// then a ONE-SIDED (Hestenes) Jacobi on the columns of C with a round-robin tournament: each round every lane
-// fetches its partner's column with shuffles, both compute the same plane rotation, each updates its own
-// column.  On convergence the columns are d_j v_j; the longest one gives (d0, v0).
+// then the DOMINANT eigenpair only (rank = 1 needs nothing else) by repeated squaring of C / tr C, which converges
+// to v0 v0^H; d0 is the Rayleigh quotient q^H Rxx q of the back-substituted q = L^-H v0.
 #pragma once
 #include "common.h"
 #include "k_cov.h"
@@ -22,18 +21,31 @@ namespace disco {
 #ifndef DISCO_SOLVE_PACKED
 #define DISCO_SOLVE_PACKED 1
 #endif
-// a sweep whose every pair was orthogonal to sqrt(DISCO_JACOBI_DONE) before being rotated ends the iteration
-#ifndef DISCO_JACOBI_DONE
-#define DISCO_JACOBI_DONE 1e-14
+// squaring stops one step after 1 - tr(B^2) fell below this (the next square is then rank one to float64 rounding)
+#ifndef DISCO_SQUARING_DONE
+#define DISCO_SQUARING_DONE 1e-8
 #endif
+#ifndef DISCO_SQUARINGS_MAX
+#define DISCO_SQUARINGS_MAX 40
+#endif
+// A group of G <= 16 lanes never spans waves, so its LDS hand-offs need no s_barrier: a wave's DS instructions execute
+// in issue order; what has to be prevented is the compiler moving a read above the write it depends on through another
+// lane, and a read issuing before the wave's own writes were accepted (same fence as fft.h).
+// The compiler-level memory clobber makes hipcc re-load LDS values after the fence instead of carrying them in registers
+// from one phase to the next (it would keep the whole of L, P(P-1)/2 complex doubles, live between the two substitutions).
+#define DISCO_GROUP_SYNC()                    \
+    do {                                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   \
+        __builtin_amdgcn_wave_barrier();      \
+        asm volatile("" ::: "memory");        \
+    } while (0)
 
 constexpr double SOLVE_EPS = 2.220446049250313e-16;     // internal_formulas.py:6  sys.float_info.epsilon
 constexpr double SOLVE_ETA = 1e6;                       // internal_formulas.py:7
 
 // 1/sqrt(x) and 1/x in float64 from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~26 good bits) plus two Newton steps:
-// ~9 / ~5 instructions instead of the ~50 / ~25 of the IEEE-exact sqrt / divide expansions, 1-2 ulp.  The Jacobi
-// rotations only need cs^2 + sn^2 = 1 and |phase| = 1 to rounding, which these deliver; the inputs are O(1)
-// covariance entries, far from the denormal / overflow corners the exact expansions exist for.
+// ~9 / ~5 instructions instead of the ~50 / ~25 of the IEEE-exact sqrt / divide expansions, 1-2 ulp; the inputs are
+// O(1) covariance entries, far from the denormal / overflow corners the exact expansions exist for.
 __device__ __forceinline__ double rsqrt64(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = y * (1.5 - 0.5 * x * y * y);
@@ -52,6 +64,9 @@ struct SolveGeom {
     static constexpr int G = P <= 4 ? 4 : (P <= 8 ? 8 : 16);
     static constexpr int THREADS = P <= 8 ? 128 : 64;           // keeps the two LDS matrices under 64 KiB
     static constexpr int PROBS = THREADS / G;
+    // waves per SIMD the register allocation must leave room for (the LDS footprint of P > 8 would otherwise let hipcc
+    // spread over all 512 registers, AGPR copies and scratch included)
+    static constexpr int WPE = P <= 4 ? 6 : (P <= 7 ? 4 : (P == 8 ? 3 : 2));
     // LDS words (c64) per problem: L as a packed lower triangle (only that half is ever read), Y as a full matrix with a
     // padded row.  Packing L takes P = 7 from 1792 to 1344 bytes per problem -- the kernel's occupancy is LDS-bound.
     static constexpr int YW = (P % 8 == 0) ? P + 1 : P;     // row pitch of Y: padded only where P * 16 B would alias LDS banks
@@ -114,21 +129,21 @@ __device__ __forceinline__ void solve_load_row(const SolveSrc& src, long long pi
 
 // The solve proper for the group of G lanes that owns one pencil: lane j (< P) passes row j of Rxx (rowA) and of Rnn
 // (rowB); Lm / Ym are the group's two LDS matrices.  Returns this lane's component of t1 and the scalar gain
-// d0 / (d0 + mu)  (w_j = t1_j * gain).  Contains block-level barriers: every thread of the block must call it, the same
-// number of times.  REENTER: a barrier first, so that a previous call's readers of Lm / Ym are done (callers in a loop).
+// d0 / (d0 + mu)  (w_j = t1_j * gain).  Contains wave-level fences and wave-wide votes: every lane of a wave must call it,
+// the same number of times.  REENTER: a fence first, so that a previous call's readers of Lm / Ym are done (callers in a loop).
 template <int P, bool REENTER>
 __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* rowB, c64* Lm, c64 (*Ym)[SolveGeom<P>::YW],
                                                  const int j, const double mu, c64& t1_j, double& gain_out) {
     constexpr int G = SolveGeom<P>::G;
     using SG = SolveGeom<P>;
-    if constexpr (REENTER) __syncthreads();
+    if constexpr (REENTER) DISCO_GROUP_SYNC();
     if (j < P) {
 #pragma unroll
         for (int c = 0; c < P; ++c) {
             if (c <= j) Lm[SG::lt(j, c)] = make_double2((double)rowB[c].x, (double)rowB[c].y);     // lower triangle only
         }
     }
-    __syncthreads();
+    DISCO_GROUP_SYNC();
 
     // ---- Cholesky, one column per step; every lane keeps the (real) diagonal in registers.
     // Breakdown: the covariances arrive as float32, so a pivot below ~1e-7 of its diagonal entry is rounding noise (a
@@ -136,9 +151,14 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     // returns finite numbers there (huge generalized eigenvalues, clamped to 1e6 by internal_formulas.py:59-60); here the
     // pivot is floored and the column below it zeroed, which bounds every later quantity instead of amplifying noise by
     // 1/sqrt(pivot) per breakdown.  Well-conditioned pencils never take this branch.
-    double dd[P], rdd[P];
+    // The diagonal slot of column c (Rnn[c][c], dead once step c has read it) then parks (1 / L[c][c], L[c][c]) for the
+    // substitutions below and at the very end: no per-column array stays in registers.  It is written one step late, by
+    // lane 0, after the fence that ends the step in which every lane read the old content.
+    double rd_prev = 0.0, d_prev = 0.0;
 #pragma unroll
     for (int c = 0; c < P; ++c) {
+        DISCO_SCHED_FENCE();
+        if (c > 0 && j == 0) Lm[SG::lt(c - 1, c - 1)] = make_double2(rd_prev, d_prev);
         const double a_cc = Lm[SG::lt(c, c)].x;
         double d2 = a_cc;
 #pragma unroll
@@ -147,106 +167,117 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         const bool brk = !(d2 >= fl);                   // also true for NaN
         const double d2c = brk ? fl : d2;
         const double rd = rsqrt64(d2c);                 // 1 / L[c][c]
-        dd[c] = d2c * rd;                               //     L[c][c]
-        rdd[c] = rd;
+        rd_prev = rd;
+        d_prev = d2c * rd;                              //     L[c][c]
         if (j > c && j < P) {
             c64 s = Lm[SG::lt(j, c)];
 #pragma unroll
             for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lm[SG::lt(j, k)], Lm[SG::lt(c, k)]));
             Lm[SG::lt(j, c)] = brk ? make_double2(0.0, 0.0) : zscale(s, rd);
         }
-        __syncthreads();
+        DISCO_GROUP_SYNC();
     }
+    if (j == 0) Lm[SG::lt(P - 1, P - 1)] = make_double2(rd_prev, d_prev);
+    DISCO_GROUP_SYNC();
 
     // ---- column j of Y = L^-1 Rxx   (Rxx[i][j] = conj(Rxx[j][i]): read row j, contiguous)
     c64 y[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
+        DISCO_SCHED_FENCE();                            // one row of L at a time (see the squaring loop)
         c64 a = make_double2((double)rowA[i].x, -(double)rowA[i].y);
 #pragma unroll
         for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], y[k]));
-        y[i] = zscale(a, rdd[i]);
+        y[i] = zscale(a, Lm[SG::lt(i, i)].x);
+        // y is only stored under `j < P` below: without a use here hipcc sinks the whole substitution into that branch
+        // while its LDS loads stay outside, i.e. all of L is loaded (and spilled) first
+        DISCO_CONSUME(y[i].x);
+        DISCO_CONSUME(y[i].y);
     }
     if (j < P) {
 #pragma unroll
         for (int i = 0; i < P; ++i) Ym[i][j] = y[i];
     }
-    __syncthreads();
+    DISCO_GROUP_SYNC();
 
     // ---- column j of C = L^-1 Y^H  (C Hermitian): rhs = conj(row j of Y)
     c64 g[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
+        DISCO_SCHED_FENCE();
         c64 a = make_double2(0.0, 0.0);
         if (j < P) a = make_double2(Ym[j][i].x, -Ym[j][i].y);
 #pragma unroll
         for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], g[k]));
-        g[i] = zscale(a, rdd[i]);
+        g[i] = zscale(a, Lm[SG::lt(i, i)].x);
+        DISCO_CONSUME(g[i].x);                          // as above: lanes >= P carry zero columns, a branch hipcc would sink into
+        DISCO_CONSUME(g[i].y);
     }
 
-    // ---- one-sided Jacobi, round-robin over G players (lanes >= P carry zero columns)
-    // Convergence is quadratic: once every pair of a sweep was already orthogonal to 1e-7 (g2 <= 1e-14 alpha beta) before
-    // being rotated, the sweep leaves it at ~1e-14 and a further (verification) sweep would rotate nothing that matters.
-    for (int sweep = 0; sweep < 40; ++sweep) {
-        int rotated = 0;
-        for (int rd = 0; rd < G - 1; ++rd) {
-            int pj;
-            if (j == G - 1) pj = rd;
-            else if (j == rd) pj = G - 1;
-            else {
-                pj = 2 * rd - j;
-                pj = pj < 0 ? pj + (G - 1) : (pj >= G - 1 ? pj - (G - 1) : pj);
-            }
-            c64 o[P];
+    asm volatile("" ::: "memory");                           // L is not needed again before the back substitution
+
+    // ---- dominant eigenpair of C by repeated squaring.  rank = 1 keeps only (d0, v0) (internal_formulas.py:63-69), so
+    // the full diagonalisation a Jacobi solver performs (what this kernel did before: 5-7 sweeps of P(P-1)/2 rotations)
+    // is not needed: with B_0 = C / tr C,  B_{k+1} = B_k^2 / tr(B_k^2)  converges to v0 v0^H and the sub-dominant
+    // directions decay like (d1/d0)^(2^k) -- 6-8 squarings for the ratios 0.5-0.9 met on real covariances, P^2 complex
+    // multiply-adds per lane each (a Jacobi SWEEP costs ~5 P^2).  tau_k = tr(B_k^2) = ||B_k||_F^2 <= 1 doubles as the
+    // normaliser and the convergence measure: 1 - tau ~ 2 (d1/d0)^(2^k), so once it is below 1e-8 the NEXT square is
+    // rank one to rounding.  Lane j owns column j; the columns meet through the group's LDS matrix Ym (wave-level
+    // fences only: a group never spans waves).  An exactly repeated top eigenvalue never converges (tau -> 1/m) and
+    // stops at the iteration cap with a vector of the dominant subspace, which is all any solver can return there.
+    bool done;
+    {
+        double trl = 0.0;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                o[i].x = __shfl(g[i].x, pj, G);
-                o[i].y = __shfl(g[i].y, pj, G);
-            }
-            const bool lo = j < pj;                       // own column plays "p" (first), partner's plays "q"
-            // |own|^2, |other|^2 and own^H other, then ordered as (alpha, beta, gamma) = (|gp|^2, |gq|^2, gp^H gq):
-            // four selects on scalars instead of 2P selects on the columns
-            double n_own = 0.0, n_oth = 0.0, cr = 0.0, ci = 0.0;
+        for (int i = 0; i < P; ++i)
+            if (i == j) trl = g[i].x;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                n_own += g[i].x * g[i].x + g[i].y * g[i].y;
-                n_oth += o[i].x * o[i].x + o[i].y * o[i].y;
-                cr += g[i].x * o[i].x + g[i].y * o[i].y;
-                ci += g[i].x * o[i].y - g[i].y * o[i].x;
-            }
-            const double alpha = lo ? n_own : n_oth, beta = lo ? n_oth : n_own;
-            const double gr = cr, gi = lo ? ci : -ci;     // gq^H gp = conj(gp^H gq)
-            const double g2 = gr * gr + gi * gi;
-            if (g2 > 1e-28 * alpha * beta && g2 > 0.0) {
-                if (g2 > DISCO_JACOBI_DONE * alpha * beta) rotated = 1;
-                const double rg = rsqrt64(g2);                                  // 1 / |gamma|
-                const double zeta = 0.5 * (beta - alpha) * rg;
-                const double hz = 1.0 + zeta * zeta;
-                double t = rcp64(fabs(zeta) + hz * rsqrt64(hz));
-                t = zeta >= 0.0 ? t : -t;
-                const double cs = rsqrt64(1.0 + t * t), sn = cs * t;
-                const c64 ph = make_double2(gr * rg, gi * rg);                  // e^{i phi}
-                // gp' = cs gp - sn e^{-i phi} gq ;  gq' = sn e^{i phi} gp + cs gq
+        for (int off = G / 2; off >= 1; off >>= 1) trl += __shfl_xor(trl, off, G);
+        const bool ok = trl > 0.0 && trl < 1.7e308;            // false for NaN / inf / the zero matrix (Rxx = 0)
+        const double rt = ok ? rcp64(trl) : 0.0;
 #pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    if (lo) {
-                        const c64 r = zmulc(o[i], ph);                // e^{-i phi} gq
-                        g[i] = make_double2(cs * g[i].x - sn * r.x, cs * g[i].y - sn * r.y);
-                    } else {
-                        const c64 r = zmul(o[i], ph);                 // e^{i phi} gp
-                        g[i] = make_double2(sn * r.x + cs * g[i].x, sn * r.y + cs * g[i].y);
-                    }
-                }
-            }
+        for (int i = 0; i < P; ++i) g[i] = ok ? zscale(g[i], rt) : make_double2(0.0, 0.0);
+        done = !ok;
+    }
+    for (int it = 0; it < DISCO_SQUARINGS_MAX; ++it) {
+        DISCO_GROUP_SYNC();                                    // previous readers of Ym (Y above / the last square) are done
+        if (j < P) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) Ym[i][j] = g[i];
         }
-        if (!__any(rotated)) break;
+        DISCO_GROUP_SYNC();
+        c64 nn[P];
+        double tl = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            // one row of B at a time: without the fences hipcc hoists all P^2 LDS loads (4 registers each) above the
+            // first multiply and the kernel drops to one wave per SIMD with spills at P = 15
+            DISCO_SCHED_FENCE();
+            c64 a = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const c64 b = Ym[i][k];
+                a.x = fma(b.x, g[k].x, fma(-b.y, g[k].y, a.x));
+                a.y = fma(b.x, g[k].y, fma(b.y, g[k].x, a.y));
+            }
+            nn[i] = a;
+            if (i == j) tl = a.x;
+        }
+        DISCO_SCHED_FENCE();
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) tl += __shfl_xor(tl, off, G);
+        const double rtau = tl > 0.0 ? rcp64(tl) : 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) g[i] = zscale(nn[i], rtau);
+        done = done || (1.0 - tl < DISCO_SQUARING_DONE);
+        if (!__any(!done)) break;                              // wave-uniform exit: finished groups keep squaring a projector
     }
 
     // L is read again by the back substitution below: make the compiler re-load it from LDS there instead of carrying
-    // the whole strict lower triangle (P(P-1)/2 complex doubles, 84 VGPRs at P = 7) in registers across the Jacobi loop
+    // the whole strict lower triangle (P(P-1)/2 complex doubles, 84 VGPRs at P = 7) in registers across the squaring loop
     asm volatile("" ::: "memory");
 
-    // ---- longest column = d0 v0 ; arg-max over the group (ties: lowest lane)
+    // ---- B = v0 v0^H: every non-zero column is a multiple of v0; take the longest (|v0[j]| largest; ties: lowest lane)
     double nrm = 0.0;
 #pragma unroll
     for (int i = 0; i < P; ++i) nrm += g[i].x * g[i].x + g[i].y * g[i].y;
@@ -262,27 +293,44 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         }
     }
     c64 v0[P];
-    const double rb = best > 0.0 ? rsqrt64(best) : 0.0;
-    const double d0 = best * rb;
+    const bool have = best > 0.0;                          // false: C = 0 or not finite -> v0 = e0 (d0 is clamped below)
+    const double rb = have ? rsqrt64(best) : 0.0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         v0[i].x = __shfl(g[i].x, bj, G);
         v0[i].y = __shfl(g[i].y, bj, G);
-        if (d0 > 0.0) v0[i] = zscale(v0[i], rb);
+        if (have) v0[i] = zscale(v0[i], rb);
         else v0[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
     }
 
-    // ---- q = L^-H v0 (back substitution), then scale
+    // ---- q = L^-H v0 (back substitution); the diagonal slots hold (1 / L[i][i], L[i][i])
     c64 q[P];
 #pragma unroll
     for (int i = P - 1; i >= 0; --i) {
+        DISCO_SCHED_FENCE();
         c64 a = v0[i];
 #pragma unroll
         for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Lm[SG::lt(k, i)].x, -Lm[SG::lt(k, i)].y), q[k]));
-        q[i] = zscale(a, rdd[i]);
+        q[i] = zscale(a, Lm[SG::lt(i, i)].x);
+    }
+    const double l00 = Lm[SG::lt(0, 0)].y;
+    // ---- d0 = v0^H C v0 = q^H Rxx q  (q^H Rnn q = |v0|^2 = 1): lane j forms (Rxx q)_j from its row of Rxx
+    double d0;
+    {
+        c64 sj = make_double2(0.0, 0.0), qj = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            sj.x = fma((double)rowA[c].x, q[c].x, fma(-(double)rowA[c].y, q[c].y, sj.x));
+            sj.y = fma((double)rowA[c].x, q[c].y, fma((double)rowA[c].y, q[c].x, sj.y));
+            if (c == j) qj = q[c];
+        }
+        double e = j < P ? qj.x * sj.x + qj.y * sj.y : 0.0;      // Re(conj(q_j) (Rxx q)_j)
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) e += __shfl_xor(e, off, G);
+        d0 = have ? e : 0.0;
     }
     const double dcl = fmin(fmax(d0, SOLVE_EPS), SOLVE_ETA);
-    const c64 gsc = make_double2(dd[0] * v0[0].x, -dd[0] * v0[0].y);     // L[0,0] conj(v0[0]) = (Q^-1)[0,0]
+    const c64 gsc = make_double2(l00 * v0[0].x, -l00 * v0[0].y);     // L[0,0] conj(v0[0]) = (Q^-1)[0,0]
     const double gain = dcl / (dcl + mu);
     t1_j = make_double2(0.0, 0.0);
 #pragma unroll
@@ -293,7 +341,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
 }
 
 template <int P, bool FROM_PART>
-__global__ __launch_bounds__(SolveGeom<P>::THREADS) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
+__global__ __launch_bounds__(SolveGeom<P>::THREADS, SolveGeom<P>::WPE) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
                                                                         c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
     __shared__ c64 s_L[PROBS][SolveGeom<P>::LSZ];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]

@@ -81,6 +81,8 @@ class Engine:
         self.T = self.lib.disco_n_frames(self.ctx)
         self.F = self.lib.disco_n_freq(self.ctx)
         self.stream = None
+        # the hipemu TEST build (tests/emu_build.py) keeps "device" memory on the host: CPU torch tensors are legitimate there
+        self._host_pointers_ok = b'gfx950' not in self.lib.disco_version()
 
     # ---- plumbing
     def _chk(self, rc):
@@ -198,6 +200,24 @@ class Engine:
         self._chk(self.lib.disco_set_node_shard(self.ctx, first_node, node_count))
         self.k0, self.Kl = first_node, node_count
 
+    def set_tuning(self, stft_frames_per_wave=0, cov_chunks=0, step2_chunks=0, istft_pairs=0):
+        """Pin the launch geometry (0 = batch-size heuristic): lets a small batch run the code path of a large one."""
+        self._chk(self.lib.disco_set_tuning(self.ctx, stft_frames_per_wave, cov_chunks, step2_chunks, istft_pairs))
+
+    def stage_timing(self, enable=True):
+        """Start (clearing) / stop the per-stage hipEvent timers of the whole-path calls."""
+        self._chk(self.lib.disco_stage_timing(self.ctx, int(bool(enable))))
+
+    def stage_report(self, max_stages=32):
+        """-> {stage: (total_ms, launches)} for everything recorded since stage_timing(True); waits for the events."""
+        names = C.create_string_buffer(32 * max_stages)
+        ms = (C.c_float * max_stages)()
+        cnt = (C.c_int * max_stages)()
+        n = self.lib.disco_stage_report(self.ctx, names, ms, cnt, max_stages)
+        if n < 0:
+            self._chk(n)
+        return {names.raw[32 * i:32 * i + 32].split(b'\0', 1)[0].decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
     def sync(self):
         self._chk(self.lib.disco_sync(self.ctx, self.stream))
 
@@ -208,8 +228,20 @@ class Engine:
         if isinstance(a, DevBuf):
             assert a.dtype == np.dtype(dtype), (a.dtype, dtype)
             return a.ptr, a
-        if hasattr(a, 'data_ptr'):                       # torch tensor on the GPU
-            assert a.is_contiguous()
+        if hasattr(a, 'data_ptr'):                       # torch tensor: zero-copy, so it must already BE what the kernel reads
+            want = np.dtype(dtype)
+            tname = str(a.dtype).replace('torch.', '')
+            ok = {'float32': ('float32',), 'float64': ('float64',), 'uint8': ('uint8',),
+                  'complex64': ('complex64', 'float32')}.get(want.name, (want.name,))     # complex64 also as its (..., 2) float32 view
+            if tname not in ok:
+                raise TypeError(f'expected a {want.name} tensor, got torch.{tname} (the kernels would reinterpret the bytes)')
+            if not a.is_contiguous():
+                raise ValueError('device tensors must be contiguous')
+            dev = a.device
+            if dev.type == 'cuda' and dev.index is not None and dev.index != self.cfg.device and not self._host_pointers_ok:
+                raise ValueError(f'tensor lives on cuda:{dev.index}, this engine on device {self.cfg.device}')
+            if dev.type != 'cuda' and not self._host_pointers_ok:
+                raise ValueError('torch tensors must live on the GPU (pass a numpy array for a host->device copy)')
             return a.data_ptr(), a
         a = np.ascontiguousarray(a, dtype=dtype)
         b = DevBuf(self, a.shape, dtype)
@@ -230,13 +262,18 @@ class Engine:
         self._chk(self.lib.disco_stft(self.ctx, px, n_sig, chans, X.ptr, self.stream))
         return X
 
-    def istft(self, Z):
-        """Z (n_sig, T, F) complex64 -> (n_sig, L) float32   [lb.core.istft, tango.py:528]"""
+    def istft(self, Z, out=None):
+        """Z (n_sig, T, F) complex64 -> (n_sig, L) float32   [lb.core.istft, tango.py:528]
+        out: optional caller-owned device array (DevBuf or torch tensor) of n_sig * L float32 to write into."""
         n_sig = Z.shape[0]
         assert tuple(Z.shape[1:]) == (self.T, self.F)
         pz, kz = self.to_device(Z, np.complex64)
-        out = self.empty((n_sig, self.Lsamp), np.float32)
-        self._chk(self.lib.disco_istft(self.ctx, pz, n_sig, out.ptr, self.stream))
+        if out is None:
+            out = self.empty((n_sig, self.Lsamp), np.float32)
+        else:
+            assert int(np.prod(tuple(out.shape))) == n_sig * self.Lsamp and not isinstance(out, np.ndarray)
+        po, ko = self.to_device(out, np.float32)
+        self._chk(self.lib.disco_istft(self.ctx, pz, n_sig, po, self.stream))
         return out
 
     def tf_mask(self, S, N, type='irm1', bin_thr=0.0):

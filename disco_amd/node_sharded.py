@@ -21,7 +21,7 @@ def node_range(rank, world, K):
     return rank * kl, kl
 
 
-def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=None):
+def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=None, out=None):
     """Shared data flow.  z_out / yf_out: caller-owned device arrays for this rank's z / yf (or None: DevBuf);
     gather(z_local) -> z of ALL nodes (R, K, T, F), numpy or device array."""
     if iters < 1:
@@ -52,7 +52,7 @@ def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=
             # DANSE-style continuation (disco_tango_enhance_iterated): re-compress with the local part of the new filter
             w_loc = eng.filter_head(w_glo)
     yf = eng.apply(X, w_glo, Z=z_all if eng.K > 1 else None, out=yf_out)
-    out = eng.istft(yf.reshape(R * Kl, eng.T, eng.F)).reshape(R, Kl, eng.Lsamp)
+    out = eng.istft(yf.reshape(R * Kl, eng.T, eng.F), out=out).reshape(R, Kl, eng.Lsamp)
     return out, yf, z_all
 
 
@@ -68,13 +68,15 @@ def tango_enhance_node_sharded(eng, y_local, mask_z_local, mask_w_local, all_gat
     return _run(eng, y_local, mask_z_local, mask_w_local, iters, None, gather)
 
 
-def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, group=None, iters=1):
+def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, group=None, iters=1, out=None, gather_events=None):
     """Device-resident variant: y_local (R, Kl, M, L) float32 and the masks (R, Kl, T, F) float32 are contiguous torch tensors
     on this rank's GPU; z stays on the GPUs and is all-gathered by torch.distributed over `group` (RCCL over xGMI; every
     rank holds the same number of nodes, rank order == node order).  The library launches on the null stream, which is
     torch's default stream, so the collective is ordered after the kernels that produce z and before those that read it.
     Per all-gather a rank sends R * Kl * T * F * 8 bytes to each peer (1.29 MB per (room, node) at C3).
-    Returns (out_local DevBuf (R, Kl, L), yf_local torch (R, Kl, T, F) complex64, z_all torch (R, K, T, F) complex64)."""
+    out: optional (R, Kl, L) float32 torch tensor to receive the time signals.  gather_events: optional list that receives a
+    (start, stop) pair of torch.cuda events per all-gather (recorded on the current stream; the caller synchronises and reads).
+    Returns (out_local (R, Kl, L) DevBuf or `out`, yf_local torch (R, Kl, T, F) complex64, z_all torch (R, K, T, F) complex64)."""
     import torch
     import torch.distributed as dist
     W = dist.get_world_size(group)
@@ -87,12 +89,20 @@ def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, g
     yf = torch.empty(shape, dtype=torch.complex64, device=dev)
     parts = torch.empty((W,) + shape, dtype=torch.complex64, device=dev)
 
+    timed = gather_events is not None and dev.type == 'cuda'
+
     def gather(z):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         # concatenated-along-dim-0 form: the one every backend (RCCL, gloo) accepts
         dist.all_gather_into_tensor(torch.view_as_real(parts).view(W * R, Kl, eng.T, eng.F, 2), torch.view_as_real(z), group=group)
+        if timed:
+            e1.record()
+            gather_events.append((e0, e1))
         # (W, R, Kl, T, F) -> (R, W*Kl, T, F): one on-device transpose copy (HBM speed, far below the link time)
         return parts.permute(1, 0, 2, 3, 4).reshape(R, K, eng.T, eng.F).contiguous()
-    return _run(eng, y_local, mask_z_local, mask_w_local, iters, z_loc, gather, yf_out=yf)
+    return _run(eng, y_local, mask_z_local, mask_w_local, iters, z_loc, gather, yf_out=yf, out=out)
 
 
 def torch_all_gather(world):

@@ -12,7 +12,8 @@
  *   - All array arguments are DEVICE pointers owned by the caller (except where "host" is stated).
  *   - complex64 is interleaved (re, im) float pairs  == numpy complex64 == disco_c32.
  *   - Every compute call is asynchronous on the given hipStream_t (pass NULL for the default stream);
- *     no hidden synchronisation.  A disco_ctx is bound to one device and is not thread-safe.
+ *     no hidden synchronisation.  A disco_ctx is bound to cfg.device and is not thread-safe: every entry point switches to
+ *     that device for its own duration and restores the calling thread's current device before it returns.
  *   - Return value: 0 on success, DISCO_E_ARG (-1) bad argument, DISCO_E_UNSUPPORTED (-2) unsupported
  *     shape, -1000 - hipError_t for a HIP failure.  Never throws, never aborts.
  *     disco_last_error(ctx) returns a static/ctx-owned message for the last failing call.
@@ -94,6 +95,25 @@ size_t disco_workspace_bytes(const disco_ctx* ctx);
  * disco_tango_enhance need all nodes on one GPU and return DISCO_E_UNSUPPORTED while a shard is active. */
 int  disco_set_node_shard(disco_ctx* ctx, int first_node, int node_count);
 
+/* Launch geometry.  By default every kernel derives its work split from the batch size (long per-wave frame runs and single
+ * covariance chunks once R*K fills the chip, short runs and up to 8 chunks for small batches).  This call pins it, so that a
+ * SMALL batch can be run -- and checked against the oracle -- on exactly the code path a large production batch takes:
+ *   stft_frames_per_wave  frames each wave of disco_stft_cov_fused streams (a workgroup covers 4x that; heuristic 8..80)
+ *   cov_chunks            frame chunks of disco_cov_masked                            (heuristic 1..8)
+ *   step2_chunks          frame chunks of disco_step2_cov_fused / disco_step2_apply_fused (heuristic 1..8)
+ *   istft_pairs           frame pairs per workgroup of disco_step2_apply_istft_fused  (heuristic 4..64)
+ * 0 keeps the heuristic for that kernel.  Results do not depend on the geometry beyond float32 summation order. */
+int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, int step2_chunks, int istft_pairs);
+
+/* Per-stage timers of the whole-path entry points (disco_tango_enhance, _iterated, _online) and of disco_mask_oracle:
+ * while enabled, every stage they launch (STFT+covariance, solves, filter passes, iSTFT ...) is bracketed by two hipEvents on
+ * the call's stream.  disco_stage_timing(ctx, 1) clears and starts, (ctx, 0) clears and stops.  disco_stage_report waits for
+ * the recorded events and returns the number of distinct stages n <= max_stages, with names[i*32 .. i*32+31] (NUL-terminated),
+ * total_ms[i] (sum over the recorded launches) and launches[i]; all three are HOST arrays.  Nothing is timed, recorded or
+ * synchronised while disabled (the default). */
+int  disco_stage_timing(disco_ctx* ctx, int enable);
+int  disco_stage_report(disco_ctx* ctx, char* names, float* total_ms, int* launches, int max_stages);
+
 /* ---- plain device-memory helpers (so a numpy-only host can drive the library without torch) -------- */
 int  disco_dev_alloc(disco_ctx* ctx, size_t bytes, void** dptr);
 int  disco_dev_free(disco_ctx* ctx, void* dptr);
@@ -133,7 +153,7 @@ int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask,
                      disco_c32* Rss, disco_c32* Rnn, disco_stream s);
 
 /* intern_filter(Rxx, Rnn, mu, type='gevd', rank=1) -- internal_formulas.py:56-73, batched:
- * top generalized eigenpair of each Hermitian pencil (float64 Cholesky whitening + one-sided Jacobi),
+ * top generalized eigenpair of each Hermitian pencil (float64 Cholesky whitening + repeated squaring),
  * eigenvalue clamped to [eps, 1e6], w = q d/(d+mu) (Q^-1)[0,0], t1 = q (Q^-1)[0,0].
  * Rss, Rnn: [n_prob][P][P]  ->  w, t1: [n_prob][P]  (t1 may be NULL).  1 <= P <= 16. */
 int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const disco_c32* Rnn, int64_t n_prob, int P,

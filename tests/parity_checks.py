@@ -533,14 +533,20 @@ def check_solver_vs_reference_golden(make_engine, golden_dir):
     return worst
 
 
-def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-4, staged_step2=False):
+def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-4, staged_step2=False, tuning=None):
     """Whole path through the C ABI vs the float64 oracle.  y, s, n: (R, K, M, L) float32.
+    tuning = (stft_frames_per_wave, cov_chunks, step2_chunks, istft_pairs): pin the launch geometry (disco_set_tuning) to
+    the one a large batch takes, and additionally check the `outputs=enhanced` call (no z / yf requested: the fused
+    filter+iSTFT kernel, which is what bench.py times) against the same oracle.
     Returns the per-output worst relative errors."""
     R, K, M, L = y.shape
     eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask, staged_step2=staged_step2)
+    if tuning is not None:
+        eng.set_tuning(*tuning)
     T, F = eng.T, eng.F
     m_dev = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F)
     out, z, yf = eng.tango_enhance(y, m_dev)
+    out_enh = eng.tango_enhance(y, m_dev, want_z=False, want_yf=False)[0].numpy() if tuning is not None else None
     out, z, yf, m_gpu = out.numpy(), z.numpy(), yf.numpy(), m_dev.numpy()
     errs = {'mask': 0.0, 'mask_max': 0.0, 'z_y': 0.0, 'yf': 0.0, 'out': 0.0}
     for r in range(R):
@@ -554,8 +560,10 @@ def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-
             errs['yf'] = max(errs['yf'], relerr(yf[r, k].T, o['yf'][k]))
             t_ref = so.istft(o['yf'][k], L, n_fft, n_fft // 2, work_dtype=np.float64)
             errs['out'] = max(errs['out'], relerr(out[r, k], t_ref))
+            if out_enh is not None:
+                errs['out_enhanced_only'] = max(errs.get('out_enhanced_only', 0.0), relerr(out_enh[r, k], t_ref))
     assert errs['mask'] < 2e-5 and errs['mask_max'] < 5e-3, errs
-    assert errs['z_y'] < tol and errs['yf'] < tol and errs['out'] < tol, errs
+    assert errs['z_y'] < tol and errs['yf'] < tol and errs['out'] < tol and errs.get('out_enhanced_only', 0.0) < tol, errs
     return errs
 
 
@@ -656,3 +664,84 @@ def check_node_sharded_torch_one_rank(make_engine, device, backend, K=3, M=2, L=
         if own_group:
             dist.destroy_process_group()
     return errs
+
+
+def check_solver_sizes(make_engine, sizes=range(1, 17), n=300, tol=2e-6):
+    """P = 1..16 (C5 needs 15): HIP float64 solver vs the numpy eigh closed form on rank-1-plus-noise pencils."""
+    rng = np.random.default_rng(11)
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    worst = 0.0
+    for P in sizes:
+        T = 6 * P + 5
+        a = rng.standard_normal((n, P, 1)) + 1j * rng.standard_normal((n, P, 1))
+        X = a * (rng.standard_normal((n, 1, T)) + 1j * rng.standard_normal((n, 1, T))) + 0.3 * (
+            rng.standard_normal((n, P, T)) + 1j * rng.standard_normal((n, P, T)))
+        Nn = rng.standard_normal((n, P, T)) + 1j * rng.standard_normal((n, P, T))
+        Rxx = (X @ X.conj().transpose(0, 2, 1) / T).astype(np.complex64)
+        Rnn = (Nn @ Nn.conj().transpose(0, 2, 1) / T).astype(np.complex64)
+        w, t1 = eng.gevd_mwf_r1(Rxx, Rnn)
+        wr, t1r, _ = mo.gevd_mwf_r1_hermitian(Rxx, Rnn, 1.0)
+        e = max(relerr(w.numpy(), wr), relerr(t1.numpy(), t1r))
+        assert e < tol, (P, e)
+        worst = max(worst, e)
+    return worst
+
+
+def _pencil_with_spectrum(rng, n, P, d):
+    """n Hermitian pencils (Rxx, Rnn) whose generalized eigenvalues are exactly d (descending), built in float64."""
+    A = rng.standard_normal((n, P, P)) + 1j * rng.standard_normal((n, P, P))
+    Rnn = A @ A.conj().transpose(0, 2, 1) / P + 0.5 * np.eye(P)
+    L = np.linalg.cholesky(Rnn)
+    V, _ = np.linalg.qr(rng.standard_normal((n, P, P)) + 1j * rng.standard_normal((n, P, P)))
+    C = (V * np.asarray(d)[None, None, :]) @ V.conj().transpose(0, 2, 1)
+    Rxx = L @ C @ L.conj().transpose(0, 2, 1)
+    return Rxx, Rnn
+
+
+def check_solver_small_gap(make_engine, sizes=(2, 4, 7, 15)):
+    """Pencils whose two largest generalized eigenvalues are close (d1/d0 up to 0.9999): the dominant-pair iteration must
+    keep going until it has separated them.  The bound scales with the conditioning of the eigenvector, 1 / (1 - d1/d0):
+    the float32 rounding of the INPUTS alone moves v0 by ~1e-7 / gap, so both solvers are compared on the same complex64
+    inputs.  Also: an exactly repeated top eigenvalue and non-finite input must give finite / contained results."""
+    rng = np.random.default_rng(5)
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    out = {}
+    for P in sizes:
+        for ratio in (0.9, 0.99, 0.999, 0.9999):
+            d = np.concatenate([[1.0, ratio], ratio * rng.uniform(0.0, 0.9, max(P - 2, 0))])[:P]
+            d = 3.0 * np.sort(d)[::-1]
+            Rxx, Rnn = _pencil_with_spectrum(rng, 64, P, d)
+            Rxx, Rnn = Rxx.astype(np.complex64), Rnn.astype(np.complex64)
+            w, t1 = eng.gevd_mwf_r1(Rxx, Rnn)
+            wr, t1r, _ = mo.gevd_mwf_r1_hermitian(Rxx, Rnn, 1.0)
+            e = max(relerr(w.numpy(), wr), relerr(t1.numpy(), t1r))
+            out[(P, ratio)] = e
+            assert e < 2e-6, (P, ratio, e)              # same inputs on both sides: float64 accuracy regardless of the gap
+    # exactly repeated top eigenvalue: any vector of the dominant plane is a valid v0; the gain d0/(d0+mu) is unique
+    P = 4
+    Rxx, Rnn = _pencil_with_spectrum(rng, 8, P, [2.0, 2.0, 0.5, 0.1])
+    w, t1 = eng.gevd_mwf_r1(Rxx.astype(np.complex64), Rnn.astype(np.complex64))
+    w, t1 = w.numpy(), t1.numpy()
+    assert np.all(np.isfinite(w.view(np.float32))) and np.all(np.isfinite(t1.view(np.float32)))
+    ratio = np.linalg.norm(w, axis=-1) / np.linalg.norm(t1, axis=-1)
+    assert np.abs(ratio - 2.0 / 3.0).max() < 1e-5, ratio
+    # a NaN pencil next to good ones must not contaminate its neighbours (groups share waves and LDS)
+    Rxx, Rnn = _pencil_with_spectrum(rng, 16, P, [2.0, 1.0, 0.5, 0.1])
+    Rxx, Rnn = Rxx.astype(np.complex64), Rnn.astype(np.complex64)
+    wr, _, _ = mo.gevd_mwf_r1_hermitian(Rxx, Rnn, 1.0)
+    Rxx[5] = np.nan
+    w, _ = eng.gevd_mwf_r1(Rxx, Rnn)
+    w = w.numpy()
+    good = np.arange(16) != 5
+    assert relerr(w[good], wr[good]) < 2e-6
+    return out
+
+
+def check_solver_degenerate(make_engine):
+    """Rss = 0 (mask 0 everywhere): eigenvalue clamps to eps -> w ~ 0, finite (internal_formulas.py:59-62)."""
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    for P in (1, 4, 7, 15):
+        Rnn = np.eye(P, dtype=np.complex64)[None].repeat(3, 0)
+        Rss = np.zeros((3, P, P), np.complex64)
+        w, t1 = eng.gevd_mwf_r1(Rss, Rnn)
+        assert np.all(np.isfinite(w.numpy().view(np.float32))) and np.abs(w.numpy()).max() < 1e-12

@@ -112,32 +112,16 @@ def test_solver_vs_reference_golden(make_engine, golden_dir):
 
 
 def test_solver_sizes_up_to_16(make_engine):
-    """P = 1..16 (C5 needs 15): HIP float64 Jacobi vs numpy eigh closed form."""
-    from oracle import mwf_oracle as mo
-    rng = np.random.default_rng(11)
-    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
-    for P in range(1, 17):
-        n, T = 300, 6 * P + 5
-        a = rng.standard_normal((n, P, 1)) + 1j * rng.standard_normal((n, P, 1))
-        X = a * (rng.standard_normal((n, 1, T)) + 1j * rng.standard_normal((n, 1, T))) + 0.3 * (
-            rng.standard_normal((n, P, T)) + 1j * rng.standard_normal((n, P, T)))
-        Nn = rng.standard_normal((n, P, T)) + 1j * rng.standard_normal((n, P, T))
-        Rxx = (X @ X.conj().transpose(0, 2, 1) / T).astype(np.complex64)
-        Rnn = (Nn @ Nn.conj().transpose(0, 2, 1) / T).astype(np.complex64)
-        w, t1 = eng.gevd_mwf_r1(Rxx, Rnn)
-        wr, t1r, _ = mo.gevd_mwf_r1_hermitian(Rxx, Rnn, 1.0)
-        e = max(pc.relerr(w.numpy(), wr), pc.relerr(t1.numpy(), t1r))
-        assert e < 2e-6, (P, e)
+    """P = 1..16 (C5 needs 15): HIP float64 solver vs numpy eigh closed form."""
+    pc.check_solver_sizes(make_engine)
+
+
+def test_solver_small_gap(make_engine):
+    print(pc.check_solver_small_gap(make_engine))
 
 
 def test_solver_degenerate_inputs(make_engine):
-    """Rss = 0 (mask 0 everywhere): eigenvalue clamps to eps -> w ~ 0, finite (internal_formulas.py:59-62)."""
-    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
-    P = 4
-    Rnn = np.eye(P, dtype=np.complex64)[None].repeat(3, 0)
-    Rss = np.zeros((3, P, P), np.complex64)
-    w, t1 = eng.gevd_mwf_r1(Rss, Rnn)
-    assert np.all(np.isfinite(w.numpy().view(np.float32))) and np.abs(w.numpy()).max() < 1e-12
+    pc.check_solver_degenerate(make_engine)
 
 
 @pytest.mark.parametrize('K,M,L,n_fft,staged', [(4, 4, 160000, 512, False), (4, 4, 160000, 512, True), (1, 4, 160000, 512, False),
@@ -149,6 +133,42 @@ def test_tango_end_to_end_vs_oracle(make_engine, K, M, L, n_fft, staged):
     y, s, n = synth.make_rooms_numpy(2, K=K, M=M, L=L)
     errs = pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, staged_step2=staged)
     print(K, M, L, n_fft, staged, errs)
+
+
+# The launch geometry bench.py's headline run takes (R*K = 4000: 80 frames per STFT wave -> 2 chunks with a short last wave,
+# single-chunk covariances, 64 frame pairs per filter+iSTFT workgroup), pinned on small batches; plus geometries whose tails
+# fall differently (empty waves, one-frame last chunks).
+@pytest.mark.parametrize('R,K,M,L,n_fft,tuning', [(2, 4, 4, 160000, 512, (80, 1, 1, 64)), (1, 4, 4, 160000, 512, (80, 1, 1, 64)),
+                                                 (2, 4, 4, 25700, 512, (80, 1, 1, 64)), (2, 2, 3, 160000, 512, (79, 1, 1, 63)),
+                                                 (2, 4, 4, 82000, 512, (40, 2, 3, 20)), (1, 2, 2, 80000, 1024, (80, 1, 1, 0)),
+                                                 (2, 1, 4, 160000, 512, (80, 1, 1, 64))])
+def test_tango_bench_geometry(make_engine, R, K, M, L, n_fft, tuning):
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    errs = pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, tuning=tuning)
+    print(errs)
+
+
+def test_large_batch_default_geometry(make_engine):
+    """R*K = 2048 rooms-nodes of a SHORT signal: the batch-size heuristics themselves pick the large-batch geometry
+    (long runs, single chunks); 4 sampled rooms are checked against the float64 oracle, the rest against the same rooms
+    computed in a small batch (batch independence)."""
+    R, K, M, L = 512, 4, 4, 25600
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L)
+    m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F)
+    out = eng.tango_enhance(y, m, want_z=False, want_yf=False)[0].numpy()
+    from oracle import stft_oracle as so
+    from oracle import tango_oracle as to
+    for r in (0, 137, 300, 511):
+        o = to.offline_tango_vec(y[r], s[r], n[r], vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+        for k in range(K):
+            ref = so.istft(o['yf'][k], L, work_dtype=np.float64)
+            assert pc.relerr(out[r, k], ref) < 1e-4, (r, k)
+    sub = slice(200, 204)
+    eng2 = make_engine(rooms=4, nodes=K, mics=M, length=L)
+    m2 = eng2.mask_oracle(s[sub, :, 0].reshape(4 * K, L), n[sub, :, 0].reshape(4 * K, L)).reshape(4, K, eng2.T, eng2.F)
+    out2 = eng2.tango_enhance(y[sub], m2, want_z=False, want_yf=False)[0].numpy()
+    assert pc.relerr(out[sub], out2) < 2e-5
 
 
 def test_c2_single_node_config(make_engine):

@@ -100,3 +100,25 @@ def test_emu_solver_vs_reference_golden(make_engine, golden_dir):
 def test_emu_tango_end_to_end(make_engine, staged):
     y, s, n = synth.make_rooms_numpy(1, K=2, M=2, L=8192)
     print(pc.check_tango_end_to_end(make_engine, y, s, n, staged_step2=staged))
+
+
+def test_emu_solver_sizes(make_engine):
+    print(pc.check_solver_sizes(make_engine, sizes=(1, 2, 3, 4, 5, 7, 8, 9, 15, 16), n=40))
+
+
+def test_emu_solver_small_gap(make_engine):
+    print(pc.check_solver_small_gap(make_engine, sizes=(2, 4, 7, 15)))
+
+
+def test_emu_solver_degenerate(make_engine):
+    pc.check_solver_degenerate(make_engine)
+
+
+@pytest.mark.parametrize('K,M,L,n_fft,tuning', [(2, 2, 25700, 512, (80, 1, 1, 64)), (3, 2, 13000, 512, (13, 2, 3, 5)),
+                                               (2, 2, 9000, 512, (80, 1, 1, 2)), (2, 1, 20000, 1024, (7, 1, 2, 0)),
+                                               (1, 3, 25700, 512, (80, 1, 1, 64))])
+def test_emu_tango_pinned_geometry(make_engine, K, M, L, n_fft, tuning):
+    """Large-batch launch geometries (long STFT runs with short / empty last waves, single-chunk covariances, many frame
+    pairs per filter+iSTFT workgroup) pinned on a small batch through disco_set_tuning."""
+    y, s, n = synth.make_rooms_numpy(2, K=K, M=M, L=L)
+    print(pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, tuning=tuning))

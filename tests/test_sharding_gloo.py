@@ -193,3 +193,32 @@ def test_node_sharded_device_resident_iterated_two_ranks():
         assert p.exitcode == 0
     for rank, e1, e2 in res:
         assert e1 < 1e-5 and e2 < 1e-4, (rank, e1, e2)
+
+
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` started plainly (no torchrun, no WORLD_SIZE) must become TWO ranks: the launcher of
+    disco_amd/dist.py:launch_ranks, exercised on CPU with gloo (`--selftest-launch` skips the GPU work, nothing else)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--selftest-launch'], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2                      # one line, from rank 0, of a 2-rank job
+    assert lines[0]['value'] == pytest.approx((1000.0 + 2000.0) / 0.6)     # sum of units / max of times over the ranks
+    # a world size that contradicts --gpus is an error, not a silent single-rank run
+    p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '1', '--selftest-launch'],
+                       env=dict(env, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0'), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and 'WORLD_SIZE' in (p.stderr + p.stdout)
+
+
+def test_launch_ranks_propagates_failure(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text('import os, sys, time\nr = int(os.environ["RANK"])\nif r == 1:\n    sys.exit(7)\ntime.sleep(30)\n')
+    import time
+    t0 = time.time()
+    rc = dd.launch_ranks(str(script), [], 2, timeout=60)
+    assert rc == 7 and time.time() - t0 < 20          # rank 0 was terminated instead of waiting out its sleep
