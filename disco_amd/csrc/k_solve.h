@@ -33,12 +33,14 @@ namespace disco {
 // lane, and a read issuing before the wave's own writes were accepted (same fence as fft.h).
 // The compiler-level memory clobber makes hipcc re-load LDS values after the fence instead of carrying them in registers
 // from one phase to the next (it would keep the whole of L, P(P-1)/2 complex doubles, live between the two substitutions).
+#ifndef DISCO_GROUP_SYNC
 #define DISCO_GROUP_SYNC()                    \
     do {                                      \
         __builtin_amdgcn_s_waitcnt(0xC07F);   \
         __builtin_amdgcn_wave_barrier();      \
         asm volatile("" ::: "memory");        \
     } while (0)
+#endif
 
 constexpr double SOLVE_EPS = 2.220446049250313e-16;     // internal_formulas.py:6  sys.float_info.epsilon
 constexpr double SOLVE_ETA = 1e6;                       // internal_formulas.py:7
@@ -225,6 +227,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     // rank one to rounding.  Lane j owns column j; the columns meet through the group's LDS matrix Ym (wave-level
     // fences only: a group never spans waves).  An exactly repeated top eigenvalue never converges (tau -> 1/m) and
     // stops at the iteration cap with a vector of the dominant subspace, which is all any solver can return there.
+    // The loop is wave-uniform (vote on the exit): groups that are done keep their B and idle.
     bool done;
     {
         double trl = 0.0;
@@ -247,7 +250,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         }
         DISCO_GROUP_SYNC();
         c64 nn[P];
-        double tl = 0.0;
+        c64 tc = make_double2(0.0, 0.0);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             // one row of B at a time: without the fences hipcc hoists all P^2 LDS loads (4 registers each) above the
@@ -261,16 +264,29 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
                 a.y = fma(b.x, g[k].y, fma(b.y, g[k].x, a.y));
             }
             nn[i] = a;
-            if (i == j) tl = a.x;
+            if (i == j) tc = a;
         }
         DISCO_SCHED_FENCE();
+        // tau = tr(B^2) as a COMPLEX number.  For an exactly Hermitian B it is real, but rounding (and inputs whose two
+        // triangles were accumulated separately, as the online kernel's) leave B = (1 + i eps) x a Hermitian matrix, and a
+        // normaliser that ignores Im tau lets that phase DOUBLE with every squaring (B^2 carries (1 + i eps)^2) until tau
+        // turns negative -- measured on the MI355X: 1 - Re tau grew 4x per iteration from 1e-11.  Dividing by the complex
+        // trace removes the common complex scale altogether; the remaining perturbations of the fixed point v0 v0^H are
+        // either annihilated or carried unchanged, so squaring on after convergence is harmless.
 #pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) tl += __shfl_xor(tl, off, G);
-        const double rtau = tl > 0.0 ? rcp64(tl) : 0.0;
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            tc.x += __shfl_xor(tc.x, off, G);
+            tc.y += __shfl_xor(tc.y, off, G);
+        }
+        const double den = tc.x * tc.x + tc.y * tc.y;
+        const double rden = den > 0.0 ? rcp64(den) : 0.0;
+        const c64 itau = make_double2(tc.x * rden, -tc.y * rden);
+        if (!done) {                                           // a finished group idles until the slowest of its wave is through
 #pragma unroll
-        for (int i = 0; i < P; ++i) g[i] = zscale(nn[i], rtau);
-        done = done || (1.0 - tl < DISCO_SQUARING_DONE);
-        if (!__any(!done)) break;                              // wave-uniform exit: finished groups keep squaring a projector
+            for (int i = 0; i < P; ++i) g[i] = zmul(nn[i], itau);
+        }
+        done = done || (1.0 - tc.x < DISCO_SQUARING_DONE) || !(den > 0.0);
+        if (!__any(!done)) break;                              // wave-uniform exit                              // wave-uniform exit: finished groups keep squaring a projector
     }
 
     // L is read again by the back substitution below: make the compiler re-load it from LDS there instead of carrying

@@ -717,6 +717,27 @@ def check_solver_small_gap(make_engine, sizes=(2, 4, 7, 15)):
             e = max(relerr(w.numpy(), wr), relerr(t1.numpy(), t1r))
             out[(P, ratio)] = e
             assert e < 2e-6, (P, ratio, e)              # same inputs on both sides: float64 accuracy regardless of the gap
+    # one slow pencil (d1/d0 = 0.99999, ~20 squarings) in a batch of quick ones whose Rxx is NOT exactly Hermitian (the two
+    # triangles differ at float32 rounding level, as in the online kernel where every lane accumulates its own row): the
+    # quick ones wait in the same wave and must come out untouched.  (A normaliser that ignores the imaginary part of
+    # tr(B^2) lets the phase of the common complex scale double per squaring: this case then fails on the whole wave.)
+    for P in (4, 7):
+        n = 64
+        d_fast = np.concatenate([[1.0, 0.6], 0.6 * rng.uniform(0.0, 0.9, P - 2)])
+        Rxx, Rnn = _pencil_with_spectrum(rng, n, P, 2.0 * np.sort(d_fast)[::-1])
+        d_slow = np.concatenate([[1.0, 0.99999], 0.5 * rng.uniform(0.0, 0.9, P - 2)])
+        Rs, Rn = _pencil_with_spectrum(rng, 1, P, 2.0 * np.sort(d_slow)[::-1])
+        Rxx[9], Rnn[9] = Rs[0], Rn[0]
+        skew = rng.standard_normal((n, P, P)) + 1j * rng.standard_normal((n, P, P))
+        skew = (skew - skew.conj().transpose(0, 2, 1)) * 2e-7 * np.abs(Rxx).mean()
+        Rxx32, Rnn32 = (Rxx + skew).astype(np.complex64), Rnn.astype(np.complex64)
+        w, t1 = eng.gevd_mwf_r1(Rxx32, Rnn32)
+        wr, t1r, _ = mo.gevd_mwf_r1_hermitian(0.5 * (Rxx32 + Rxx32.conj().transpose(0, 2, 1)), Rnn32, 1.0)
+        quick = np.arange(n) != 9
+        e = max(relerr(w.numpy()[quick], wr[quick]), relerr(t1.numpy()[quick], t1r[quick]))
+        out[(P, 'mixed')] = e
+        assert e < 5e-6, (P, e)                         # 2e-7 of skew / a relative gap of 0.4
+        assert np.all(np.isfinite(w.numpy().view(np.float32)))
     # exactly repeated top eigenvalue: any vector of the dominant plane is a valid v0; the gain d0/(d0+mu) is unique
     P = 4
     Rxx, Rnn = _pencil_with_spectrum(rng, 8, P, [2.0, 2.0, 0.5, 0.1])
