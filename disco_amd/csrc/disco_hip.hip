@@ -462,8 +462,37 @@ static int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco
 }
 
 // chunk partials of the masked covariances into ctx->scratch ([R*K][chunks][F][NP] float4)
+// (M, KR) shapes for which the block-partitioned kernel k_cov_split is instantiated: 9 <= M + KR <= 16, and the step-1
+// shapes (KR = 0) whose 2 * M(M+1)/2 complex accumulators no longer fit one thread without spilling (M >= 7)
+#define DISCO_FOR_SPLIT(X_)                                                      \
+    X_(7, 0) X_(8, 0)                                                            \
+    X_(8, 1) X_(8, 2) X_(8, 3) X_(8, 4) X_(8, 5) X_(8, 6) X_(8, 7) X_(8, 8)      \
+    X_(4, 5) X_(4, 6) X_(4, 7) X_(4, 8) X_(4, 9) X_(4, 10) X_(4, 11) X_(4, 12)   \
+    X_(2, 7) X_(2, 8) X_(2, 9) X_(2, 10) X_(2, 11) X_(2, 12) X_(2, 13) X_(2, 14)
+
+template <int M, int KR>
+static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {
+    if constexpr (KR > 0) {
+        if (skiploc) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+}
+
+static bool cov_split_shape(int M, int KR) {
+#define X_(M_, KR_) if (M == M_ && KR == KR_) return true;
+    DISCO_FOR_SPLIT(X_)
+#undef X_
+    return false;
+}
+
+// skiploc (step 2 only, internal): the caller guarantees that `scratch` holds the step-1 partial sums of THIS X with THIS
+// mask (ctx->loc_M == M): the leading M x M block is then neither accumulated nor written, the partial sums go to `scratch2`
+// and the solver assembles the pencil from both.  Honoured only by k_cov_split; the return value of *skiploc_used says so.
 static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs, const disco_c32* Zn,
-                        int mask_remote, int P, int* chunks_out, disco_stream s) {
+                        int mask_remote, int P, int* chunks_out, disco_stream s, bool skiploc = false) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, KR = P - M;
     if (!X || !mask) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
@@ -474,14 +503,28 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     const long long G = (long long)c.rooms * ctx->Kl;
     const int NP = P * (P + 1) / 2;
     const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
-    int rc = ensure_scratch(ctx, need);
+    const bool same = (Zs == Zn);
+    const bool split = (KR == 0 || (P > 8 && same && mask_remote)) && cov_split_shape(M, KR);
+    skiploc = skiploc && split && KR > 0 && ctx->loc_M == M;
+    int rc = 0;
+    if (skiploc) {
+        if (ctx->scratch2_bytes < need) {
+            if (ctx->scratch2) HIPCHK(ctx, hipFree(ctx->scratch2));
+            ctx->scratch2 = nullptr;
+            ctx->scratch2_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->scratch2, need));
+            ctx->scratch2_bytes = need;
+        }
+    } else {
+        rc = ensure_scratch(ctx, need);
+    }
     if (rc) return rc;
     CovArgs a;
     a.X = (const c32*)X;
     a.mask = mask;
     a.Zs = (const c32*)Zs;
     a.Zn = (const c32*)Zn;
-    a.part = (float4*)ctx->scratch;
+    a.part = (float4*)(skiploc ? ctx->scratch2 : ctx->scratch);
     a.K = c.nodes;
     a.T = ctx->T;
     a.F = ctx->F;
@@ -489,9 +532,20 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     a.mask_remote = mask_remote;
     a.Kl = ctx->Kl;
     a.k0 = ctx->k0;
-    const bool same = (Zs == Zn);
     const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
     bool launched = false;
+    if (split) {                // 9 <= P <= 16, one vector for both statistics: one block of pairs per wave
+        const int tiles = (ctx->F - 1 + 63) / 64;
+        const long long nblk = G * (tiles + 1) * chunks;
+        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
+#define X_(M_, KR_)                                                                                                  \
+    if (!launched && M == M_ && KR == KR_) {                                                                         \
+        launch_cov_split<M_, KR_>(skiploc, (unsigned)nblk, (hipStream_t)s, a);                                       \
+        launched = true;                                                                                             \
+    }
+        DISCO_FOR_SPLIT(X_)
+#undef X_
+    }
 #define X_(M_, KR_)                                                                                                  \
     if (!launched && M == M_ && KR == KR_) {                                                                         \
         if (c.n_fft == 512) {                                                                                        \
@@ -521,8 +575,13 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
     ctx->pending_P = P;
-    ctx->pending_skiploc = 0;
-    ctx->loc_M = 0;                    // `scratch` no longer holds k_stft_cov's step-1 partials
+    ctx->pending_skiploc = skiploc ? 1 : 0;
+    if (!skiploc) {
+        // `scratch` now holds THIS call's partial sums: step-1 ones (P == M, all nodes here) can be re-used by a step 2
+        // on the same mask, anything else invalidates what k_stft_cov / an earlier step-1 call left
+        ctx->loc_M = (KR == 0 && !sharded(ctx)) ? M : 0;
+        ctx->loc_chunks = chunks;
+    }
     return check_launch(ctx, "k_cov");
 }
 
@@ -679,9 +738,6 @@ static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, co
     }
     return false;
 }
-
-static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs, const disco_c32* Zn,
-                        int mask_remote, int P, int* chunks_out, disco_stream s);
 
 static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s) {
     if (!y || !mask_z || !X) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
@@ -894,8 +950,9 @@ extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X,
     a.F = ctx->F;
     a.chunks = 1;
     const int n_seg = (c.length + c.hop - 1) / c.hop;
-    // frame pairs per workgroup: as many as possible (<= 64) while leaving >= ~2048 workgroups
-    const long long bpr_wanted = std::max<long long>(1, (2048 + c.rooms - 1) / c.rooms);
+    // frame pairs per workgroup: as many as possible (<= 64) while leaving >= ~8192 waves (a workgroup has K of them)
+    const long long units = (long long)c.rooms * K;
+    const long long bpr_wanted = std::max<long long>(1, (8192 + units - 1) / units);
     int pairs = (int)(((n_seg + bpr_wanted - 1) / bpr_wanted + 2) / 2);
     pairs = std::min(64, std::max(4, pairs));
     if (ctx->tune_pairs > 0) pairs = ctx->tune_pairs;
@@ -999,6 +1056,11 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     int chunks1 = 1;
     if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks1, s))) return rc;
     if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks1, M, w, s)))) return rc;
+    if (c.nodes == 1 && mask_w == mask_z && !z_y && !yf && c.n_fft == 512) {
+        // single node, enhanced output only (config C2): filter + iSTFT in one pass over X, z never reaches HBM
+        rc = STAGE(ctx, s, "step2_apply_istft", disco_step2_apply_istft_fused(ctx, X, w, w, out, s));
+        if (rc != DISCO_E_UNSUPPORTED) return rc;
+    }
     if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w, M, 1, z, s)))) return rc;
     if (c.nodes == 1 && mask_w == mask_z) {
         // single node, same mask: step 2 would rebuild the very same statistics from the very same inputs
@@ -1007,7 +1069,8 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
         return STAGE(ctx, s, "istft", disco_istft(ctx, z, G, out, s));
     }
     // exchange + step 2 (tango.py:378-450), mask_for_z = 'local'
-    if ((rc = STAGE(ctx, s, "cov2", disco_cov_masked(ctx, X, mask_w, z, z, 1, P2, nullptr, nullptr, s)))) return rc;     // partial sums stay pending
+    int chunks2 = 1;              // partial sums stay pending; the local M x M block is step 1's when the mask is the same
+    if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, z, z, 1, P2, &chunks2, s, mask_w == mask_z)))) return rc;
     if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w, nullptr, s)))) return rc;
     if ((rc = STAGE(ctx, s, "apply2", disco_apply(ctx, X, z, w, P2, 1, yo, s)))) return rc;
     return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
@@ -1227,7 +1290,9 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     if ((rc = STAGE(ctx, s, "solve1", disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s)))) return rc;
     if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
     for (int it = 0; it < iters; ++it) {
-        if ((rc = STAGE(ctx, s, "cov2", disco_cov_masked(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, nullptr, nullptr, s)))) return rc;
+        int chunks2 = 1;
+        if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &chunks2, s,
+                                                     mask_w == mask_z && c.nodes > 1)))) return rc;
         if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s)))) return rc;
         if (it + 1 < iters) {
             const long long nb = (long long)G * ctx->F;

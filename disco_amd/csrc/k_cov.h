@@ -287,6 +287,210 @@ __global__ __launch_bounds__(64 * CB_S) void k_cov_big(CovArgs a, int M, int KR)
     }
 }
 
+// ---- 9 <= P <= 16, both statistics on the SAME vector (step 2 with mask_for_z = 'local', tango.py:416-418) -------------
+// k_cov_big above gives every wave ALL P components of a bin and a quarter of the pairs: four times the loads, 136
+// accumulators and 30 live inputs per lane, two waves per SIMD.  Here the P x P triangle is cut along the halves of the
+// two component groups -- A = the node's own M channels, B = the K-1 remote z's -- and every wave of a workgroup owns one
+// BLOCK of pairs, so it loads only the (at most two) half-groups its block touches:
+//     wave 0..3 : A0 x B0, A0 x B1, A1 x B0, A1 x B1          wave 4 : tri(B0) + tri(B1)       wave 5 : B0 x B1
+//     wave 6, 7 : tri(A0) + tri(A1), A0 x A1   -- only when the leading M x M block is wanted: with SKIPLOC it is the
+//                 step-1 covariance (same mask), already in the context as partial sums (cf. k_step2_cov_fused)
+// 8 x 7 (config C5): at most 16 pairs = 64 accumulators and 8 inputs per lane.  u_i conj(u_j) is formed once per pair and
+// added into both statistics with the weights m^2 and (1-m)^2 (cov_accumulate_shared).  Lane = bin of a 64-bin tile; the
+// Nyquist bin gets one more workgroup per (node, chunk) whose lanes stride over frames (as everywhere else).
+template <int M, int KR, int X0, int X1, int Y0, int Y1, bool TRI>
+struct CovSplitRole {
+    // components [X0, X1) and [Y0, Y1) of v = [x_0..x_{M-1}, z_0..z_{KR-1}]; TRI: the two upper triangles, else the X x Y block
+    static constexpr int NX = X1 - X0, NY = Y1 - Y0;
+    static constexpr int NPAIR = TRI ? NX * (NX + 1) / 2 + NY * (NY + 1) / 2 : NX * NY;
+};
+
+template <int M, int KR, int C0, int C1>
+__device__ __forceinline__ void cov_split_fetch(c32* u, const c32* __restrict__ xp, const c32* const* zp, int tf) {
+    // components [C0, C1) of one (frame, bin); tf = t * F + f as a 32-bit offset into the node's [T][F] plane, so that the
+    // wave-uniform plane pointers xp / zp stay in scalar registers (one VGPR of offset instead of a 64-bit pointer per row).
+    // The mics among the components come as 16-byte pairs where the layout allows it (M even, even first index, even count).
+    constexpr int XA = C0 < M ? C0 : M, XB = C1 < M ? C1 : M, ZA = C0 > M ? C0 : M;
+    if constexpr (XB > XA) {
+        if constexpr (M % 2 == 0 && XA % 2 == 0 && (XB - XA) % 2 == 0) {
+            const float4* src = reinterpret_cast<const float4*>(xp + (long long)tf * M + XA);
+#pragma unroll
+            for (int p = 0; p < (XB - XA) / 2; ++p) {
+                const float4 q = src[p];
+                u[XA - C0 + 2 * p] = make_float2(q.x, q.y);
+                u[XA - C0 + 2 * p + 1] = make_float2(q.z, q.w);
+            }
+        } else {
+#pragma unroll
+            for (int c = XA; c < XB; ++c) u[c - C0] = xp[(long long)tf * M + c];
+        }
+    }
+#pragma unroll
+    for (int c = ZA; c < C1; ++c) u[c - C0] = zp[c - M][tf];
+}
+
+template <int M, int KR, int X0, int X1, int Y0, int Y1, bool TRI>
+__device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, int c, int tile, int lane) {
+    using Role = CovSplitRole<M, KR, X0, X1, Y0, Y1, TRI>;
+    constexpr int P = M + KR, NP = P * (P + 1) / 2, NX = Role::NX, NY = Role::NY, NPAIR = Role::NPAIR;
+    if constexpr (NPAIR == 0) {
+        return;
+    } else {
+        const int K = a.K, T = a.T, F = a.F;
+        const int nbin = F - 1, tiles = (nbin + 63) / 64;
+        const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
+        const bool nyq = tile == tiles;
+        int f = nyq ? nbin : tile * 64 + lane;
+        const bool live = nyq || f < nbin;
+        if (f > nbin) f = nbin;
+        const int t_step = nyq ? 64 : 1, t_off = nyq ? lane : 0;
+        const long long r = g / a.Kl;
+        const int k = a.k0 + (int)(g % a.Kl);
+        const c32* xp = a.X + (g * T * (long long)F) * M;                     // wave-uniform plane pointers (scalar registers)
+        const float* mp = a.mask + g * T * (long long)F;
+        const c32* zp[KR > 0 ? KR : 1];
+#pragma unroll
+        for (int jj = 0; jj < KR; ++jj) {
+            const int j = jj < k ? jj : jj + 1;                                  // concatenate_signals order
+            zp[jj] = a.Zs + ((r * K + j) * T) * (long long)F;
+        }
+        c32 acc_s[NPAIR], acc_n[NPAIR];
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
+        // one frame ahead: raw, unconditional loads (frame index clamped into the chunk), weighed 0 when out of range
+        c32 ux[NX > 0 ? NX : 1], uy[NY > 0 ? NY : 1], nx[NX > 0 ? NX : 1], ny[NY > 0 ? NY : 1];
+        float mcur, mnext;
+        auto fetch = [&](int tu, c32* px, c32* py, float& m_) {
+            int t_ = tu + t_off;
+            t_ = t_ < t1 ? t_ : t1 - 1;
+            const int tfm = t_ * F + f;                              // (frame, bin) offset inside the node's plane
+            m_ = mp[tfm];
+            cov_split_fetch<M, KR, X0, X1>(px, xp, zp, tfm);
+            cov_split_fetch<M, KR, Y0, Y1>(py, xp, zp, tfm);
+        };
+        fetch(t0, ux, uy, mcur);
+        for (int tu = t0; tu < t1; tu += t_step) {
+            fetch(tu + t_step, nx, ny, mnext);                       // harmless clamp at the end of the chunk
+            const bool ok = live && (tu + t_off) < t1;
+            const float m = ok ? mcur : 0.f, mc = ok ? 1.f - mcur : 0.f;
+            const float wa = m * m, wb = mc * mc;
+            int q = 0;
+            if constexpr (TRI) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = i; j < NX; ++j, ++q) {
+                        const float pr = fmaf(ux[i].x, ux[j].x, ux[i].y * ux[j].y);
+                        acc_s[q].x = fmaf(wa, pr, acc_s[q].x);
+                        acc_n[q].x = fmaf(wb, pr, acc_n[q].x);
+                        if (j != i) {
+                            const float pi = fmaf(ux[i].y, ux[j].x, -(ux[i].x * ux[j].y));
+                            acc_s[q].y = fmaf(wa, pi, acc_s[q].y);
+                            acc_n[q].y = fmaf(wb, pi, acc_n[q].y);
+                        }
+                    }
+#pragma unroll
+                for (int i = 0; i < NY; ++i)
+#pragma unroll
+                    for (int j = i; j < NY; ++j, ++q) {
+                        const float pr = fmaf(uy[i].x, uy[j].x, uy[i].y * uy[j].y);
+                        acc_s[q].x = fmaf(wa, pr, acc_s[q].x);
+                        acc_n[q].x = fmaf(wb, pr, acc_n[q].x);
+                        if (j != i) {
+                            const float pi = fmaf(uy[i].y, uy[j].x, -(uy[i].x * uy[j].y));
+                            acc_s[q].y = fmaf(wa, pi, acc_s[q].y);
+                            acc_n[q].y = fmaf(wb, pi, acc_n[q].y);
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j < NY; ++j, ++q) {
+                        const float pr = fmaf(ux[i].x, uy[j].x, ux[i].y * uy[j].y);          // u_i conj(u_j), i in X, j in Y
+                        const float pi = fmaf(ux[i].y, uy[j].x, -(ux[i].x * uy[j].y));
+                        acc_s[q].x = fmaf(wa, pr, acc_s[q].x);
+                        acc_n[q].x = fmaf(wb, pr, acc_n[q].x);
+                        acc_s[q].y = fmaf(wa, pi, acc_s[q].y);
+                        acc_n[q].y = fmaf(wb, pi, acc_n[q].y);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) ux[i] = nx[i];
+#pragma unroll
+            for (int i = 0; i < NY; ++i) uy[i] = ny[i];
+            mcur = mnext;
+        }
+        if (nyq) {          // lanes hold partial sums over disjoint frames of the same bin
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    acc_s[q].x += __shfl_xor(acc_s[q].x, off);
+                    acc_s[q].y += __shfl_xor(acc_s[q].y, off);
+                    acc_n[q].x += __shfl_xor(acc_n[q].x, off);
+                    acc_n[q].y += __shfl_xor(acc_n[q].y, off);
+                }
+        }
+        if (live && (!nyq || lane == 0)) {
+            float4* o = a.part + (((g * a.chunks + c) * F) + f) * (long long)NP;
+            int q = 0;
+            if constexpr (TRI) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = i; j < NX; ++j, ++q)
+                        o[tri_index<P>(X0 + i, X0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+#pragma unroll
+                for (int i = 0; i < NY; ++i)
+#pragma unroll
+                    for (int j = i; j < NY; ++j, ++q)
+                        o[tri_index<P>(Y0 + i, Y0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j < NY; ++j, ++q)                 // X precedes Y in v: (X0 + i, Y0 + j) is in the upper triangle
+                        o[tri_index<P>(X0 + i, Y0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+            }
+        }
+    }
+}
+
+// waves per workgroup: six blocks of pairs that involve the remote rows (none when KR = 0: the step-1 shape), two for the
+// local M x M block (none with SKIPLOC)
+template <int KR, bool SKIPLOC>
+constexpr int cov_split_waves() { return (KR > 0 ? 6 : 0) + (SKIPLOC ? 0 : 2); }
+
+// grid = R*Kl * (tiles + 1) * chunks blocks of 64 * cov_split_waves() threads; Zs == Zn and mask_remote != 0 are the caller's contract
+template <int M, int KR, bool SKIPLOC>
+__global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_split(CovArgs a) {
+    static_assert(KR > 0 || !SKIPLOC, "nothing to compute");
+    constexpr int MA = (M + 1) / 2, KB = (KR + 1) / 2, P = M + KR;
+    const int nbin = a.F - 1, tiles = (nbin + 63) / 64;
+    int bid = blockIdx.x;
+    const int c = bid % a.chunks;
+    bid /= a.chunks;
+    const int tile = bid % (tiles + 1);
+    const long long g = bid / (tiles + 1);
+    const int lane = threadIdx.x & 63;
+    const int role = wave_id() + (KR > 0 ? 0 : 6);
+    switch (role) {
+        case 0: cov_split_wave<M, KR, 0, MA, M, M + KB, false>(a, g, c, tile, lane); break;
+        case 1: cov_split_wave<M, KR, 0, MA, M + KB, P, false>(a, g, c, tile, lane); break;
+        case 2: cov_split_wave<M, KR, MA, M, M, M + KB, false>(a, g, c, tile, lane); break;
+        case 3: cov_split_wave<M, KR, MA, M, M + KB, P, false>(a, g, c, tile, lane); break;
+        case 4: cov_split_wave<M, KR, M, M + KB, M + KB, P, true>(a, g, c, tile, lane); break;
+        case 5: cov_split_wave<M, KR, M, M + KB, M + KB, P, false>(a, g, c, tile, lane); break;
+        case 6:
+            if constexpr (!SKIPLOC) cov_split_wave<M, KR, 0, MA, MA, M, true>(a, g, c, tile, lane);
+            break;
+        default:
+            if constexpr (!SKIPLOC) cov_split_wave<M, KR, 0, MA, MA, M, false>(a, g, c, tile, lane);
+            break;
+    }
+}
+
 // part [n_gf/F][chunks][F][NP] -> Rss, Rnn [n_gf][P][P], mean over T, Hermitian mirror.
 __global__ void k_cov_finalize(const float4* __restrict__ part, c32* __restrict__ Rss, c32* __restrict__ Rnn,
                                long long n_gf, int F, int chunks, int P, float inv_T) {

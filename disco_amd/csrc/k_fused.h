@@ -245,8 +245,8 @@ namespace disco {
 template <int N, int M, int K>
 struct alignas(16) ApplyIstftShared {
     c32 buf[K][fft_buf_len<N>()];
-    c32 zbuf[2][K][N / 2 + 1];
-    c32 wl[K][N / 2 + 1][M];
+    c32 zbuf[2][K][K > 1 ? N / 2 + 1 : 1];      // K = 1 (single node): nothing is exchanged, w_glo = w_loc lives in registers
+    c32 wl[K][K > 1 ? N / 2 + 1 : 1][M];
 };
 
 // 2 waves per SIMD is what the 68 kB of LDS allow; stated so that the allocator keeps the prefetch within 256 registers
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
     const long long g = r * K + k;
     const c32* Xg = a.X + (g * T * (long long)F) * M;
     // the room's local filters -> LDS (every wave needs all of them only through z; its own row is read per frame)
-    {
+    if constexpr (K > 1) {
         const c32* src = a.w_loc + (r * K) * (long long)F * M;
         c32* dst = &sh.wl[0][0][0];
         for (int i = threadIdx.x; i < K * F * M; i += 64 * K) dst[i] = src[i];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
         }
     };
     fetch_pair(s0);
-    __syncthreads();
+    if constexpr (K > 1) __syncthreads();
     for (int pr = 0; pr < pairs; ++pr) {
         const int tA = s0 + 2 * pr;
         c32 yf[2][NJ];
@@ -324,15 +324,17 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
                     else v = Xg[(tf0 + f) * M + i];
                     x[i] = tv ? v : make_float2(0.f, 0.f);
                 }
-                c32 wl[M];
+                if constexpr (K > 1) {
+                    c32 wl[M];
 #pragma unroll
-                for (int i = 0; i < M; ++i) wl[i] = sh.wl[k][f][i];
-                const c32 z = filt_conj<M>(wl, x);
-                if (j < EH || lane == 0) sh.zbuf[fr][k][f] = z;
+                    for (int i = 0; i < M; ++i) wl[i] = sh.wl[k][f][i];
+                    const c32 z = filt_conj<M>(wl, x);
+                    if (j < EH || lane == 0) sh.zbuf[fr][k][f] = z;
+                }
                 yf[fr][j] = filt_conj<M>(wg[j], x);
             }
         }
-        __syncthreads();
+        if constexpr (K > 1) __syncthreads();      // K = 1 (single node, w_glo = w_loc): one wave, nothing to exchange
         // ---- remote rows: yf += sum_jj conj(wg[M+jj]) z_j   (concatenate_signals order)
 #pragma unroll
         for (int fr = 0; fr < 2; ++fr) {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
         for (int e = 0; e < EH; ++e) carry[e] = gB[e + EH];
         // zbuf is rewritten by the next pair only after every wave has passed the next __syncthreads... but a fast wave
         // could reach its z stores of pair pr+1 while a slow one still reads zbuf of pair pr: fence the reuse
-        __syncthreads();
+        if constexpr (K > 1) __syncthreads();
     }
 }
 

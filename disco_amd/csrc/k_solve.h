@@ -21,9 +21,14 @@ namespace disco {
 #ifndef DISCO_SOLVE_PACKED
 #define DISCO_SOLVE_PACKED 1
 #endif
-// squaring stops one step after 1 - tr(B^2) fell below this (the next square is then rank one to float64 rounding)
+// squaring stops one step after 1 - tr(B^2) fell below this: the sub-dominant weight rho is then < 5e-7 and the next
+// square, the one that is kept, carries rho^2 < 3e-13 (1e-8 instead of 1e-6 costs half a squaring on average and buys nothing
+// a float32 filter can show)
 #ifndef DISCO_SQUARING_DONE
-#define DISCO_SQUARING_DONE 1e-8
+#define DISCO_SQUARING_DONE 1e-6
+#endif
+#ifndef DISCO_SQ_ROWS
+#define DISCO_SQ_ROWS 1
 #endif
 #ifndef DISCO_SQUARINGS_MAX
 #define DISCO_SQUARINGS_MAX 40
@@ -223,7 +228,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     // is not needed: with B_0 = C / tr C,  B_{k+1} = B_k^2 / tr(B_k^2)  converges to v0 v0^H and the sub-dominant
     // directions decay like (d1/d0)^(2^k) -- 6-8 squarings for the ratios 0.5-0.9 met on real covariances, P^2 complex
     // multiply-adds per lane each (a Jacobi SWEEP costs ~5 P^2).  tau_k = tr(B_k^2) = ||B_k||_F^2 <= 1 doubles as the
-    // normaliser and the convergence measure: 1 - tau ~ 2 (d1/d0)^(2^k), so once it is below 1e-8 the NEXT square is
+    // normaliser and the convergence measure: 1 - tau ~ 2 (d1/d0)^(2^k), so once it is below DISCO_SQUARING_DONE the NEXT square is
     // rank one to rounding.  Lane j owns column j; the columns meet through the group's LDS matrix Ym (wave-level
     // fences only: a group never spans waves).  An exactly repeated top eigenvalue never converges (tau -> 1/m) and
     // stops at the iteration cap with a vector of the dominant subspace, which is all any solver can return there.
@@ -253,9 +258,9 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         c64 tc = make_double2(0.0, 0.0);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            // one row of B at a time: without the fences hipcc hoists all P^2 LDS loads (4 registers each) above the
-            // first multiply and the kernel drops to one wave per SIMD with spills at P = 15
-            DISCO_SCHED_FENCE();
+            // DISCO_SQ_ROWS rows of B at a time: without the fences hipcc hoists all P^2 LDS loads (4 registers each) above
+            // the first multiply and the kernel drops to one wave per SIMD with spills at P = 15
+            if (i % DISCO_SQ_ROWS == 0) DISCO_SCHED_FENCE();
             c64 a = make_double2(0.0, 0.0);
 #pragma unroll
             for (int k = 0; k < P; ++k) {
