@@ -24,6 +24,13 @@ class DiscoCfg(C.Structure):
                 ('pad_mode', C.c_int32), ('device', C.c_int32), ('flags', C.c_int32), ('reserved', C.c_int32 * 2)]
 
 
+class DiscoRefOutputs(C.Structure):
+    """struct disco_ref_outputs: device pointers of the nine returns of offline_tango (NULL = not wanted)."""
+    _fields_ = [(nm, C.c_void_p) for nm in ('yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w')]
+
+
+MASK_FOR_Z = {'local': 0, None: 1, 'distant': 2, 'compressed': 3, 'use_oracle_refs': 4, 'use_oracle_zs': 5, 'previous': 6}
+
 # name -> (restype, argtypes); every symbol the header declares
 _vp, _i64, _int, _sz, _f = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float
 PROTOTYPES = {
@@ -49,6 +56,7 @@ PROTOTYPES = {
     'disco_mask_oracle': (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     'disco_cov_masked': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     'disco_gevd_mwf_r1': (_int, [_vp, _vp, _vp, _i64, _int, _f, _vp, _vp, _vp]),
+    'disco_mwf_filter': (_int, [_vp, _vp, _vp, _i64, _int, _f, _int, _vp, _vp]),
     'disco_gevd_mwf_r1_pending': (_int, [_vp, _f, _vp, _vp, _vp]),
     'disco_apply': (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     'disco_noise_residual': (_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -64,6 +72,8 @@ PROTOTYPES = {
     'disco_ism_rir': (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f, _f, _vp, _int, _vp]),
     'disco_pair_stats': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp]),
     'disco_band_stats': (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
+    'disco_reference_workspace_bytes': (_sz, [_vp]),
+    'disco_tango_reference': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, C.POINTER(DiscoRefOutputs), _vp, _sz, _vp]),
     'disco_tango_enhance_iterated': (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     'disco_online_mwf': (_int, [_vp, _vp, _vp, _vp, _int, _f, _f, _int, _f, _vp, _vp, _vp]),
     'disco_tango_online': (_int, [_vp, _vp, _vp, _vp, _f, _int, _f, _vp, _vp, _vp, _vp, _sz, _vp]),

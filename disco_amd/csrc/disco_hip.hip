@@ -638,6 +638,32 @@ extern "C" int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const dis
     return solve_dispatch(ctx, src, n_prob, P, mu, w, t1, s);
 }
 
+// The two branches of intern_filter the hot path never takes (see k_mwf_variants)
+extern "C" int disco_mwf_filter(disco_ctx* ctx, const disco_c32* Rxx, const disco_c32* Rnn, int64_t n_prob, int P, float mu,
+                                int type, disco_c32* w, disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!Rxx || !Rnn || !w || n_prob < 1) return fail(ctx, DISCO_E_ARG, "disco_mwf_filter: bad argument");
+    if (type != DISCO_FILTER_R1_MWF && type != DISCO_FILTER_MWF) return fail(ctx, DISCO_E_ARG, "disco_mwf_filter: unknown filter type");
+    if (P < 1 || P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mwf_filter: P must be in 1..16");
+    if (n_prob / 4 > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mwf_filter: batch too large");
+    hipStream_t st = (hipStream_t)s;
+    switch (P) {
+#define C_(P_)                                                                                                          \
+    case P_: {                                                                                                          \
+        const dim3 grid((unsigned)((n_prob + SolveGeom<P_>::PROBS - 1) / SolveGeom<P_>::PROBS)), block(SolveGeom<P_>::THREADS);  \
+        if (type == DISCO_FILTER_MWF)                                                                                   \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mwf_variants<P_, FILTER_MWF>), grid, block, 0, st, (const c32*)Rxx, (const c32*)Rnn, \
+                               (long long)n_prob, (double)mu, (c32*)w);                                                 \
+        else                                                                                                            \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mwf_variants<P_, FILTER_R1_MWF>), grid, block, 0, st, (const c32*)Rxx, (const c32*)Rnn, \
+                               (long long)n_prob, (double)mu, (c32*)w);                                                 \
+    } break;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+#undef C_
+    }
+    return check_launch(ctx, "k_mwf_variants");
+}
+
 extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w, disco_c32* t1, disco_stream s) {
     DISCO_ENTER(ctx);
     if (!w) return fail(ctx, DISCO_E_ARG, "disco_gevd_mwf_r1_pending: null argument");
@@ -1104,6 +1130,172 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
     }
     if ((rc = STAGE(ctx, s, "step2_apply", disco_step2_apply_fused(ctx, X, w_loc, w_glo, nullptr, yo, s)))) return rc;
     return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
+}
+
+// ---- reference outputs: all nine returns of offline_tango, device resident ------------------------------------------------
+namespace {
+struct RefLayout {
+    size_t Xy, Xs, Xn, zy, zs, zn_, znres, rows_s, rows_n, mz, mw, mc, Rss, Rnn, Rtmp, w_loc, w_glo, total;
+};
+RefLayout ref_layout(const disco_ctx* ctx) {
+    const disco_cfg& c = ctx->cfg;
+    const size_t G = (size_t)c.rooms * c.nodes, TF = (size_t)ctx->T * ctx->F;
+    const size_t Pmax = (size_t)c.mics + c.nodes - 1;
+    RefLayout l;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes); return at; };
+    l.Xy = take(G * TF * c.mics * sizeof(c32));
+    l.Xs = take(G * TF * c.mics * sizeof(c32));
+    l.Xn = take(G * TF * c.mics * sizeof(c32));
+    l.zy = take(G * TF * sizeof(c32));
+    l.zs = take(G * TF * sizeof(c32));
+    l.zn_ = take(G * TF * sizeof(c32));
+    l.znres = take(G * TF * sizeof(c32));
+    l.rows_s = take(G * TF * sizeof(c32));
+    l.rows_n = take(G * TF * sizeof(c32));
+    l.mz = take(G * TF * sizeof(float));
+    l.mw = take(G * TF * sizeof(float));
+    l.mc = take(G * TF * sizeof(float));
+    l.Rss = take(G * ctx->F * c.mics * c.mics * sizeof(c32));
+    l.Rnn = take(G * ctx->F * c.mics * c.mics * sizeof(c32));
+    l.Rtmp = take(G * ctx->F * c.mics * c.mics * sizeof(c32));
+    l.w_loc = take(G * ctx->F * c.mics * sizeof(c32));
+    l.w_glo = take(G * ctx->F * Pmax * sizeof(c32));
+    l.total = o;
+    return l;
+}
+inline unsigned ew_grid(long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 16384); }
+}  // namespace
+
+extern "C" size_t disco_reference_workspace_bytes(const disco_ctx* ctx) { return ctx ? ref_layout(ctx).total : 0; }
+
+extern "C" int disco_tango_reference(disco_ctx* ctx, const float* y, const float* s_img, const float* n_img, const float* mask_z_in,
+                                     const float* mask_w_in, int mask_for_z, int steps, const disco_ref_outputs* out,
+                                     void* workspace, size_t workspace_bytes, disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!y || !s_img || !n_img || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_reference: null argument");
+    if (steps < 1 || steps > 3) return fail(ctx, DISCO_E_ARG, "disco_tango_reference: steps must be 1, 2 or 3");
+    if (mask_for_z < DISCO_MZ_LOCAL || mask_for_z > DISCO_MZ_PREVIOUS) return fail(ctx, DISCO_E_ARG, "disco_tango_reference: unknown mask_for_z");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_reference: node shard active");
+    const disco_cfg& c = ctx->cfg;
+    if (c.mask_type < DISCO_MASK_IRM || c.mask_type > DISCO_MASK_IAM) return fail(ctx, DISCO_E_ARG, "disco_tango_reference: unknown mask type");
+    const int M = c.mics, K = c.nodes, P2 = M + K - 1;
+    if (P2 > CB_PMAX || M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_reference: M + K - 1 > 16 or M > 8");
+    // the workspace: the caller's, or a context-owned one kept in `own_ws` (shared with the enhanced-output entry points)
+    const RefLayout l = ref_layout(ctx);
+    char* ws = (char*)workspace;
+    if (ws) {
+        if (workspace_bytes < l.total) return fail(ctx, DISCO_E_ARG, "disco_tango_reference: workspace too small");
+    } else {
+        if (ctx->own_ws_bytes < l.total) {
+            if (steps == 2) return fail(ctx, DISCO_E_ARG, "disco_tango_reference: steps = 2 needs the workspace of the preceding steps = 1 call");
+            if (ctx->own_ws) {
+                HIPCHK(ctx, hipFree(ctx->own_ws));
+                ctx->own_ws = nullptr;
+                ctx->own_ws_bytes = 0;
+            }
+            HIPCHK(ctx, hipMalloc(&ctx->own_ws, l.total));
+            ctx->own_ws_bytes = l.total;
+        }
+        ws = (char*)ctx->own_ws;
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int64_t G = (int64_t)c.rooms * K;
+    const long long nTF = (long long)G * ctx->T * ctx->F;
+    const size_t plane_b = (size_t)nTF * sizeof(c32), mask_b = (size_t)nTF * sizeof(float);
+    disco_c32 *Xy = (disco_c32*)(ws + l.Xy), *Xs = (disco_c32*)(ws + l.Xs), *Xn = (disco_c32*)(ws + l.Xn);
+    disco_c32 *zy = (disco_c32*)(ws + l.zy), *zs = (disco_c32*)(ws + l.zs), *zn_ = (disco_c32*)(ws + l.zn_), *znres = (disco_c32*)(ws + l.znres);
+    disco_c32 *rows_s = (disco_c32*)(ws + l.rows_s), *rows_n = (disco_c32*)(ws + l.rows_n);
+    float *mz = (float*)(ws + l.mz), *mw = (float*)(ws + l.mw), *mc = (float*)(ws + l.mc);
+    disco_c32 *Rss = (disco_c32*)(ws + l.Rss), *Rnn = (disco_c32*)(ws + l.Rnn), *Rtmp = (disco_c32*)(ws + l.Rtmp), *w_loc = (disco_c32*)(ws + l.w_loc), *w_glo = (disco_c32*)(ws + l.w_glo);
+    const float thr = powf(10.f, c.mask_bin_thr_db / 10.f);
+    const bool oracle_sigs = mask_for_z == DISCO_MZ_ORACLE_REFS || mask_for_z == DISCO_MZ_ORACLE_ZS;     // tango.py:343
+    auto give = [&](void* dst, const void* src, size_t bytes) -> int {
+        if (dst && dst != src) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    int rc;
+    if (steps & 1) {
+        // ---- STFTs of the mixture and of both images (tango.py:335-337)
+        if ((rc = disco_stft(ctx, y, G, M, Xy, s))) return rc;
+        if ((rc = disco_stft(ctx, s_img, G, M, Xs, s))) return rc;
+        if ((rc = disco_stft(ctx, n_img, G, M, Xn, s))) return rc;
+        // ---- step-1 mask at the reference microphone (tango.py:338-342)
+        if (mask_z_in) {
+            HIPCHK(ctx, hipMemcpyAsync(mz, mask_z_in, mask_b, hipMemcpyDeviceToDevice, st));
+        } else {
+            hipLaunchKernelGGL(k_tf_mask_channel, dim3(ew_grid(nTF)), dim3(256), 0, st, (const c32*)Xs, (const c32*)Xn, mz, nTF, M, c.ref_mic,
+                               c.mask_type, c.mask_pow, thr);
+            if ((rc = check_launch(ctx, "k_tf_mask_channel"))) return rc;
+        }
+        // ---- step 1: local statistics, filter, compressed signals (tango.py:343-376)
+        if (oracle_sigs) {            // s_hat = S, n_hat = N: Rss from the target image alone, Rnn from the noise image alone
+            hipLaunchKernelGGL(k_fill_f32, dim3(ew_grid(nTF)), dim3(256), 0, st, mc, 1.f, nTF);
+            if ((rc = disco_cov_masked(ctx, Xs, mc, nullptr, nullptr, 0, M, Rss, Rtmp, s))) return rc;      // mask 1: Rss = <S S^H>  (Rtmp = 0)
+            hipLaunchKernelGGL(k_fill_f32, dim3(ew_grid(nTF)), dim3(256), 0, st, mc, 0.f, nTF);
+            if ((rc = disco_cov_masked(ctx, Xn, mc, nullptr, nullptr, 0, M, Rtmp, Rnn, s))) return rc;      // mask 0: Rnn = <N N^H>  (Rtmp = 0)
+            if ((rc = disco_gevd_mwf_r1(ctx, Rss, Rnn, G * ctx->F, M, c.mu, w_loc, nullptr, s))) return rc;
+        } else {
+            int chunks = 1;
+            if ((rc = cov_partials(ctx, Xy, mz, nullptr, nullptr, 0, M, &chunks, s))) return rc;
+            if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s))) return rc;
+        }
+        if ((rc = disco_apply(ctx, Xy, nullptr, w_loc, M, 1, zy, s))) return rc;
+        if ((rc = disco_apply(ctx, Xs, nullptr, w_loc, M, 1, zs, s))) return rc;
+        if ((rc = disco_apply(ctx, Xn, nullptr, w_loc, M, 1, zn_, s))) return rc;
+        if ((rc = disco_noise_residual(ctx, Xy, zy, znres, s))) return rc;                                  // tango.py:376
+        if ((rc = give(out->z_y, zy, plane_b)) || (rc = give(out->z_s, zs, plane_b)) || (rc = give(out->z_n, zn_, plane_b)) ||
+            (rc = give(out->zn, znres, plane_b)) || (rc = give(out->masks_z, mz, mask_b)))
+            return rc;
+    }
+    if (!(steps & 2)) return 0;
+    // ---- step-2 mask at channel 0 (tango.py:388-394)
+    if (mask_w_in) {
+        HIPCHK(ctx, hipMemcpyAsync(mw, mask_w_in, mask_b, hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(k_tf_mask_channel, dim3(ew_grid(nTF)), dim3(256), 0, st, (const c32*)Xs, (const c32*)Xn, mw, nTF, M, 0,
+                           c.mask_type, c.mask_pow, thr);
+        if ((rc = check_launch(ctx, "k_tf_mask_channel"))) return rc;
+    }
+    if ((rc = give(out->mask_w, mw, mask_b))) return rc;
+    // ---- the exchanged rows (tango.py:396-429) and the global statistics (433-440)
+    const disco_c32 *Zs_rows = zy, *Zn_rows = zy;
+    int mask_remote = 0;
+    if (K > 1) {
+        switch (mask_for_z) {
+            case DISCO_MZ_LOCAL: mask_remote = 1; break;
+            case DISCO_MZ_NONE: Zn_rows = znres; break;
+            case DISCO_MZ_DISTANT:
+                hipLaunchKernelGGL(k_mask_rows, dim3(ew_grid(nTF)), dim3(256), 0, st, (const c32*)zy, (const float*)mw, (c32*)rows_s, (c32*)rows_n, nTF);
+                Zs_rows = rows_s;
+                Zn_rows = rows_n;
+                break;
+            case DISCO_MZ_COMPRESSED: {           // the sender's mask from ITS compressed target / noise (get_mask(z_s, z_n), tango.py:402-403)
+                hipLaunchKernelGGL(k_tf_mask, dim3(ew_grid(nTF)), dim3(256), 0, st, (const c32*)zs, (const c32*)zn_, mc, nTF, c.mask_type,
+                                   c.mask_pow, thr);
+                hipLaunchKernelGGL(k_mask_rows, dim3(ew_grid(nTF)), dim3(256), 0, st, (const c32*)zy, (const float*)mc, (c32*)rows_s, (c32*)rows_n, nTF);
+                Zs_rows = rows_s;
+                Zn_rows = rows_n;
+            } break;
+            case DISCO_MZ_ORACLE_REFS:
+                hipLaunchKernelGGL(k_pick_channel, dim3(ew_grid(nTF)), dim3(256), 0, st, (const c32*)Xs, (c32*)rows_s, nTF, M, c.ref_mic);
+                hipLaunchKernelGGL(k_pick_channel, dim3(ew_grid(nTF)), dim3(256), 0, st, (const c32*)Xn, (c32*)rows_n, nTF, M, c.ref_mic);
+                Zs_rows = rows_s;
+                Zn_rows = rows_n;
+                break;
+            case DISCO_MZ_ORACLE_ZS: Zs_rows = zs; Zn_rows = zn_; break;
+            default: break;                   // 'previous': unmasked z_y in both
+        }
+        if ((rc = check_launch(ctx, "reference rows"))) return rc;
+    }
+    int chunks2 = 1;
+    if ((rc = cov_partials(ctx, Xy, mw, K > 1 ? Zs_rows : nullptr, K > 1 ? Zn_rows : nullptr, mask_remote, P2, &chunks2, s))) return rc;
+    if ((rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s))) return rc;
+    // ---- the global filter on the mixture and on both images (tango.py:445-450); outputs straight into the caller's arrays
+    if (out->yf && (rc = disco_apply(ctx, Xy, K > 1 ? zy : nullptr, w_glo, P2, 1, out->yf, s))) return rc;
+    if (out->sf && (rc = disco_apply(ctx, Xs, K > 1 ? zs : nullptr, w_glo, P2, 1, out->sf, s))) return rc;
+    if (out->nf && (rc = disco_apply(ctx, Xn, K > 1 ? zn_ : nullptr, w_glo, P2, 1, out->nf, s))) return rc;
+    return 0;
 }
 
 // ---- online / adaptive mode ------------------------------------------------------------------------------

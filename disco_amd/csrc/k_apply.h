@@ -113,4 +113,27 @@ __global__ void k_noise_residual(const c32* __restrict__ X, const c32* __restric
     }
 }
 
+// ---- small elementwise helpers of the reference-output path (disco_tango_reference) ---------------------------------
+// tf_mask on ONE channel of two interleaved STFTs: mask[i] = tf_mask(S[i*M + ch], N[i*M + ch])   (tango.py:338-342, 391)
+__global__ void k_tf_mask_channel(const c32* __restrict__ S, const c32* __restrict__ Nn, float* __restrict__ mask, long long n, int M,
+                                  int ch, int mask_type, int mask_pow, float thr_lin);
+// the sender-side variants of mask_for_z (tango.py:396-405): zs = m z, zn = (1 - m) z
+__global__ void k_mask_rows(const c32* __restrict__ z, const float* __restrict__ m, c32* __restrict__ zs, c32* __restrict__ zn,
+                            long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const c32 v = z[i];
+        const float a = m[i], b = 1.f - m[i];
+        zs[i] = make_float2(a * v.x, a * v.y);
+        zn[i] = make_float2(b * v.x, b * v.y);
+    }
+}
+// plane[i] = X[i*M + ch]   ('use_oracle_refs': the remote rows are the oracle images at the reference microphone, tango.py:406-407)
+__global__ void k_pick_channel(const c32* __restrict__ X, c32* __restrict__ plane, long long n, int M, int ch) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        plane[i] = X[i * M + ch];
+}
+__global__ void k_fill_f32(float* __restrict__ p, float v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
 }  // namespace disco

@@ -134,16 +134,14 @@ __device__ __forceinline__ void solve_load_row(const SolveSrc& src, long long pi
     }
 }
 
-// The solve proper for the group of G lanes that owns one pencil: lane j (< P) passes row j of Rxx (rowA) and of Rnn
-// (rowB); Lm / Ym are the group's two LDS matrices.  Returns this lane's component of t1 and the scalar gain
-// d0 / (d0 + mu)  (w_j = t1_j * gain).  Contains wave-level fences and wave-wide votes: every lane of a wave must call it,
-// the same number of times.  REENTER: a fence first, so that a previous call's readers of Lm / Ym are done (callers in a loop).
-template <int P, bool REENTER>
-__device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* rowB, c64* Lm, c64 (*Ym)[SolveGeom<P>::YW],
-                                                 const int j, const double mu, c64& t1_j, double& gain_out) {
-    constexpr int G = SolveGeom<P>::G;
+// ---- building blocks of the group solves (a group of G lanes, lane j owns row / column j; Lm, Ym: the group's LDS) ----------
+
+// Cholesky factor of the Hermitian matrix whose row j lane j passes in `row` (only the lower triangle is used), left in Lm:
+// strict lower triangle = L, diagonal slots = (1 / L[c][c], L[c][c]).
+template <int P>
+__device__ __forceinline__ void group_cholesky(const c32* row, c64* Lm, const int j) {
     using SG = SolveGeom<P>;
-    if constexpr (REENTER) DISCO_GROUP_SYNC();
+    const c32* rowB = row;
     if (j < P) {
 #pragma unroll
         for (int c = 0; c < P; ++c) {
@@ -186,53 +184,13 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     }
     if (j == 0) Lm[SG::lt(P - 1, P - 1)] = make_double2(rd_prev, d_prev);
     DISCO_GROUP_SYNC();
+}
 
-    // ---- column j of Y = L^-1 Rxx   (Rxx[i][j] = conj(Rxx[j][i]): read row j, contiguous)
-    c64 y[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        DISCO_SCHED_FENCE();                            // one row of L at a time (see the squaring loop)
-        c64 a = make_double2((double)rowA[i].x, -(double)rowA[i].y);
-#pragma unroll
-        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], y[k]));
-        y[i] = zscale(a, Lm[SG::lt(i, i)].x);
-        // y is only stored under `j < P` below: without a use here hipcc sinks the whole substitution into that branch
-        // while its LDS loads stay outside, i.e. all of L is loaded (and spilled) first
-        DISCO_CONSUME(y[i].x);
-        DISCO_CONSUME(y[i].y);
-    }
-    if (j < P) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) Ym[i][j] = y[i];
-    }
-    DISCO_GROUP_SYNC();
-
-    // ---- column j of C = L^-1 Y^H  (C Hermitian): rhs = conj(row j of Y)
-    c64 g[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        DISCO_SCHED_FENCE();
-        c64 a = make_double2(0.0, 0.0);
-        if (j < P) a = make_double2(Ym[j][i].x, -Ym[j][i].y);
-#pragma unroll
-        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], g[k]));
-        g[i] = zscale(a, Lm[SG::lt(i, i)].x);
-        DISCO_CONSUME(g[i].x);                          // as above: lanes >= P carry zero columns, a branch hipcc would sink into
-        DISCO_CONSUME(g[i].y);
-    }
-
-    asm volatile("" ::: "memory");                           // L is not needed again before the back substitution
-
-    // ---- dominant eigenpair of C by repeated squaring.  rank = 1 keeps only (d0, v0) (internal_formulas.py:63-69), so
-    // the full diagonalisation a Jacobi solver performs (what this kernel did before: 5-7 sweeps of P(P-1)/2 rotations)
-    // is not needed: with B_0 = C / tr C,  B_{k+1} = B_k^2 / tr(B_k^2)  converges to v0 v0^H and the sub-dominant
-    // directions decay like (d1/d0)^(2^k) -- 6-8 squarings for the ratios 0.5-0.9 met on real covariances, P^2 complex
-    // multiply-adds per lane each (a Jacobi SWEEP costs ~5 P^2).  tau_k = tr(B_k^2) = ||B_k||_F^2 <= 1 doubles as the
-    // normaliser and the convergence measure: 1 - tau ~ 2 (d1/d0)^(2^k), so once it is below DISCO_SQUARING_DONE the NEXT square is
-    // rank one to rounding.  Lane j owns column j; the columns meet through the group's LDS matrix Ym (wave-level
-    // fences only: a group never spans waves).  An exactly repeated top eigenvalue never converges (tau -> 1/m) and
-    // stops at the iteration cap with a vector of the dominant subspace, which is all any solver can return there.
-    // The loop is wave-uniform (vote on the exit): groups that are done keep their B and idle.
+// Dominant eigenvector of the Hermitian matrix whose column j lane j passes in g (destroyed): v0 (unit norm, every lane gets
+// all of it).  Returns false when the matrix is zero or not finite (v0 = e0 then).
+template <int P>
+__device__ __forceinline__ bool group_dominant(c64* g, c64 (*Ym)[SolveGeom<P>::YW], const int j, c64* v0) {
+    constexpr int G = SolveGeom<P>::G;
     bool done;
     {
         double trl = 0.0;
@@ -313,7 +271,6 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
             bj = oj;
         }
     }
-    c64 v0[P];
     const bool have = best > 0.0;                          // false: C = 0 or not finite -> v0 = e0 (d0 is clamped below)
     const double rb = have ? rsqrt64(best) : 0.0;
 #pragma unroll
@@ -323,9 +280,14 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         if (have) v0[i] = zscale(v0[i], rb);
         else v0[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
     }
+    return have;
+}
 
+// q = L^-H v (back substitution against the factor group_cholesky left in Lm); every lane computes all of q
+template <int P>
+__device__ __forceinline__ void group_back_substitute(const c64* v0, const c64* Lm, c64* q) {
+    using SG = SolveGeom<P>;
     // ---- q = L^-H v0 (back substitution); the diagonal slots hold (1 / L[i][i], L[i][i])
-    c64 q[P];
 #pragma unroll
     for (int i = P - 1; i >= 0; --i) {
         DISCO_SCHED_FENCE();
@@ -334,6 +296,85 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
         for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Lm[SG::lt(k, i)].x, -Lm[SG::lt(k, i)].y), q[k]));
         q[i] = zscale(a, Lm[SG::lt(i, i)].x);
     }
+}
+
+// x = L^-1 b (forward substitution), in place; every lane computes all of it
+template <int P>
+__device__ __forceinline__ void group_forward_substitute(c64* b, const c64* Lm) {
+    using SG = SolveGeom<P>;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        DISCO_SCHED_FENCE();
+        c64 a = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], b[k]));
+        b[i] = zscale(a, Lm[SG::lt(i, i)].x);
+    }
+}
+
+// The solve proper for the group of G lanes that owns one pencil: lane j (< P) passes row j of Rxx (rowA) and of Rnn
+// (rowB); Lm / Ym are the group's two LDS matrices.  Returns this lane's component of t1 and the scalar gain
+// d0 / (d0 + mu)  (w_j = t1_j * gain).  Contains wave-level fences and wave-wide votes: every lane of a wave must call it,
+// the same number of times.  REENTER: a fence first, so that a previous call's readers of Lm / Ym are done (callers in a loop).
+template <int P, bool REENTER>
+__device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* rowB, c64* Lm, c64 (*Ym)[SolveGeom<P>::YW],
+                                                 const int j, const double mu, c64& t1_j, double& gain_out) {
+    constexpr int G = SolveGeom<P>::G;
+    using SG = SolveGeom<P>;
+    if constexpr (REENTER) DISCO_GROUP_SYNC();
+    group_cholesky<P>(rowB, Lm, j);
+
+    // ---- column j of Y = L^-1 Rxx   (Rxx[i][j] = conj(Rxx[j][i]): read row j, contiguous)
+    c64 y[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        DISCO_SCHED_FENCE();                            // one row of L at a time (see the squaring loop)
+        c64 a = make_double2((double)rowA[i].x, -(double)rowA[i].y);
+#pragma unroll
+        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], y[k]));
+        y[i] = zscale(a, Lm[SG::lt(i, i)].x);
+        // y is only stored under `j < P` below: without a use here hipcc sinks the whole substitution into that branch
+        // while its LDS loads stay outside, i.e. all of L is loaded (and spilled) first
+        DISCO_CONSUME(y[i].x);
+        DISCO_CONSUME(y[i].y);
+    }
+    if (j < P) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) Ym[i][j] = y[i];
+    }
+    DISCO_GROUP_SYNC();
+
+    // ---- column j of C = L^-1 Y^H  (C Hermitian): rhs = conj(row j of Y)
+    c64 g[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        DISCO_SCHED_FENCE();
+        c64 a = make_double2(0.0, 0.0);
+        if (j < P) a = make_double2(Ym[j][i].x, -Ym[j][i].y);
+#pragma unroll
+        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], g[k]));
+        g[i] = zscale(a, Lm[SG::lt(i, i)].x);
+        DISCO_CONSUME(g[i].x);                          // as above: lanes >= P carry zero columns, a branch hipcc would sink into
+        DISCO_CONSUME(g[i].y);
+    }
+
+    asm volatile("" ::: "memory");                           // L is not needed again before the back substitution
+
+    // ---- dominant eigenpair of C by repeated squaring.  rank = 1 keeps only (d0, v0) (internal_formulas.py:63-69), so
+    // the full diagonalisation a Jacobi solver performs (what this kernel did before: 5-7 sweeps of P(P-1)/2 rotations)
+    // is not needed: with B_0 = C / tr C,  B_{k+1} = B_k^2 / tr(B_k^2)  converges to v0 v0^H and the sub-dominant
+    // directions decay like (d1/d0)^(2^k) -- 6-8 squarings for the ratios 0.5-0.9 met on real covariances, P^2 complex
+    // multiply-adds per lane each (a Jacobi SWEEP costs ~5 P^2).  tau_k = tr(B_k^2) = ||B_k||_F^2 <= 1 doubles as the
+    // normaliser and the convergence measure: 1 - tau ~ 2 (d1/d0)^(2^k), so once it is below DISCO_SQUARING_DONE the NEXT square is
+    // rank one to rounding.  Lane j owns column j; the columns meet through the group's LDS matrix Ym (wave-level
+    // fences only: a group never spans waves).  An exactly repeated top eigenvalue never converges (tau -> 1/m) and
+    // stops at the iteration cap with a vector of the dominant subspace, which is all any solver can return there.
+    // The loop is wave-uniform (vote on the exit): groups that are done keep their B and idle.
+    c64 v0[P];
+    const bool have = group_dominant<P>(g, Ym, j, v0);
+
+    c64 q[P];
+    group_back_substitute<P>(v0, Lm, q);
     const double l00 = Lm[SG::lt(0, 0)].y;
     // ---- d0 = v0^H C v0 = q^H Rxx q  (q^H Rnn q = |v0|^2 = 1): lane j forms (Rxx q)_j from its row of Rxx
     double d0;
@@ -391,6 +432,87 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, SolveGeom<P>::WPE) void k_ge
         if (t1_out) t1_out[pid * P + j] = make_float2((float)t1.x, (float)t1.y);
         w_out[pid * P + j] = make_float2((float)(t1.x * gain), (float)(t1.y * gain));
     }
+}
+
+// ---- the other two branches of intern_filter (internal_formulas.py:45-54, 74-76): dead on the hot path, offered so that the
+// function's whole surface (its DEFAULT type is 'r1-mwf') is there.  Same mapping and the same group primitives:
+//   'mwf'    : Wint = ((Rnn + Rxx)^-1 Rxx)[:, 0]                               -- one Cholesky solve
+//   'r1-mwf' : Rxx1 = |Dmax| x x^H (dominant eigenpair of Rxx alone); P = Rnn^-1 Rxx1; Wint = P[:, 0] / (mu + tr P)
+//              = |Dmax| conj(x_0) u / (mu + |Dmax| x^H u),  u = Rnn^-1 x      -- squaring + one Cholesky solve
+// (np.linalg.lstsq's minimum-norm answer for a singular matrix is NOT reproduced: the pivot floor of group_cholesky applies.)
+constexpr int FILTER_R1_MWF = 1, FILTER_MWF = 2;
+
+template <int P, int TYPE>
+__global__ __launch_bounds__(SolveGeom<P>::THREADS, SolveGeom<P>::WPE) void k_mwf_variants(const c32* __restrict__ Rxx,
+                                                                                          const c32* __restrict__ Rnn, long long n_prob,
+                                                                                          double mu, c32* __restrict__ w_out) {
+    constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
+    using SG = SolveGeom<P>;
+    __shared__ c64 s_L[PROBS][SolveGeom<P>::LSZ];
+    __shared__ c64 s_Y[PROBS][P][SolveGeom<P>::YW];
+    const int j = threadIdx.x % G, slot = threadIdx.x / G;
+    const long long pid = (long long)blockIdx.x * PROBS + slot;
+    const bool col = pid < n_prob && j < P;
+    c32 rowA[P], rowB[P];                       // row j of Rxx / of the matrix to factor
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        rowA[c] = col ? Rxx[pid * P * P + j * P + c] : make_float2(0.f, 0.f);
+        const c32 b = col ? Rnn[pid * P * P + j * P + c] : make_float2(c == j ? 1.f : 0.f, 0.f);
+        rowB[c] = TYPE == FILTER_MWF ? make_float2(b.x + rowA[c].x, b.y + rowA[c].y) : b;
+    }
+    c64* Lm = s_L[slot];
+    c64 rhs[P];                                 // the right-hand side, all of it in every lane
+    double scale = 1.0;                         // 'r1-mwf': |Dmax|
+    if constexpr (TYPE == FILTER_MWF) {         // column 0 of Rxx = conj(row 0), which lane 0 of the group holds
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            rhs[i] = make_double2((double)__shfl(rowA[i].x, 0, G), -(double)__shfl(rowA[i].y, 0, G));
+    } else {                                    // dominant eigenpair of Rxx: column j = conj(row j)
+        c64 g[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) g[i] = make_double2((double)rowA[i].x, -(double)rowA[i].y);
+        group_dominant<P>(g, s_Y[slot], j, rhs);
+        // Dmax = x^H Rxx x: lane j forms (Rxx x)_j from its row
+        c64 sj = make_double2(0.0, 0.0), xj = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            sj.x = fma((double)rowA[c].x, rhs[c].x, fma(-(double)rowA[c].y, rhs[c].y, sj.x));
+            sj.y = fma((double)rowA[c].x, rhs[c].y, fma((double)rowA[c].y, rhs[c].x, sj.y));
+            if (c == j) xj = rhs[c];
+        }
+        double e = j < P ? xj.x * sj.x + xj.y * sj.y : 0.0;
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) e += __shfl_xor(e, off, G);
+        scale = fabs(e);
+    }
+    group_cholesky<P>(rowB, Lm, j);
+    c64 x0 = rhs[0];                            // 'r1-mwf' needs x_0 and x^H u after the solve has overwritten nothing: keep x
+    c64 xk[TYPE == FILTER_R1_MWF ? P : 1];
+    if constexpr (TYPE == FILTER_R1_MWF) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) xk[i] = rhs[i];
+    }
+    group_forward_substitute<P>(rhs, Lm);
+    c64 u[P];
+    group_back_substitute<P>(rhs, Lm, u);
+    c64 wj = make_double2(0.0, 0.0);
+    if constexpr (TYPE == FILTER_MWF) {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            if (i == j) wj = u[i];
+    } else {
+        c64 xu = make_double2(0.0, 0.0);        // x^H u
+#pragma unroll
+        for (int i = 0; i < P; ++i) xu = zadd(xu, zmul(make_double2(xk[i].x, -xk[i].y), u[i]));
+        const c64 den = make_double2(mu + scale * xu.x, scale * xu.y);
+        const double rd = rcp64(den.x * den.x + den.y * den.y);
+        const c64 num = zscale(make_double2(x0.x, -x0.y), scale);                   // |Dmax| conj(x_0)
+        const c64 f = zmul(num, make_double2(den.x * rd, -den.y * rd));             // / (mu + tr P)
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            if (i == j) wj = zmul(u[i], f);
+    }
+    if (col) w_out[pid * P + j] = make_float2((float)wj.x, (float)wj.y);
 }
 
 }  // namespace disco

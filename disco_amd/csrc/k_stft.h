@@ -225,6 +225,12 @@ __global__ void k_tf_mask(const c32* __restrict__ S, const c32* __restrict__ Nn,
         mask[i] = tf_mask_value(S[i], Nn[i], mask_type, mask_pow, thr_lin);
 }
 
+__global__ void k_tf_mask_channel(const c32* __restrict__ S, const c32* __restrict__ Nn, float* __restrict__ mask, long long n, int M,
+                                  int ch, int mask_type, int mask_pow, float thr_lin) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        mask[i] = tf_mask_value(S[i * M + ch], Nn[i * M + ch], mask_type, mask_pow, thr_lin);
+}
+
 // ---- iSTFT --------------------------------------------------------------------------------------------
 // Z: [n_sig][T][F] -> out: [n_sig][L].  A block owns ISTFT_FRAMES consecutive frames of one signal (each wave
 // inverts two frames with one complex FFT), overlap-adds them in LDS and emits the ISTFT_FRAMES - 1 hop

@@ -326,6 +326,18 @@ class Engine:
                                              t1.ptr if want_t1 else None, self.stream))
         return w, t1
 
+    def mwf_filter(self, Rxx, Rnn, type='r1-mwf', mu=None):
+        """intern_filter's 'r1-mwf' / 'mwf' branches (internal_formulas.py:45-54, 74-76), batched: (..., P, P) -> w (..., P)."""
+        shape = tuple(Rxx.shape)
+        P = shape[-1]
+        n_prob = int(np.prod(shape[:-2], dtype=np.int64))
+        pa, ka = self.to_device(Rxx, np.complex64)
+        pb, kb = self.to_device(Rnn, np.complex64)
+        w = self.empty(shape[:-1], np.complex64)
+        self._chk(self.lib.disco_mwf_filter(self.ctx, pa, pb, n_prob, P, self.cfg.mu if mu is None else mu,
+                                            {'r1-mwf': 1, 'mwf': 2}[type], w.ptr, self.stream))
+        return w
+
     def gevd_mwf_r1_pending(self, P, mu=None, want_t1=False):
         """Solve straight from the partial sums the last covariance call left in the context."""
         w = self.empty((self.R, self.Kl, self.F, P), np.complex64)
@@ -428,6 +440,26 @@ class Engine:
         yf = self.empty((self.R, self.K, self.T, self.F), np.complex64)
         self._chk(self.lib.disco_tango_enhance_iterated(self.ctx, py, pmz, pmw, iters, out.ptr, None, yf.ptr, None, 0, self.stream))
         return out, yf
+
+    def tango_reference(self, y, s, n, mask_z=None, mask_w=None, mask_for_z='local', steps=3, want=None):
+        """offline_tango's nine outputs in ONE device-resident call (disco_tango_reference): y, s, n (R,K,M,L) float32;
+        mask_z / mask_w (R,K,T,F) float32 or None (oracle TF masks of the engine's mask type); steps 1 | 2 | 3.
+        Returns {name: DevBuf (R,K,T,F)} for the names in `want` (default: all that the requested steps produce)."""
+        step1 = ('z_y', 'z_s', 'z_n', 'zn', 'masks_z')
+        step2 = ('yf', 'sf', 'nf', 'mask_w')
+        names = [nm for nm in (step1 if steps & 1 else ()) + (step2 if steps & 2 else ())]
+        if want is not None:
+            names = [nm for nm in names if nm in want]
+        py, ky = self.to_device(y, np.float32)
+        ps, ks = self.to_device(s, np.float32)
+        pn, kn = self.to_device(n, np.float32)
+        pmz, kmz = self.to_device(mask_z, np.float32)
+        pmw, kmw = (pmz, kmz) if (mask_w is mask_z and mask_z is not None) else self.to_device(mask_w, np.float32)
+        bufs = {nm: self.empty((self.R, self.K, self.T, self.F), np.float32 if nm.startswith('mask') else np.complex64) for nm in names}
+        outs = L.DiscoRefOutputs(**{nm: b.ptr for nm, b in bufs.items()})
+        self._chk(self.lib.disco_tango_reference(self.ctx, py, ps, pn, pmz, pmw, L.MASK_FOR_Z[mask_for_z], steps, C.byref(outs), None, 0,
+                                                 self.stream))
+        return bufs
 
     # ---- whole path
     def workspace_bytes(self):

@@ -1,8 +1,9 @@
 """`intern_filter` with the reference's signature (disco_theque/se_utils/internal_formulas.py:31-81), on the MI355X.
 
-Only the branch the hot path uses is implemented on the GPU: type='gevd', rank=1 (tango.py:367, 443).  The other
-branches of the reference ('r1-mwf', 'mwf') are dead on the hot path and raise NotImplementedError;
-an unknown type raises AttributeError and the default rank='Full' raises TypeError, exactly like the reference."""
+All three branches run on the GPU: type='gevd' with rank=1 is the one the hot path uses (tango.py:367, 443); 'r1-mwf'
+(the function's default type, internal_formulas.py:45-54) and 'mwf' (:74-76) are dead there and offered for
+completeness (disco_mwf_filter).  An unknown type raises AttributeError and type='gevd' with the default rank='Full'
+raises TypeError, exactly like the reference."""
 import numpy as np
 
 from .._engines import get_engine
@@ -14,8 +15,15 @@ eta = 1e6                        # internal_formulas.py:7
 def intern_filter(Rxx, Rnn, mu=1, type='r1-mwf', rank='Full'):
     """Returns (Wint, (t1, sort_index)).  Wint, t1: complex128 (P,) arrays (computed in float64 on the GPU, returned
     through complex64).  sort_index is None: the GPU solver extracts only the dominant generalized eigenpair."""
-    if type in ('r1-mwf', 'mwf'):
-        raise NotImplementedError("intern_filter: only type='gevd', rank=1 (the hot-path branch) runs on the GPU")
+    if type in ('r1-mwf', 'mwf'):                                             # `rank` is not looked at by these branches
+        Rxx = np.ascontiguousarray(Rxx, dtype=np.complex64)
+        Rnn = np.ascontiguousarray(Rnn, dtype=np.complex64)
+        assert Rxx.shape == Rnn.shape and Rxx.ndim == 2 and Rxx.shape[0] == Rxx.shape[1]
+        eng = get_engine(rooms=1, nodes=1, mics=1, length=1024)
+        w = eng.mwf_filter(Rxx[None], Rnn[None], type=type, mu=float(mu)).numpy()[0].astype(np.complex128)
+        t1 = np.zeros(Rxx.shape[0])
+        t1[0] = 1.0                                                           # internal_formulas.py:43 (e1, untouched by these branches)
+        return w, (t1, None)
     if type != 'gevd':
         raise AttributeError('Unknown filter reference')                      # internal_formulas.py:79
     if not isinstance(rank, (int, np.integer)):

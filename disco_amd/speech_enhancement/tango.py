@@ -28,7 +28,7 @@ def _as_batch(x):
 def _mask_names(vads, mods=None):
     if isinstance(vads, str):
         vads = [vads, vads]
-    mods = [None, None] if mods is None else list(mods)
+    mods = [None, None] if mods is None else list(mods) + [None] * max(0, 2 - len(mods))
     for i, v in enumerate(vads[:2]):
         if v[:-1] in ('irm', 'ibm', 'iam') or v == 'ivad':
             continue
@@ -66,47 +66,57 @@ def _get_mask(eng, Sh_c, Nh_c, ts, vad, mod=None, Yh_c=None, z_rows=None):
     return eng.tf_mask(np.ascontiguousarray(Sh_c), np.ascontiguousarray(Nh_c), type=vad).numpy().astype(np.float32)
 
 
+def _time_mask(eng, vad, s_ch, n_ch, y_ch=None, mod=None, z_rows=None, n_fft=N_FFT, pad_mode='reflect'):
+    """A mask the library does not compute by itself inside disco_tango_reference, as a device array (R, K, T, F):
+    'ivad' (frame VAD of the target image's time signal, tango.py:217-221), a TF mask of ANOTHER type than the engine's
+    (step 2 with vads[1] != vads[0]), or the CRNN's prediction from |STFT(y_ch)| [+ |z| of the other nodes]."""
+    R, K, L = s_ch.shape
+    if vad == 'ivad':
+        return eng.mask_ivad(np.ascontiguousarray(s_ch.reshape(R * K, L))).reshape(R, K, eng.T, eng.F)
+    if vad == 'crnn':
+        import torch
+        Yc = eng.stft(np.ascontiguousarray(y_ch.reshape(R * K, 1, L))).numpy().reshape(R * K, 1, eng.T, eng.F)
+        mag = np.abs(Yc)
+        if z_rows is not None:
+            mag = np.concatenate([mag, np.abs(z_rows).reshape(R * K, -1, eng.T, eng.F)], axis=1)
+        par = next(mod.parameters())
+        with torch.no_grad():
+            m = mod.predict_masks(torch.from_numpy(np.ascontiguousarray(mag)).to(par.device, par.dtype))
+        return np.ascontiguousarray(m.float().cpu().numpy().reshape(R, K, eng.T, eng.F))
+    other = get_engine(rooms=R, nodes=K, mics=1, length=L, n_fft=n_fft, mask=vad, pad_mode=pad_mode)
+    return other.mask_oracle(np.ascontiguousarray(s_ch.reshape(R * K, L)), np.ascontiguousarray(n_ch.reshape(R * K, L))).numpy() \
+        .reshape(R, K, eng.T, eng.F)
+
+
 def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_sigs='zs_hat', n_fft=N_FFT,
-                          pad_mode='reflect', ref_mic=0, mu=1.0):
+                          pad_mode='reflect', ref_mic=0, mu=1.0, steps=3):
     """y, s, n: (R, K, M, L) float32.  Returns a dict of device-computed arrays with a leading room axis, in the
-    engine's frame-major layout (R, K, T, F): yf, sf, nf, z_y, z_s, z_n, zn, masks_z, mask_w."""
+    engine's frame-major layout (R, K, T, F): yf, sf, nf, z_y, z_s, z_n, zn, masks_z, mask_w (steps=1: the step-1 five).
+    The whole path is ONE library call (disco_tango_reference: STFTs, masks, statistics, solves, every mask_for_z variant and
+    the three filter passes stay on the device); only 'ivad' / DNN masks are prepared outside it and passed in."""
     vads = _mask_names(vads, mods)
-    mods = [None, None] if mods is None else list(mods)
+    mods = [None, None] if mods is None else list(mods) + [None] * (2 - len(mods))
     MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous')
     if mask_for_z not in MODES:
         raise NotImplementedError(f'mask_for_z must be one of {MODES}')       # 'use_oracle_sigs' is broken in the reference
-    oracle_sigs = isinstance(mask_for_z, str) and 'use_oracle_' in mask_for_z
     y = np.ascontiguousarray(y, dtype=np.float32)
     s = np.ascontiguousarray(s, dtype=np.float32)
     n = np.ascontiguousarray(n, dtype=np.float32)
     R, K, M, L = y.shape
+    if mask_for_z == 'compressed' and vads[0] in ('ivad', 'crnn') and steps & 2:
+        raise NotImplementedError("mask_for_z='compressed' needs a TF mask type at step 1 (the reference passes neither a time signal nor z to get_mask there, tango.py:403)")
     eng = get_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=_engine_mask_type(vads[0]), pad_mode=pad_mode,
                      ref_mic=ref_mic, mu=mu, staged_step2=True)
-    T, F = eng.T, eng.F
-    G = R * K
-    Y = eng.stft(y.reshape(G, M, L)).reshape(R, K, T, F, M)
-    S = eng.stft(s.reshape(G, M, L)).reshape(R, K, T, F, M)
-    N = eng.stft(n.reshape(G, M, L)).reshape(R, K, T, F, M)
-    Sh, Nh = S.numpy(), N.numpy()
-    # masks at the reference mic (step 1, tango.py:338-342: ts = that channel's time signal) and at channel 0 (step 2,
-    # tango.py:391-394: ts = s[node][0])
-    Yh = Y.numpy() if 'crnn' in vads else None
-    mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], s[:, :, ref_mic].reshape(G, L), vads[0], mods[0],
-                   None if Yh is None else Yh[..., ref_mic])
-    if vads[1] != 'crnn':                                                      # a DNN step-2 mask needs z: after step 1
-        same = (vads[1] == vads[0]) and ref_mic == 0
-        mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], s[:, :, 0].reshape(G, L), vads[1])
-    # step 1 (tango.py:357-376)
-    if oracle_sigs:                                                            # statistics from the oracle images (tango.py:343-345)
-        Rss, _ = eng.cov_masked(S, np.ones_like(mz))
-        _, Rnn = eng.cov_masked(N, np.zeros_like(mz))
-        w_loc, _ = eng.gevd_mwf_r1(Rss, Rnn, want_t1=False)
-    else:
-        eng.cov_masked(Y, mz)
-        w_loc, _ = eng.gevd_mwf_r1_pending(M)
-    z_y, z_s, z_n = eng.apply(Y, w_loc), eng.apply(S, w_loc), eng.apply(N, w_loc)
-    zn = eng.noise_residual(Y, z_y)
-    out = dict(masks_z=mz, z_y=z_y.numpy(), z_s=z_s.numpy(), z_n=z_n.numpy(), zn=zn.numpy())
+    tf = lambda v: v[:-1] in ('irm', 'ibm', 'iam')
+    # masks the library cannot derive from (S, N) with the engine's own TF type (see _time_mask); None = computed inside
+    mz = None if tf(vads[0]) else _time_mask(eng, vads[0], s[:, :, ref_mic], n[:, :, ref_mic], y[:, :, ref_mic], mods[0],
+                                             n_fft=n_fft, pad_mode=pad_mode)
+    yd, sd, nd = eng.to_device(y, np.float32)[1], eng.to_device(s, np.float32)[1], eng.to_device(n, np.float32)[1]
+    need_z_for_mw = vads[1] == 'crnn' and mods[1] is not None
+    if steps == 1 or need_z_for_mw:
+        out = {k: v.numpy() for k, v in eng.tango_reference(yd, sd, nd, mask_z=mz, mask_for_z=mask_for_z, steps=1).items()}
+        if steps == 1:
+            return out
     if vads[1] == 'crnn':
         if mods[1] is None:                                                    # same predicted mask as at step 1 (tango.py:388-389)
             mw = mz
@@ -114,34 +124,17 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
             from ..dnn.crnn import get_z_for_mask
             rows = np.stack([np.stack([get_z_for_mask(out['z_y'][r], out['zn'][r], k, K, z_sigs) for k in range(K)])
                              for r in range(R)]) if K > 1 else None
-            mw = _get_mask(eng, None, None, None, 'crnn', mods[1], Yh[..., 0], rows)
-    out['mask_w'] = mw
-    # exchange + step 2 (tango.py:378-450)
-    if mask_for_z == 'local':
-        eng.cov_masked(Y, mw, z_y, z_y, mask_remote=True)
-    elif mask_for_z is None:                                                   # unmasked z / zn rows (tango.py:419-422)
-        eng.cov_masked(Y, mw, z_y, zn, mask_remote=False)
-    else:                                                                      # sender-side variants (tango.py:396-409): the
-        zy = out['z_y']                                                        # remote rows are prepared on the host, then fed
-        if mask_for_z == 'distant':                                            # to the same covariance kernel unmasked
-            zs_rows, zn_rows = zy * mw, zy * (1 - mw)
-        elif mask_for_z == 'compressed':
-            if vads[0] in ('ivad', 'crnn'):
-                raise NotImplementedError("mask_for_z='compressed' needs a TF mask type at step 1 (the reference passes neither a time signal nor z to get_mask there, tango.py:403)")
-            mc = eng.tf_mask(out['z_s'], out['z_n'], type=vads[0]).numpy()
-            zs_rows, zn_rows = zy * mc, zy * (1 - mc)
-        elif mask_for_z == 'use_oracle_refs':
-            zs_rows, zn_rows = np.ascontiguousarray(Sh[..., ref_mic]), np.ascontiguousarray(Nh[..., ref_mic])
-        elif mask_for_z == 'use_oracle_zs':
-            zs_rows, zn_rows = out['z_s'], out['z_n']
-        else:                                                                  # 'previous': the reference's final else
-            zs_rows, zn_rows = zy, zy                                          # (tango.py:428-429), unmasked z_y in both
-        eng.cov_masked(Y, mw, zs_rows.astype(np.complex64), zn_rows.astype(np.complex64), mask_remote=False)
-    w_glo, _ = eng.gevd_mwf_r1_pending(M + K - 1)
-    out['yf'] = eng.apply(Y, w_glo, Z=z_y if K > 1 else None).numpy()
-    out['sf'] = eng.apply(S, w_glo, Z=z_s if K > 1 else None).numpy()
-    out['nf'] = eng.apply(N, w_glo, Z=z_n if K > 1 else None).numpy()
-    return out
+            mw = _time_mask(eng, 'crnn', s[:, :, 0], n[:, :, 0], y[:, :, 0], mods[1], rows, n_fft=n_fft, pad_mode=pad_mode)
+    elif tf(vads[1]) and tf(vads[0]) and vads[1] == vads[0]:
+        mw = None                                                              # the library's own tf_mask at channel 0
+    elif vads[1] == vads[0] and ref_mic == 0:
+        mw = mz                                                                # 'ivad' twice on the same channel
+    else:
+        mw = _time_mask(eng, vads[1], s[:, :, 0], n[:, :, 0], n_fft=n_fft, pad_mode=pad_mode)
+    if need_z_for_mw:
+        out.update({k: v.numpy() for k, v in eng.tango_reference(yd, sd, nd, mask_z=mz, mask_w=mw, mask_for_z=mask_for_z, steps=2).items()})
+        return out
+    return {k: v.numpy() for k, v in eng.tango_reference(yd, sd, nd, mask_z=mz, mask_w=mw, mask_for_z=mask_for_z, steps=3).items()}
 
 
 def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='reflect', ref_mic=0, mu=1.0):

@@ -159,6 +159,16 @@ int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask,
 int disco_gevd_mwf_r1(disco_ctx* ctx, const disco_c32* Rss, const disco_c32* Rnn, int64_t n_prob, int P,
                       float mu, disco_c32* w, disco_c32* t1, disco_stream s);
 
+/* intern_filter's other two branches (internal_formulas.py:45-54 'r1-mwf' -- the function's DEFAULT type -- and :74-76 'mwf');
+ * neither is reached by offline_tango, both are here so that the whole function is:
+ *   DISCO_FILTER_R1_MWF  Rxx1 = |Dmax| x x^H (dominant eigenpair of Rxx); P = Rnn^-1 Rxx1; w = P[:, 0] / (mu + trace P)
+ *   DISCO_FILTER_MWF     w = ((Rnn + Rxx)^-1 Rxx)[:, 0]
+ * Rxx, Rnn [n_prob][P][P] -> w [n_prob][P]; t1 of these branches is e_1 (internal_formulas.py:43), the caller's to fill. */
+#define DISCO_FILTER_R1_MWF 1
+#define DISCO_FILTER_MWF    2
+int disco_mwf_filter(disco_ctx* ctx, const disco_c32* Rxx, const disco_c32* Rnn, int64_t n_prob, int P, float mu, int type,
+                     disco_c32* w, disco_stream s);
+
 /* The same solve, fed straight from the partial sums the LAST covariance call of this context left in its scratch
  * (any of disco_cov_masked / disco_stft_cov_fused / disco_step2_cov_fused; those accept Rss == Rnn == NULL when the
  * matrices themselves are not wanted).  Saves writing and re-reading the [R][K][F][P][P] matrices.
@@ -226,6 +236,35 @@ int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X, const disc
 int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w,
                         float* out, disco_c32* z_y, disco_c32* yf,
                         void* workspace, size_t workspace_bytes, disco_stream s);
+
+/* offline_tango(y, s, n, vads, mods, mask_for_z) with ALL nine outputs ("reference" outputs, tango.py:252-457), device
+ * resident: the target / noise images s, n ride through the same filters as the mixture so that the result can be scored
+ * (tango.py:541-593).  One call = the loop nests tango.py:326-450 in order; nothing returns to the host in between.
+ *   y, s, n      float [R][K][M][L]
+ *   mask_z_in    float [R][K][T][F] step-1 mask, or NULL: tf_mask(S, N, cfg.mask_type) at cfg.ref_mic     (tango.py:338-342)
+ *   mask_w_in    float [R][K][T][F] step-2 mask, or NULL: tf_mask(S, N, cfg.mask_type) at channel 0        (tango.py:391-394)
+ *                ('ivad' / DNN masks are computed by the caller -- disco_mask_ivad, the CRNN -- and passed in)
+ *   mask_for_z   DISCO_MZ_*: what the remote rows of the step-2 statistics are (tango.py:343-348, 396-429)
+ *   steps        1: step 1 only (get_z_signals.py:213-317); 3: both; 2: step 2 only, on the state a previous `steps = 1` call
+ *                with the same y, s, n left in the SAME workspace (a DNN step-2 mask needs z before it can be computed)
+ *   out          device pointers, each [R][K][T][F]; any of them may be NULL (not wanted)
+ * workspace: at least disco_reference_workspace_bytes(ctx) (three STFTs, the exchanged rows, filters), or NULL to let the
+ * context allocate and keep it. */
+#define DISCO_MZ_LOCAL        0   /* remote rows = z_y under the RECEIVING node's mask (the default, tango.py:36)        */
+#define DISCO_MZ_NONE         1   /* mask_for_z=None: z_y for Rss, zn for Rnn, unmasked       (tango.py:419-422)      */
+#define DISCO_MZ_DISTANT      2   /* z_y under the SENDER's step-2 mask                       (tango.py:396-401)      */
+#define DISCO_MZ_COMPRESSED   3   /* z_y under tf_mask(z_s, z_n) of the sender                (tango.py:402-405)      */
+#define DISCO_MZ_ORACLE_REFS  4   /* oracle images at the reference mics; oracle statistics   (tango.py:343-345, 406) */
+#define DISCO_MZ_ORACLE_ZS    5   /* z_s / z_n; oracle statistics at step 1                   (tango.py:408-409)      */
+#define DISCO_MZ_PREVIOUS     6   /* any other string in the reference: unmasked z_y in both  (tango.py:428-429)      */
+typedef struct disco_ref_outputs {
+    disco_c32 *yf, *sf, *nf, *z_y, *z_s, *z_n, *zn;
+    float *masks_z, *mask_w;
+} disco_ref_outputs;
+size_t disco_reference_workspace_bytes(const disco_ctx* ctx);
+int disco_tango_reference(disco_ctx* ctx, const float* y, const float* s, const float* n, const float* mask_z_in,
+                          const float* mask_w_in, int mask_for_z, int steps, const disco_ref_outputs* out,
+                          void* workspace, size_t workspace_bytes, disco_stream st);
 
 /* DANSE-style continuation of the two-step scheme (BASELINE.json configs[4]; NOT in the reference, which is strictly
  * two-step, tango.py:1-7): step 2 is run `iters` times, and between two runs every node re-compresses with the local part

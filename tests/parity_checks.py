@@ -766,3 +766,24 @@ def check_solver_degenerate(make_engine):
         Rss = np.zeros((3, P, P), np.complex64)
         w, t1 = eng.gevd_mwf_r1(Rss, Rnn)
         assert np.all(np.isfinite(w.numpy().view(np.float32))) and np.abs(w.numpy()).max() < 1e-12
+
+
+def check_enhanced_path_vs_long_golden(make_engine, golden_dir, staged=False):
+    """disco_tango_enhance (the path bench.py times: fused kernels, outputs=enhanced) against the reference's own z_y / yf on
+    the long golden scene, directly at 1e-4.  The masks are the reference's own (passed in as a DNN's would be)."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'tango_ref_long.npz'))
+    K, M, L = int(g['K']), int(g['M']), int(g['L'])
+    y = np.stack([g[f'y{k}'] for k in range(K)])[None]
+    m = np.stack([g[f'masks_z{k}'].T for k in range(K)])[None].astype(np.float32)          # (1, K, T, F)
+    eng = make_engine(rooms=1, nodes=K, mics=M, length=L, staged_step2=staged)
+    out, z, yf = eng.tango_enhance(y, m)
+    z, yf = z.numpy(), yf.numpy()
+    errs = {}
+    for k in range(K):
+        errs[f'z_y{k}'] = relerr(z[0, k].T, g[f'z_y{k}'])
+        errs[f'yf{k}'] = relerr(yf[0, k].T, g[f'yf{k}'])
+        ref_t = so.istft(g[f'yf{k}'], L, work_dtype=np.float64)
+        errs[f'out{k}'] = relerr(out.numpy()[0, k], ref_t)
+    assert max(errs.values()) < 1e-4, errs
+    return errs

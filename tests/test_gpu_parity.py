@@ -201,3 +201,8 @@ def test_full_size_properties(make_engine):
     gain on the inputs (w^H y scales linearly, masks unchanged); (iv) batch independence: room r of a batch
     equals the same room processed alone."""
     pc.check_size_independent_properties(make_engine, R=6, K=4, M=4, L=160000)
+
+
+@pytest.mark.parametrize('staged', [False, True])
+def test_enhanced_path_vs_long_reference_golden(make_engine, golden_dir, staged):
+    print(pc.check_enhanced_path_vs_long_golden(make_engine, golden_dir, staged=staged))

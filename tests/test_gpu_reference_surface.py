@@ -144,12 +144,19 @@ def test_offline_tango_errors():
 def test_intern_filter_vs_reference_golden(golden_dir):
     from disco_amd.se_utils.internal_formulas import intern_filter
     g = np.load(os.path.join(golden_dir, 'intern_filter_ref.npz'))
+    seen = set()
     for i in range(int(g['n_cases'])):
-        if str(g[f'c{i}_type']) != 'gevd':
-            continue
-        w, (t1, si) = intern_filter(g[f'c{i}_Rxx'], g[f'c{i}_Rnn'], mu=1, type='gevd', rank=1)
+        typ = str(g[f'c{i}_type'])
+        seen.add(typ)
+        if typ == 'gevd':
+            w, (t1, si) = intern_filter(g[f'c{i}_Rxx'], g[f'c{i}_Rnn'], mu=1, type='gevd', rank=1)
+        else:                                                   # 'r1-mwf' (the function's default type) and 'mwf'
+            w, (t1, si) = intern_filter(g[f'c{i}_Rxx'], g[f'c{i}_Rnn'], mu=1, type=typ)
         assert w.dtype == np.complex128 and si is None
-        assert relerr(w, g[f'c{i}_w']) < 2e-4 and relerr(t1, g[f'c{i}_t1']) < 2e-4
+        assert relerr(w, g[f'c{i}_w']) < 2e-4 and relerr(t1, g[f'c{i}_t1']) < 2e-4, (i, typ)
+    assert seen == {'gevd', 'r1-mwf', 'mwf'}
+    w_default, _ = intern_filter(g['c0_Rxx'], g['c0_Rnn'])      # defaults: type='r1-mwf', rank='Full' (unused by that branch)
+    assert np.all(np.isfinite(w_default))
     R = np.eye(3, dtype=np.complex64)
     with pytest.raises(AttributeError):
         intern_filter(R, R, type='nope')
@@ -184,3 +191,19 @@ def test_my_stft_istft():
     assert np.abs(X - ref).max() / np.abs(ref).max() < 2e-6
     xr = my_istft(X, 16000)
     assert xr.shape == (16000,) and np.abs(xr - x).max() < 2e-5
+
+
+def test_long_reference_golden_scene_direct_1e4(golden_dir):
+    """The reference's OWN outputs on a longer, well-conditioned scene (tests/golden/make_golden_long.py: 101 frames, 2 x 3
+    microphones, every pencil well conditioned) against the HIP path DIRECTLY at the north star's 1e-4 -- no oracle in between."""
+    from disco_amd.speech_enhancement.tango import offline_tango
+    g = np.load(os.path.join(golden_dir, 'tango_ref_long.npz'))
+    K = int(g['K'])
+    y, s, n = ([g[f'{c}{k}'] for k in range(K)] for c in 'ysn')
+    res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mods=[None, None])
+    names = ['yf', 'sf', 'nf', 'z_y', 'z_s', 'z_n', 'zn', 'masks_z', 'mask_w']
+    for i, nm in enumerate(names):
+        for k in range(K):
+            if f'{nm}{k}' in g.files:
+                e = relerr(res[i][k], g[f'{nm}{k}'])
+                assert e < (2e-5 if 'mask' in nm else 1e-4), (nm, k, e)

@@ -122,3 +122,8 @@ def test_emu_tango_pinned_geometry(make_engine, K, M, L, n_fft, tuning):
     pairs per filter+iSTFT workgroup) pinned on a small batch through disco_set_tuning."""
     y, s, n = synth.make_rooms_numpy(2, K=K, M=M, L=L)
     print(pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, tuning=tuning))
+
+
+@pytest.mark.parametrize('staged', [False, True])
+def test_emu_enhanced_path_vs_long_reference_golden(make_engine, golden_dir, staged):
+    print(pc.check_enhanced_path_vs_long_golden(make_engine, golden_dir, staged=staged))

@@ -49,8 +49,8 @@ def test_intern_filter_argument_errors():
         intern_filter(R, R, type='nope')
     with pytest.raises(TypeError):
         intern_filter(R, R, type='gevd')               # default rank='Full', as in the reference
-    with pytest.raises(NotImplementedError):
-        intern_filter(R, R, type='mwf')
+    with pytest.raises(TypeError):
+        intern_filter(R, R, type='gevd', rank='full')  # the reference slices D[rank:, :] with it (internal_formulas.py:66-67)
 
 
 def test_offline_tango_argument_errors():
