@@ -598,6 +598,16 @@ extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float*
 
 template <int P>
 static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s) {
+    if constexpr (P <= 4) {             // one thread per pencil (k_solve_small.h)
+        const long long grid = (n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;
+        if (src.part)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1_thread<P, true>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, s, src, n_prob,
+                               mu, w, t1);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1_thread<P, false>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, s, src, n_prob,
+                               mu, w, t1);
+        return;
+    }
     const int probs = SolveGeom<P>::PROBS;
     const long long grid = (n_prob + probs - 1) / probs;
     if (src.part)
@@ -1331,11 +1341,18 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
     hipStream_t st = (hipStream_t)s;
     switch (P) {
 #define C_(P_)                                                                                                          \
-    case P_: {                                                                                                          \
+    case P_: {                          /* one thread per (room, node, bin) */                                          \
+        const long long grid = (a.n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;                              \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf_thread<P_>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, st, a); \
+    } break;
+        C_(1) C_(2) C_(3) C_(4)
+#undef C_
+#define C_(P_)                                                                                                          \
+    case P_: {                          /* a group of 8 / 16 lanes per (room, node, bin) */                             \
         const long long grid = (a.n_prob + SolveGeom<P_>::PROBS - 1) / SolveGeom<P_>::PROBS;                            \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf<P_>), dim3((unsigned)grid), dim3(SolveGeom<P_>::THREADS), 0, st, a); \
     } break;
-        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+        C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
 #undef C_
     }
     return check_launch(ctx, "k_online_mwf");

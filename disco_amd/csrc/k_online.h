@@ -14,6 +14,7 @@
 // launches of this kernel (step 1: P = M, Z = NULL -> z; step 2: P = M + K - 1, Z = z) with no other barrier.
 #pragma once
 #include "k_solve.h"
+#include "k_solve_small.h"
 
 namespace disco {
 
@@ -111,6 +112,87 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
         if (live && j == 0) a.out[(g * a.T + t) * a.F + f] = make_float2(orx, oix);
     }
     if (col && a.w_last) a.w_last[pid * P + j] = wj;
+}
+
+// P <= 4: one thread per (room, node, bin) with both smoothed matrices in its registers (lower triangles, float32) and the
+// thread-local float64 solve of k_solve_small.h; consecutive threads are consecutive bins, so the per-frame loads stay
+// contiguous.  Same recursion, same outputs as k_online_mwf.
+template <int P>
+__global__ __launch_bounds__(SOLVE_SMALL_THREADS) void k_online_mwf_thread(OnlineArgs a) {
+    constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
+    const long long pid = (long long)blockIdx.x * SOLVE_SMALL_THREADS + threadIdx.x;
+    const bool live = pid < a.n_prob;
+    const long long pc = live ? pid : 0;                  // dead threads walk problem 0 and write nothing
+    const long long g = pc / a.F;
+    const int f = (int)(pc % a.F);
+    const long long r = g / a.Kl;
+    const int k = a.k0 + (int)(g % a.Kl);
+    const int M = a.M;
+    const c32* xb = a.X + ((g * a.T) * a.F + f) * (long long)M;
+    const c32* zb = a.Z ? a.Z + ((r * a.K) * a.T) * a.F + f : nullptr;
+    const long long TF = (long long)a.T * a.F;
+    const float* mp = a.mask + (g * a.T) * a.F + f;
+    float a_d[P], b_d[P];
+    c32 a_o[NO], b_o[NO];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        a_d[i] = 0.f;
+        b_d[i] = a.init_diag;
+    }
+#pragma unroll
+    for (int q = 0; q < NO; ++q) a_o[q] = b_o[q] = make_float2(0.f, 0.f);
+    const float lam = a.lambda_cor, oml = 1.f - a.lambda_cor;
+    c32 wv[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) wv[i] = make_float2(0.f, 0.f);
+    int until_update = 0;
+    for (int t = 0; t < a.T; ++t) {
+        c32 v[P];
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            if (c < M) {
+                v[c] = xb[(long long)t * a.F * M + c];
+            } else {
+                const int jn = (c - M) < k ? (c - M) : (c - M) + 1;        // skip the node's own z
+                v[c] = zb ? zb[jn * TF + (long long)t * a.F] : make_float2(0.f, 0.f);
+            }
+        }
+        const float m = mp[(long long)t * a.F];
+        const float cs = oml * m, cn = oml * (1.f - m);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float p2 = v[i].x * v[i].x + v[i].y * v[i].y;
+            a_d[i] = lam * a_d[i] + cs * p2;
+            b_d[i] = lam * b_d[i] + cn * p2;
+#pragma unroll
+            for (int c = 0; c < i; ++c) {
+                const float pr = v[i].x * v[c].x + v[i].y * v[c].y;          // v_i conj(v_c)
+                const float pi = v[i].y * v[c].x - v[i].x * v[c].y;
+                const int q = i * (i - 1) / 2 + c;
+                a_o[q] = make_float2(lam * a_o[q].x + cs * pr, lam * a_o[q].y + cs * pi);
+                b_o[q] = make_float2(lam * b_o[q].x + cn * pr, lam * b_o[q].y + cn * pi);
+            }
+        }
+        if (until_update == 0) {                           // uniform: every problem updates at the same frames
+            c64 w[P], t1[P];
+            gevd_solve_thread<P>(a_d, a_o, b_d, b_o, a.mu, w, t1);
+#pragma unroll
+            for (int i = 0; i < P; ++i) wv[i] = make_float2((float)w[i].x, (float)w[i].y);
+            until_update = a.update_every;
+        }
+        --until_update;
+        float orx = 0.f, oix = 0.f;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            orx += wv[i].x * v[i].x + wv[i].y * v[i].y;
+            oix += wv[i].x * v[i].y - wv[i].y * v[i].x;
+        }
+        if (live) a.out[(g * a.T + t) * a.F + f] = make_float2(orx, oix);
+    }
+    if (live && a.w_last) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) a.w_last[pid * P + i] = wv[i];
+    }
 }
 
 }  // namespace disco

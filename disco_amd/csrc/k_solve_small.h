@@ -1,0 +1,262 @@
+// Rank-1 GEVD-MWF for SMALL pencils (P <= 4: every step-1 solve of a node with up to 4 microphones), one THREAD per
+// problem.  Same algorithm and the same float64 arithmetic as k_solve.h (Cholesky whitening, dominant eigenpair by
+// repeated squaring, back substitution; internal_formulas.py:56-73) -- but at this size a group of 4 lanes spends more
+// instructions on hand-offs (LDS round trips, fences, shuffle reductions) than on arithmetic, so everything lives in the
+// registers of one thread: no LDS, no shuffles, 64 problems per wave instead of 16.  The Hermitian matrices are held as
+// (real diagonal, strict lower triangle); B^2 is formed on that half only, which also keeps B exactly Hermitian.
+#pragma once
+#include "k_solve.h"
+
+namespace disco {
+
+template <int P>
+struct HermReg {                       // Hermitian P x P: d[i] = A[i][i] (real), o[i(i-1)/2 + k] = A[i][k], i > k
+    double d[P];
+    c64 o[P > 1 ? P * (P - 1) / 2 : 1];
+    __device__ __forceinline__ c64 at(int i, int k) const {       // i, k compile-time after unrolling
+        if (i == k) return make_double2(d[i], 0.0);
+        if (i > k) return o[i * (i - 1) / 2 + k];
+        const c64 v = o[k * (k - 1) / 2 + i];
+        return make_double2(v.x, -v.y);
+    }
+};
+
+// Rxx, Rnn given as (diag, strict lower triangle) in float32.  w, t1: this problem's P filter entries.
+// Contains a wave-wide vote: every lane of the wave must call it (dead lanes pass Rxx = 0, Rnn = I).
+template <int P>
+__device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a_o, const float* b_d, const c32* b_o, const double mu,
+                                                  c64* w, c64* t1) {
+    constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
+    auto lo = [](int i, int k) { return i * (i - 1) / 2 + k; };
+    auto A = [&](int i, int k) -> c64 {        // Rxx[i][k]
+        if (i == k) return make_double2((double)a_d[i], 0.0);
+        if (i > k) return make_double2((double)a_o[i * (i - 1) / 2 + k].x, (double)a_o[i * (i - 1) / 2 + k].y);
+        return make_double2((double)a_o[k * (k - 1) / 2 + i].x, -(double)a_o[k * (k - 1) / 2 + i].y);
+    };
+    // ---- Cholesky Rnn = L L^H with the pivot floor of k_solve.h (numerically singular noise statistics)
+    double Ld[P], rL[P];
+    c64 Lo[NO];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        const double a_cc = (double)b_d[c];
+        double d2 = a_cc;
+#pragma unroll
+        for (int k = 0; k < c; ++k) d2 -= Lo[lo(c, k)].x * Lo[lo(c, k)].x + Lo[lo(c, k)].y * Lo[lo(c, k)].y;
+        const double fl = fmax(1e-7 * a_cc, 1e-30);
+        const bool brk = !(d2 >= fl);
+        const double d2c = brk ? fl : d2;
+        const double rd = rsqrt64(d2c);
+        rL[c] = rd;
+        Ld[c] = d2c * rd;
+#pragma unroll
+        for (int i = c + 1; i < P; ++i) {
+            c64 s = make_double2((double)b_o[lo(i, c)].x, (double)b_o[lo(i, c)].y);
+#pragma unroll
+            for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lo[lo(i, k)], Lo[lo(c, k)]));
+            Lo[lo(i, c)] = brk ? make_double2(0.0, 0.0) : zscale(s, rd);
+        }
+    }
+    // ---- C = L^-1 Rxx L^-H, column by column; only the lower triangle is kept
+    HermReg<P> B;
+    double tr = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        // column j of C directly: C[:, j] = L^-1 (Rxx (L^-H e_j)); u = L^-H e_j has entries 0..j only
+        c64 yj[P], u[P];
+#pragma unroll
+        for (int i = P - 1; i >= 0; --i) {
+            c64 a = make_double2(i == j ? 1.0 : 0.0, 0.0);
+#pragma unroll
+            for (int k = i + 1; k < P; ++k)
+                if (k <= j) a = zsub(a, zmul(make_double2(Lo[lo(k, i)].x, -Lo[lo(k, i)].y), u[k]));
+            u[i] = i <= j ? zscale(a, rL[i]) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {            // yj = Rxx u
+            c64 a = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                if (k <= j) a = zadd(a, zmul(A(i, k), u[k]));
+            yj[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {            // c = L^-1 yj (in place)
+            c64 a = yj[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lo[lo(i, k)], yj[k]));
+            yj[i] = zscale(a, rL[i]);
+        }
+        B.d[j] = yj[j].x;
+        tr += yj[j].x;
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) B.o[lo(i, j)] = yj[i];
+    }
+    // ---- dominant eigenpair by repeated squaring of B = C / tr C (see k_solve.h); tau = tr(B^2) = ||B||_F^2 is real here
+    const bool ok = tr > 0.0 && tr < 1.7e308;
+    {
+        const double rt = ok ? rcp64(tr) : 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) B.d[i] = ok ? B.d[i] * rt : 0.0;
+#pragma unroll
+        for (int q = 0; q < NO; ++q) B.o[q] = ok ? zscale(B.o[q], rt) : make_double2(0.0, 0.0);
+    }
+    bool done = !ok || P == 1;
+    for (int it = 0; it < DISCO_SQUARINGS_MAX; ++it) {
+        if (!__any(!done)) break;
+        HermReg<P> S;
+        double tau = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            double dj = 0.0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const c64 b = B.at(j, k);
+                dj = fma(b.x, b.x, fma(b.y, b.y, dj));
+            }
+            S.d[j] = dj;
+            tau += dj;
+#pragma unroll
+            for (int i = j + 1; i < P; ++i) {
+                c64 a = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const c64 x = B.at(i, k), y = B.at(k, j);
+                    a.x = fma(x.x, y.x, fma(-x.y, y.y, a.x));
+                    a.y = fma(x.x, y.y, fma(x.y, y.x, a.y));
+                }
+                S.o[lo(i, j)] = a;
+            }
+        }
+        const double rtau = tau > 0.0 ? rcp64(tau) : 0.0;
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) B.d[i] = S.d[i] * rtau;
+#pragma unroll
+            for (int q = 0; q < NO; ++q) B.o[q] = zscale(S.o[q], rtau);
+        }
+        done = done || (1.0 - tau < DISCO_SQUARING_DONE) || !(tau > 0.0);
+    }
+    // ---- B = v0 v0^H: the longest column (ties: lowest index), normalised
+    c64 v0[P];
+    double best = -1.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double nj = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const c64 b = B.at(i, j);
+            nj += b.x * b.x + b.y * b.y;
+        }
+        if (nj > best) {
+            best = nj;
+#pragma unroll
+            for (int i = 0; i < P; ++i) v0[i] = B.at(i, j);
+        }
+    }
+    const bool have = best > 0.0;
+    const double rb = have ? rsqrt64(best) : 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) v0[i] = have ? zscale(v0[i], rb) : make_double2(i == 0 ? 1.0 : 0.0, 0.0);
+    // ---- q = L^-H v0, d0 = q^H Rxx q (q^H Rnn q = 1), t1 = q L[0][0] conj(v0[0]), w = t1 d0 / (d0 + mu)
+    c64 q[P];
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) {
+        c64 a = v0[i];
+#pragma unroll
+        for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Lo[lo(k, i)].x, -Lo[lo(k, i)].y), q[k]));
+        q[i] = zscale(a, rL[i]);
+    }
+    double d0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        c64 sj = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < P; ++k) sj = zadd(sj, zmul(A(i, k), q[k]));
+        d0 += q[i].x * sj.x + q[i].y * sj.y;
+    }
+    d0 = have ? d0 : 0.0;
+    const double dcl = fmin(fmax(d0, SOLVE_EPS), SOLVE_ETA);
+    const double gain = dcl / (dcl + mu);
+    const c64 gsc = make_double2(Ld[0] * v0[0].x, -Ld[0] * v0[0].y);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        t1[i] = zmul(q[i], gsc);
+        w[i] = zscale(t1[i], gain);
+    }
+}
+
+// (diag, strict lower triangle) of both matrices of problem pid, from full row-major matrices or from chunk partials
+template <int P, bool FROM_PART>
+__device__ __forceinline__ void solve_load_tri(const SolveSrc& src, long long pid, float* a_d, c32* a_o, float* b_d, c32* b_o) {
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) {
+            c32 rs, rn;                          // R[i][k], i >= k
+            if constexpr (!FROM_PART) {
+                rs = src.Rss[pid * P * P + i * P + k];
+                rn = src.Rnn[pid * P * P + i * P + k];
+            } else {
+                constexpr int NP = P * (P + 1) / 2;
+                const long long g = pid / src.F;
+                const int f = (int)(pid % src.F);
+                const bool loc = i < src.M_loc;                                   // upper-triangle entry (k, i): k <= i < M_loc
+                const int Pq = loc ? src.M_loc : P;
+                const int q = k * Pq - (k * (k - 1)) / 2 + (i - k);
+                const float4* base = loc ? src.part_loc : src.part;
+                const int nch = loc ? src.chunks_loc : src.chunks;
+                const long long npq = loc ? (long long)(src.M_loc * (src.M_loc + 1) / 2) : (long long)NP;
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int ch = 0; ch < nch; ++ch) {
+                    const float4 v = base[(((g * nch + ch) * src.F) + f) * npq + q];
+                    s.x += v.x;
+                    s.y += v.y;
+                    s.z += v.z;
+                    s.w += v.w;
+                }
+                rs = make_float2(s.x * src.inv_T, -s.y * src.inv_T);              // stored (k, i) -> R[i][k] = conj
+                rn = make_float2(s.z * src.inv_T, -s.w * src.inv_T);
+            }
+            if (i == k) {
+                a_d[i] = rs.x;
+                b_d[i] = rn.x;
+            } else {
+                a_o[i * (i - 1) / 2 + k] = rs;
+                b_o[i * (i - 1) / 2 + k] = rn;
+            }
+        }
+}
+
+constexpr int SOLVE_SMALL_THREADS = 128;
+
+template <int P, bool FROM_PART>
+__global__ __launch_bounds__(SOLVE_SMALL_THREADS) void k_gevd_mwf_r1_thread(SolveSrc src, long long n_prob, double mu,
+                                                                              c32* __restrict__ w_out, c32* __restrict__ t1_out) {
+    constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
+    const long long pid = (long long)blockIdx.x * SOLVE_SMALL_THREADS + threadIdx.x;
+    const bool live = pid < n_prob;
+    float a_d[P], b_d[P];
+    c32 a_o[NO], b_o[NO];
+    if (live) {
+        solve_load_tri<P, FROM_PART>(src, pid, a_d, a_o, b_d, b_o);
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            a_d[i] = 0.f;
+            b_d[i] = 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NO; ++q) a_o[q] = b_o[q] = make_float2(0.f, 0.f);
+    }
+    c64 w[P], t1[P];
+    gevd_solve_thread<P>(a_d, a_o, b_d, b_o, mu, w, t1);
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            w_out[pid * P + i] = make_float2((float)w[i].x, (float)w[i].y);
+            if (t1_out) t1_out[pid * P + i] = make_float2((float)t1[i].x, (float)t1[i].y);
+        }
+    }
+}
+
+}  // namespace disco
