@@ -70,6 +70,9 @@ PROTOTYPES = {
     'disco_mask_ivad': (_int, [_vp, _vp, _i64, _vp, _vp]),
     'disco_rir_convolve': (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _int, _vp]),
     'disco_ism_rir': (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f, _f, _vp, _int, _vp]),
+    'disco_gru_gates': (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    'disco_maxpool_last4': (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
+    'disco_crnn_windows': (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp]),
     'disco_pair_stats': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp]),
     'disco_band_stats': (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
     'disco_reference_workspace_bytes': (_sz, [_vp]),

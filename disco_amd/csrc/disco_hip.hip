@@ -1308,6 +1308,44 @@ extern "C" int disco_tango_reference(disco_ctx* ctx, const float* y, const float
     return 0;
 }
 
+// ---- helper of the mask-estimation DNN (disco_amd/dnn/crnn.py): the pointwise half of a GRU step -----------------------------
+extern "C" int disco_gru_gates(disco_ctx* ctx, const float* gi, int64_t gi_stride, const float* gh, const float* gh_bias,
+                               const float* h_prev, float* h_out, int64_t n, int H, disco_stream s) {
+    // ctx may be NULL (the DNN owns no context): the launch then goes to the calling thread's current device
+    if (!gi || !h_out || (!gh && !gh_bias) || n < 1 || H < 1 || gi_stride < 3 * (int64_t)H) return ctx ? fail(ctx, DISCO_E_ARG, "disco_gru_gates: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    const long long total = (long long)n * H;
+    hipLaunchKernelGGL(k_gru_gates, dim3((unsigned)std::min<long long>((total + 255) / 256, 65536)), dim3(256), 0, (hipStream_t)s, gi,
+                       (long long)gi_stride, gh, gh_bias, h_prev, h_out, (long long)n, H);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return DISCO_E_HIP_BASE - (int)e;
+    return 0;
+}
+
+extern "C" int disco_maxpool_last4(disco_ctx* ctx, const float* x, const float* bias, int64_t n_rows, int row_len, int rows_per_channel,
+                                   int channels, float* out, disco_stream s) {
+    if (!x || !out || n_rows < 1 || row_len < 4 || (bias && (rows_per_channel < 1 || channels < 1))) return ctx ? fail(ctx, DISCO_E_ARG, "disco_maxpool_last4: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    const long long total = (long long)n_rows * (row_len / 4);
+    hipLaunchKernelGGL(k_maxpool_last4, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)s, x, bias, out,
+                       (long long)n_rows, row_len, rows_per_channel > 0 ? rows_per_channel : 1, channels > 0 ? channels : 1);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
+}
+
+extern "C" int disco_crnn_windows(disco_ctx* ctx, const float* feat, int64_t B, int C, int Tp, int T, int W, int n_keep, float* out,
+                                  disco_stream s) {
+    if (!feat || !out || B < 1 || C < 1 || T < 1 || W < 1 || Tp < T + W - 1 || n_keep < 4 || n_keep % 4 || n_keep > C * W * 4 ||
+        ((uintptr_t)feat & 15) || ((uintptr_t)out & 15))
+        return ctx ? fail(ctx, DISCO_E_ARG, "disco_crnn_windows: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    const long long total = (long long)B * T * (n_keep / 4);
+    hipLaunchKernelGGL(k_crnn_windows, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)s,
+                       (const float4*)feat, (float4*)out, (long long)B, C, Tp, T, W, n_keep / 4);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
+}
+
 // ---- online / adaptive mode ------------------------------------------------------------------------------
 
 extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const float* mask, int P,

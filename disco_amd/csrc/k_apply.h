@@ -136,4 +136,66 @@ __global__ void k_fill_f32(float* __restrict__ p, float v, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// GRU cell, pointwise part (gate order r, z, n as torch.nn.GRU): the two matrix products are GEMMs of the caller,
+//   r = sigm(gi_r + gh_r), z = sigm(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h
+// gi: rows of 3H floats at stride gi_stride (a time slice of the all-steps input projection); gh [n][3H] or NULL with gh_bias
+// [3H] (first step: h = 0, the recurrent product is its bias); h_prev [n][H] or NULL (= 0); h_out [n][H].
+__global__ void k_gru_gates(const float* __restrict__ gi, long long gi_stride, const float* __restrict__ gh, const float* __restrict__ gh_bias,
+                            const float* __restrict__ h_prev, float* __restrict__ h_out, long long n, int H) {
+    const long long total = n * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / H;
+        const int c = (int)(i - row * H);
+        const float* g = gi + row * gi_stride;
+        float hr, hz, hn;
+        if (gh) {
+            const float* q = gh + row * 3 * H;
+            hr = q[c];
+            hz = q[H + c];
+            hn = q[2 * H + c];
+        } else {
+            hr = gh_bias[c];
+            hz = gh_bias[H + c];
+            hn = gh_bias[2 * H + c];
+        }
+        const float r = 1.f / (1.f + expf(-(g[c] + hr)));
+        const float z = 1.f / (1.f + expf(-(g[H + c] + hz)));
+        const float nn = tanhf(g[2 * H + c] + r * hn);
+        const float hp = h_prev ? h_prev[i] : 0.f;
+        h_out[i] = (1.f - z) * nn + z * hp;
+    }
+}
+
+// MaxPool2d((1, 4)) over the last axis (floor mode) of x [B][C][rows_per_ch][row_len], plus the convolution's per-channel bias
+// (a constant commutes with the maximum, and adding it here saves a read-modify-write pass over the 4x larger input):
+// out[r][q] = max x[r][4q .. 4q+3] + bias[channel of row r],  q < row_len / 4
+__global__ void k_maxpool_last4(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, long long n_rows,
+                                int row_len, int rows_per_ch, int C) {
+    const int nq = row_len / 4;
+    const long long total = n_rows * nq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / nq;
+        const int q = (int)(i - r * nq);
+        const float* p = x + r * row_len + 4 * q;
+        const float b = bias ? bias[(r / rows_per_ch) % C] : 0.f;
+        out[i] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])) + b;
+    }
+}
+
+// The recurrent layer's input windows (crnn.py:59 `.view`): out[(b T + t) * n_keep + e] = feat[b][c][t + w][fy] with
+// e = (c W + w) 4 + fy < n_keep -- the leading n_keep floats of window t's (C, W, 4) block, moved 16 bytes at a time.
+// feat [B][C][Tp][4] (Tp >= T + W - 1), n_keep a multiple of 4.
+__global__ void k_crnn_windows(const float4* __restrict__ feat, float4* __restrict__ out, long long B, int C, int Tp, int T, int W,
+                               int n_keep4) {
+    const long long total = B * T * n_keep4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e4 = (int)(i % n_keep4);
+        const long long bt = i / n_keep4;
+        const int t = (int)(bt % T);
+        const long long b = bt / T;
+        const int c = e4 / W, w = e4 - c * W;
+        out[i] = feat[(b * C + c) * Tp + t + w];
+    }
+}
+
 }  // namespace disco

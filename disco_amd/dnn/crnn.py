@@ -22,6 +22,52 @@ WIN_LEN = 21                            # tango.py:34
 PRED_FRAME = 'mid'                      # tango.py:35
 
 
+def _gru_gates_hip(g, gh, b_hh, h, H):
+    """One GRU step's gate arithmetic on the GPU through libdisco_hip.so (disco_gru_gates): g (n, 3H) strided rows of the
+    input projection, gh (n, 3H) contiguous or None (first step), h (n, H) or None -> new h (n, H)."""
+    from .. import _lib
+    lib = _lib.load()
+    n = g.shape[0]
+    assert g.stride(1) == 1 and (gh is None or gh.is_contiguous()) and (h is None or h.is_contiguous())
+    out = torch.empty((n, H), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib.disco_gru_gates(None, g.data_ptr(), g.stride(0), None if gh is None else gh.data_ptr(), b_hh.data_ptr(),
+                                 None if h is None else h.data_ptr(), out.data_ptr(), n, H, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f'disco_gru_gates failed ({rc})')
+    return out
+
+
+def _maxpool4_hip(x, bias):
+    """MaxPool2d((1, 4)) of a (B, C, T, F) map plus the convolution's per-channel bias, on the GPU through libdisco_hip.so
+    (torch's generic pooling kernel and the separate bias pass took a quarter of a step)."""
+    from .. import _lib
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(x.shape[:-1] + (x.shape[-1] // 4,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.disco_maxpool_last4(None, x.data_ptr(), bias.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], x.shape[2], x.shape[1],
+                                     out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f'disco_maxpool_last4 failed ({rc})')
+    return out
+
+
+def _crnn_windows_hip(feat, T, W, n_keep):
+    """feat (nb, C, Tp, 4) contiguous float32 on the GPU -> (nb * T, n_keep): the leading n_keep floats of every window's
+    flattened (C, W, 4) block (disco_crnn_windows)."""
+    from .. import _lib
+    lib = _lib.load()
+    nb, C, Tp, Fy = feat.shape
+    assert feat.is_contiguous() and Fy == 4
+    out = torch.empty((nb * T, n_keep), dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = lib.disco_crnn_windows(None, feat.data_ptr(), nb, C, Tp, T, W, n_keep, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f'disco_crnn_windows failed ({rc})')
+    return out
+
+
 class _Seq(nn.Module):
     """Holder that reproduces the reference's `<brick>.model = nn.Sequential(...)` key layout."""
 
@@ -83,27 +129,112 @@ class CRNN(nn.Module):
         """Index of the output frame reshape_mask('mid') selects (tango.py:232-234)."""
         return int(np.floor(self.x_out / 2))
 
+    @torch.no_grad()
+    def predict_masks_windowed(self, mag, frame_to_pred=PRED_FRAME):
+        """The reference's own evaluation order, kept for checking `predict_masks`: explicit 21-frame windows (prepare_data),
+        the module's forward on every window, the selected output frame (reshape_mask).  mag (n_ch, T, F) -> (T, F)."""
+        C, T, F = mag.shape
+        W = self.x_out
+        if frame_to_pred == 'mid':
+            pad, sel = (WIN_LEN // 2, WIN_LEN // 2), int(np.floor(W / 2))
+        else:
+            s_ = (WIN_LEN + W) // 2
+            pad, sel = (s_ - 1, WIN_LEN - s_), W - 1
+        x = torch.nn.functional.pad(torch.clamp(mag, STFT_MIN, STFT_MAX), (0, 0, pad[0], pad[1]))
+        wins = x.unfold(1, WIN_LEN, 1).permute(1, 0, 3, 2)          # (T, C, 21, F)
+        return self.forward(wins.contiguous())[:, sel, :]
+
+    def _cnn_folded(self, x):
+        """The convolutional stack with every BatchNorm2d (inference statistics) folded into the convolution before it:
+        w' = w g / sqrt(var + eps), b' = (b - mean) g / sqrt(var + eps) + beta -- the same function, one kernel less per
+        layer (MIOpen's inference batch-norm was 10 % of the GPU time of a step).  Folded weights are cached per parameter
+        version, so loading a checkpoint afterwards is picked up."""
+        mods = list(self.cnn.model)
+        key = tuple((p.data_ptr(), p._version) for m in mods for p in list(m.parameters()) + list(m.buffers()))
+        if getattr(self, '_fold_key', None) != key:
+            folded = []
+            for conv, bn in zip(mods[0::3], mods[1::3]):
+                g = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                folded.append(((conv.weight * g.view(-1, 1, 1, 1)).contiguous(), ((conv.bias - bn.running_mean) * g + bn.bias).contiguous(),
+                               conv.padding))
+            self._folded, self._fold_key = folded, key
+        for (w, b, pad), pool in zip(self._folded, mods[2::3]):
+            if x.is_cuda and x.dtype == torch.float32 and tuple(pool.kernel_size) == (1, 4):
+                x = _maxpool4_hip(torch.nn.functional.conv2d(x, w, None, stride=1, padding=pad), b)      # bias added after the max
+            else:
+                x = pool(torch.nn.functional.conv2d(x, w, b, stride=1, padding=pad))
+        return x
+
     # ---- sequence evaluation
     @torch.no_grad()
-    def predict_masks(self, mag, chunk=256):
+    def predict_masks(self, mag, chunk=256, frame_to_pred=PRED_FRAME, norm_type=None):
         """mag: (B, n_ch, T, F) magnitudes (un-clipped |STFT| of the node's reference mic, then |z| of the other nodes)
-        -> masks (B, T, F), equal to reshape_mask(model(prepare_data(...)), 'mid') of the reference for every item."""
+        -> masks (B, T, F), equal to reshape_mask(model(prepare_data(..., frame_to_pred, norm_type)), frame_to_pred) of the
+        reference for every item (speech_enhancement/utils.py:13-66, 69-138; tango.py:228-240).
+        frame_to_pred: 'mid' (tango.py:35, what offline_tango uses) or 'last' (prepare_data's own default);
+        norm_type: None | 'scale_to_unit_norm' | 'scale_to_1' | 'center_and_scale' (per frequency over the whole sequence,
+        utils.py:36-66; 'pcen' is librosa's and not offered)."""
         B, C, T, F = mag.shape
-        pad = WIN_LEN // 2                                          # get_frames_to_pad('mid'): (10, 10)
-        x = torch.clamp(mag, STFT_MIN, STFT_MAX)                    # normalization(norm_type=None)
-        x = torch.nn.functional.pad(x, (0, 0, pad, pad))            # zeros AFTER clipping, as prepare_data does
-        feat = self.cnn(x)                                          # (B, 64, T + 20 - 6, 4)
-        Cc, W, Fy = feat.shape[1], self.x_out, self.y_out
-        steps = self.mid_frame() + 1                                # GRU steps needed to reach the selected output frame
+        W = self.x_out                                              # 15 output frames per 21-frame window
+        if frame_to_pred == 'mid':                                  # get_frames_to_pad (utils.py:13-33), reshape_mask (tango.py:228-240)
+            pad = (WIN_LEN // 2, WIN_LEN // 2)
+            steps = int(np.floor(W / 2)) + 1                        # GRU steps needed to reach the selected output frame
+        elif frame_to_pred == 'last':
+            sel = (WIN_LEN + W) // 2
+            pad = (sel - 1, WIN_LEN - sel)
+            steps = W
+        else:
+            raise ValueError(":param output_frames: should be 'mid' or 'last' ('all' is not implemented in the reference either)")
+        x = torch.clamp(mag, STFT_MIN, STFT_MAX)                    # normalization(): clip first, whatever the type
+        if norm_type == 'scale_to_unit_norm':
+            x = x / torch.linalg.vector_norm(x, dim=2, keepdim=True)
+        elif norm_type == 'scale_to_1':
+            x = x / torch.quantile(x, 0.99, dim=2, keepdim=True)
+        elif norm_type == 'center_and_scale':
+            x = x - x.mean(dim=2, keepdim=True)
+            x = x / x.std(dim=2, keepdim=True, unbiased=False)
+        elif norm_type is not None:
+            raise NotImplementedError(f"norm_type '{norm_type}' (librosa's pcen is third-party and absent)")
+        x = torch.nn.functional.pad(x, (0, 0, pad[0], pad[1]))      # zeros AFTER clipping / scaling, as prepare_data does
+        feat = self._cnn_folded(x)                                  # (B, 64, T + 20 - 6, 4)
+        Cc, Fy = feat.shape[1], self.y_out
+        # The reference's `.view` (crnn.py:59) re-interprets each window's (64, 15, 4) block as (15, 256) WITHOUT a transpose:
+        # GRU step s reads elements [256 s, 256 (s + 1)) of the flattened block, i.e. only the first ceil(256 steps / 60)
+        # channels matter for the `steps` steps that are run.
+        c_used = min(Cc, -(-(steps * Cc * Fy) // (W * Fy)))
         gru = self.rnn.model[0].rnn_layer
+        H = gru.hidden_size
+        w_ih, w_hh, b_ih, b_hh = gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0
         out = torch.empty((B, T, F), dtype=mag.dtype, device=mag.device)
+        feat = feat.contiguous()
+        sB, sC = feat.stride(0), feat.stride(1)
         for b0 in range(0, B, chunk):
-            fb = feat[b0:b0 + chunk]
-            nb = fb.shape[0]
-            win = fb.unfold(2, W, 1)                                # (nb, 64, T, 4, 15): window i = frames i .. i+14
-            win = win.permute(0, 2, 1, 4, 3).reshape(nb * T, Cc * W * Fy)        # each row = the (64, 15, 4) block, C-order
-            seq = win.view(nb * T, W, Cc * Fy)[:, :steps, :]        # the reference's .view, truncated to the needed steps
-            h = gru(seq.contiguous())[0][:, -1, :]                  # hidden state after step `mid`
+            nb = min(chunk, B - b0)
+            # window i of channel c = frames i .. i+14 of that channel = W * Fy CONTIGUOUS floats starting at i * Fy: an
+            # overlapping strided view, gathered into rows (c, w, fy) with 60-float runs (a permuted unfold of the same
+            # data copies element by element and was the slowest kernel of the whole step)
+            if feat.is_cuda and feat.dtype == torch.float32 and Fy == 4:
+                seq = _crnn_windows_hip(feat[b0:b0 + nb], T, W, steps * Cc * Fy).view(nb * T, steps, Cc * Fy)
+            else:
+                win = feat[b0:b0 + nb].as_strided((nb, T, c_used, W * Fy), (sB, Fy, sC, 1)).reshape(nb * T, c_used * W * Fy)
+                seq = win[:, :steps * Cc * Fy].view(nb * T, steps, Cc * Fy)
+            # The GRU over `steps` steps from a zero state, for all nb * T windows at once, as plain GEMMs: one for the input
+            # projections of every step, one per step for the recurrent part (torch's / MIOpen's nn.GRU kernel is an order of
+            # magnitude slower on this shape: a quarter of a million 8-step sequences).  Gate order r, z, n; same arithmetic.
+            gi = torch.addmm(b_ih, seq.reshape(-1, Cc * Fy), w_ih.t()).view(nb * T, steps, 3 * H)
+            fused = gi.is_cuda and gi.dtype == torch.float32          # pointwise gate math in one HIP kernel (libdisco_hip.so)
+            h = None
+            for st in range(steps):
+                g = gi[:, st]
+                if fused:
+                    gh = None if h is None else torch.addmm(b_hh, h, w_hh.t())
+                    h = _gru_gates_hip(g, gh, b_hh, h, H)
+                    continue
+                gh = b_hh.expand(nb * T, -1) if h is None else torch.addmm(b_hh, h, w_hh.t())
+                r = torch.sigmoid(g[:, :H] + gh[:, :H])
+                zg = torch.sigmoid(g[:, H:2 * H] + gh[:, H:2 * H])
+                nn_ = torch.tanh(g[:, 2 * H:] + r * gh[:, 2 * H:])
+                h = (1 - zg) * nn_ if h is None else torch.addcmul((1 - zg) * nn_, zg, h)
             out[b0:b0 + chunk] = self.ff(h).view(nb, T, F)
         return out
 

@@ -307,6 +307,30 @@ int disco_tango_online(disco_ctx* ctx, const float* y, const float* mask_z, cons
                        float* out, disco_c32* z_y, disco_c32* yf,
                        void* workspace, size_t workspace_bytes, disco_stream s);
 
+/* ---- helper of the mask-estimation DNN, which otherwise stays in PyTorch-ROCm ------------------------------------
+ * The pointwise half of one GRU step for n independent sequences (gate order r, z, n as torch.nn.GRU; the two matrix products
+ * are the caller's GEMMs):  r = sigm(gi_r + gh_r), z = sigm(gi_z + gh_z), c = tanh(gi_n + r gh_n), h' = (1 - z) c + z h.
+ *   gi      rows of 3H floats at stride gi_stride (floats): one time step of the all-steps input projection
+ *   gh      [n][3H] = h W_hh^T + b_hh, or NULL together with gh_bias [3H] for the first step (h = 0)
+ *   h_prev  [n][H] or NULL (= 0);  h_out [n][H] (may alias h_prev)
+ * ctx may be NULL: the launch then goes to the calling thread's current device (the DNN owns no disco_ctx). */
+int disco_gru_gates(disco_ctx* ctx, const float* gi, int64_t gi_stride, const float* gh, const float* gh_bias,
+                    const float* h_prev, float* h_out, int64_t n, int H, disco_stream s);
+
+/* MaxPool2d((1, 4)) of the CRNN's convolutional stack (dnn/models/crnn.py via nn_structures.py): floor-mode maximum over groups
+ * of 4 along the last axis, plus the preceding convolution's per-channel bias (a constant commutes with the maximum; adding it here
+ * spares a pass over the four times larger un-pooled map).  x [B][channels][rows_per_channel][row_len] seen as n_rows rows ->
+ * out [n_rows][row_len / 4]; bias [channels] or NULL.  ctx may be NULL. */
+int disco_maxpool_last4(disco_ctx* ctx, const float* x, const float* bias, int64_t n_rows, int row_len, int rows_per_channel,
+                        int channels, float* out, disco_stream s);
+
+/* The recurrent layer's input windows: the reference re-interprets every 15-frame window of the (C, frames, 4) feature map as a
+ * (15, 256) sequence WITHOUT a transpose (dnn/models/crnn.py:59), so window t is the flattened block feat[:, t : t + W, :];
+ * out[(b T + t)][0 : n_keep] = its leading n_keep floats (n_keep = 256 x GRU steps actually run, a multiple of 4).
+ * feat [B][C][Tp][4] float, Tp >= T + W - 1; feat and out 16-byte aligned.  ctx may be NULL. */
+int disco_crnn_windows(disco_ctx* ctx, const float* feat, int64_t B, int C, int Tp, int T, int W, int n_keep, float* out,
+                       disco_stream s);
+
 /* ---- evaluation metrics right after the path --------------------------------------------------
  * Raw float64 moments behind disco_theque/metrics.py; the dB / clipping / weighting of a handful of numbers per signal
  * is host arithmetic (disco_amd/metrics.py).

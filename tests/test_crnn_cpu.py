@@ -75,3 +75,24 @@ def test_shapes_of_the_architecture():
     keys = set(m.state_dict())
     assert {'cnn.model.0.weight', 'cnn.model.1.running_mean', 'cnn.model.6.bias', 'rnn.model.0.rnn_layer.weight_ih_l0',
             'ff.layers.0.weight'} <= keys
+
+
+@pytest.mark.parametrize('tag,n_ch', [('sc', 1), ('mc', 4)])
+@pytest.mark.parametrize('ftp,nt', [('last', None), ('mid', 'scale_to_unit_norm'), ('mid', 'scale_to_1'), ('last', 'center_and_scale')])
+def test_frame_to_pred_last_and_normalisations(gold, golden_dir, tag, n_ch, ftp, nt):
+    """prepare_data's other output-frame choice ('last': pad (17, 3), all 15 GRU steps, last output frame) and the three
+    numpy normalisations, against the reference's own prepare_data / normalization / reshape_mask (crnn_variants_ref.npz)."""
+    var = np.load(os.path.join(golden_dir, 'crnn_variants_ref.npz'))
+    model = _model(gold, tag, n_ch)
+    chans = [np.abs(gold[f'{tag}_Y'])]
+    if n_ch > 1:
+        chans += [np.abs(z) for z in gold[f'{tag}_Z']]
+    mag = torch.from_numpy(np.stack(chans)[None].transpose(0, 1, 3, 2).copy())
+    mask = model.predict_masks(mag, frame_to_pred=ftp, norm_type=nt).numpy()[0]
+    ref = var[f'{tag}_{ftp}_{nt}']
+    assert mask.shape == ref.T.shape
+    assert np.abs(mask - ref.T).max() < 1e-5, np.abs(mask - ref.T).max()
+    with pytest.raises(NotImplementedError):
+        model.predict_masks(mag, norm_type='pcen')
+    with pytest.raises(ValueError):
+        model.predict_masks(mag, frame_to_pred='all')

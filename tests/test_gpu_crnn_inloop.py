@@ -8,6 +8,9 @@ from disco_amd.engine import Engine
 
 pytestmark = pytest.mark.gpu
 
+# the north star's bar; the MWF is fed the SAME masks on both sides, so nothing network-specific enters the comparison
+CRNN_TOL = float(__import__('os').environ.get('DISCO_CRNN_TOL', '1e-4'))
+
 
 def _rand_model(n_ch, seed, device):
     import torch
@@ -46,9 +49,7 @@ def test_crnn_in_loop_vs_oracle(K, M, two_models):
         o = to.offline_tango_vec(y[r], s[r], n[r], masks=masks, precision='f64', solver='eigh')
         for k in range(K):
             ref = so.istft(o['yf'][k], L, work_dtype=np.float64)
-            # randomly initialised networks give masks close to 0.5 everywhere, i.e. Rss almost proportional to Rnn and a
-            # nearly degenerate generalized eigenproblem: the 1e-4 bar of the oracle-mask tests relaxes to 1e-3 here
-            assert pc.relerr(out[r, k], ref) < 1e-3, (r, k, pc.relerr(out[r, k], ref))
+            assert pc.relerr(out[r, k], ref) < CRNN_TOL, (r, k, pc.relerr(out[r, k], ref))
         # 2) the step-1 masks themselves: the same network in float64 on the oracle's |Y_ref|
         mag = np.stack([np.abs(o['Y'][k][0]).T for k in range(K)])[:, None]            # (K, 1, T, F)
         ref_mz = cpu_z.predict_masks(torch.from_numpy(mag)).numpy()
@@ -84,7 +85,7 @@ def test_offline_tango_with_crnn_masks(two_models):
     ref = to.as_reference_tuple(o)
     for nm, got, want in zip(names[:7], res[:7], ref[:7]):
         for k in range(K):
-            assert pc.relerr(got[k], want[k]) < 1e-3, (nm, k, pc.relerr(got[k], want[k]))
+            assert pc.relerr(got[k], want[k]) < CRNN_TOL, (nm, k, pc.relerr(got[k], want[k]))
     cpu_z = _rand_model(1, 1, 'cpu').double()
     mag = np.stack([np.abs(o['Y'][k][0]).T for k in range(K)])[:, None]
     ref_mz = cpu_z.predict_masks(torch.from_numpy(mag)).numpy()
