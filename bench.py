@@ -251,12 +251,14 @@ def main(argv=None):
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = dd.init('nccl', rank, world, device=dev) if world > 1 else None    # RCCL
+    node_sharded = args.shard == 'nodes'
+    if world == 1 and node_sharded:
+        os.environ.setdefault('MASTER_PORT', str(dd.free_port()))
+    dist = dd.init('nccl', rank, world, device=dev) if (world > 1 or node_sharded) else None    # RCCL (one-rank group for --shard nodes)
 
     R, K, M, Ls, N = args.rooms, args.nodes, args.mics, args.length, args.n_fft
     H, F = N // 2, N // 2 + 1
     lib = _lib.load()
-    node_sharded = args.shard == 'nodes'
     if node_sharded and (args.mask != 'oracle' or args.online_every):
         raise SystemExit('--shard nodes runs the batch path with oracle masks')
     eng = Engine(rooms=R, nodes=K, mics=M, length=Ls, n_fft=N, device=local_rank, lib=lib)
@@ -444,7 +446,7 @@ def main(argv=None):
         if exchange:
             line['exchange'] = exchange
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()                    # rank 0 may still be in its per-stage timing / parity check: leave together
         dist.destroy_process_group()
     if parity is not None and not parity['ok']:

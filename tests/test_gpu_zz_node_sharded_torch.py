@@ -19,3 +19,43 @@ def test_node_sharded_torch_one_rank_rccl():
     torch.cuda.set_device(0)
     errs = pc.check_node_sharded_torch_one_rank(lambda **cfg: Engine(lib=lib, **cfg), 'cuda:0', 'nccl', K=4, M=4, L=40000, iters=2)
     print(errs)
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    return lines[0]
+
+
+@pytest.mark.timeout(900)
+def test_bench_node_sharded_one_rank():
+    """bench.py --shard nodes on ONE GPU: the node-sharded driver (staged kernels, all_gather_into_tensor over a 1-rank RCCL
+    group) timed and parity-checked against the oracle like the default mode."""
+    d = _run_bench(['--gpus', '1', '--shard', 'nodes', '--rooms', '6', '--length', '40000', '--steps', '2', '--warmup', '1',
+                    '--no-cpu-baseline'])
+    assert d['n_gpus'] == 1 and d['parity_sample']['ok'] and d['parity_sample']['worst_rel'] < 1e-4
+    assert d['exchange']['gathers_per_step'] == 1 and d['exchange']['ms_per_gather'] is not None
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('shard', ['rooms', 'nodes'])
+def test_bench_two_ranks_rccl(shard):
+    """`python bench.py --gpus 2` started plainly: the script launches its own two ranks (one per GPU, RCCL).  --shard nodes
+    splits the 4 nodes of every room 2 + 2 and exchanges z with a real two-rank all-gather over xGMI; rank 0's nodes are
+    checked against the float64 oracle of the WHOLE room.  Needs two GPUs (skipped on the single-GPU test box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    d = _run_bench(['--gpus', '2', '--shard', shard, '--rooms', '8', '--length', '40000', '--steps', '2', '--warmup', '1',
+                    '--no-cpu-baseline'])
+    assert d['n_gpus'] == 2 and d['parity_sample']['ok'] and d['parity_sample']['worst_rel'] < 1e-4
+    if shard == 'nodes':
+        assert d['exchange']['link_GBps'] is not None and d['scaling'] == 'strong'
