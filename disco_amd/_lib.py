@@ -42,6 +42,7 @@ PROTOTYPES = {
     'disco_n_freq': (_int, [_vp]),
     'disco_workspace_bytes': (_sz, [_vp]),
     'disco_set_node_shard': (_int, [_vp, _int, _int]),
+    'disco_set_z_blocks': (_int, [_vp, _int]),
     'disco_set_tuning': (_int, [_vp, _int, _int, _int, _int]),
     'disco_stage_timing': (_int, [_vp, _int]),
     'disco_stage_report': (_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int), _int]),

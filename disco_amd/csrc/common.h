@@ -72,6 +72,14 @@ __device__ __forceinline__ c64 zscale(c64 a, double s) { return make_double2(a.x
 // then wraps every access guarded by a per-wave condition in exec-mask branches (one per load).
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Index of the [T][F] plane of (room r, GLOBAL node j) inside an array of exchanged signals Z.  The plain layout is [R][K]
+// (zblk = K).  An all-gather over ranks that hold zblk nodes each delivers [K / zblk][R][zblk] -- rank-major -- and is consumed
+// as it arrives when zblk says so (disco_set_z_blocks): no transposing copy between the collective and step 2.
+__device__ __forceinline__ long long z_plane(long long r, int j, int K, long long R, int zblk) {
+    (void)K;
+    return ((long long)(j / zblk) * R + r) * zblk + (j % zblk);
+}
+
 // reflect / zero padded sample fetch, branch-free: p is the index into the un-padded signal of length L.
 // The load is unconditional (clamped index); out-of-range samples of constant padding are zeroed by a select.
 __device__ __forceinline__ float load_padded(const float* __restrict__ x, int p, int L, int pad_mode) {

@@ -35,11 +35,13 @@ struct disco_ctx {
     void* scratch2;                  // step-2 partials when the step-1 ones in `scratch` are re-used (SKIPLOC)
     size_t scratch2_bytes;
     int loc_chunks, loc_M;           // geometry of the step-1 partials kept in `scratch` for that re-use
+    const void *loc_X, *loc_mask;    // the STFT / mask arrays those step-1 partials were computed from (identity check of the re-use)
     int pending_skiploc;             // the pending step-2 partials (scratch2) lack their leading loc_M x loc_M block
     c32* d_tw_conv;                  // 1024-point twiddles of disco_rir_convolve (== d_tw when n_fft is 1024), lazy
     void* conv_ws;                   // its spectra workspace, lazy
     size_t conv_ws_bytes;
     int k0, Kl;                      // node shard: this context holds nodes [k0, k0 + Kl) of every room (default 0, K)
+    int zblk;                        // layout of the exchanged-signal arguments Zs / Zn / Z (disco_set_z_blocks; default K = plain)
     int tune_runw, tune_cov_chunks, tune_step2_chunks, tune_pairs;   // disco_set_tuning overrides (0 = batch-size heuristic)
     // per-stage hipEvent timers of the whole-path entry points (disco_stage_timing / disco_stage_report)
     struct StageRec {
@@ -192,12 +194,14 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->pending_P = 0;
     ctx->k0 = 0;
     ctx->Kl = cfg->nodes;
+    ctx->zblk = cfg->nodes;
     ctx->tune_runw = ctx->tune_cov_chunks = ctx->tune_step2_chunks = ctx->tune_pairs = 0;
     ctx->stage_on = false;
     ctx->scratch2 = nullptr;
     ctx->scratch2_bytes = 0;
     ctx->loc_chunks = 0;
     ctx->loc_M = 0;
+    ctx->loc_X = ctx->loc_mask = nullptr;
     ctx->pending_skiploc = 0;
     ctx->d_tw_conv = nullptr;
     ctx->conv_ws = nullptr;
@@ -294,7 +298,16 @@ extern "C" int disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int co
     return 0;
 }
 
-static inline bool sharded(const disco_ctx* ctx) { return ctx->Kl != ctx->cfg.nodes; }
+extern "C" int disco_set_z_blocks(disco_ctx* ctx, int nodes_per_block) {
+    DISCO_ENTER(ctx);
+    if (nodes_per_block < 1 || ctx->cfg.nodes % nodes_per_block)
+        return fail(ctx, DISCO_E_ARG, "disco_set_z_blocks: nodes_per_block must divide cfg.nodes");
+    ctx->zblk = nodes_per_block;
+    return 0;
+}
+
+// whole-path entry points work on all nodes of a room and on their own plain [R][K] exchanged-signal arrays
+static inline bool sharded(const disco_ctx* ctx) { return ctx->Kl != ctx->cfg.nodes || ctx->zblk != ctx->cfg.nodes; }
 
 extern "C" int disco_n_frames(const disco_ctx* ctx) { return ctx ? ctx->T : DISCO_E_ARG; }
 extern "C" int disco_n_freq(const disco_ctx* ctx) { return ctx ? ctx->F : DISCO_E_ARG; }
@@ -505,7 +518,7 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
     const bool same = (Zs == Zn);
     const bool split = (KR == 0 || (P > 8 && same && mask_remote)) && cov_split_shape(M, KR);
-    skiploc = skiploc && split && KR > 0 && ctx->loc_M == M;
+    skiploc = skiploc && split && KR > 0 && ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask;
     int rc = 0;
     if (skiploc) {
         if (ctx->scratch2_bytes < need) {
@@ -532,6 +545,8 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     a.mask_remote = mask_remote;
     a.Kl = ctx->Kl;
     a.k0 = ctx->k0;
+    a.zblk = ctx->zblk;
+    a.R = c.rooms;
     const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
     bool launched = false;
     if (split) {                // 9 <= P <= 16, one vector for both statistics: one block of pairs per wave
@@ -581,6 +596,8 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
         // on the same mask, anything else invalidates what k_stft_cov / an earlier step-1 call left
         ctx->loc_M = (KR == 0 && !sharded(ctx)) ? M : 0;
         ctx->loc_chunks = chunks;
+        ctx->loc_X = X;
+        ctx->loc_mask = mask;
     }
     return check_launch(ctx, "k_cov");
 }
@@ -711,7 +728,7 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     if (!launched && M == M_ && KR == KR_) {                                                                         \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply<M_, KR_>), grid, block, 0, (hipStream_t)s, (const c32*)X,         \
                            (const c32*)Z, (const c32*)w, (c32*)out, c.nodes, ctx->T, ctx->F, conj_w, bpn, ctx->Kl,   \
-                           ctx->k0);                                                                                 \
+                           ctx->k0, ctx->zblk, (long long)c.rooms);                                                                                 \
         launched = true;                                                                                             \
     }
     DISCO_FOR_MKR(X_)
@@ -725,7 +742,8 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_m<M_>), grid_m, dim3(64), 0, (hipStream_t)s, (const c32*)X, (const c32*)Z, \
-                           (const c32*)w, (c32*)out, KR, c.nodes, ctx->T, ctx->F, conj_w, tiles, t_chunks, ctx->Kl, ctx->k0); \
+                           (const c32*)w, (c32*)out, KR, c.nodes, ctx->T, ctx->F, conj_w, tiles, t_chunks, ctx->Kl, ctx->k0, ctx->zblk, \
+                           (long long)c.rooms);                                                                    \
         break;
             C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8)
 #undef C_
@@ -810,6 +828,8 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
     ctx->pending_skiploc = 0;
     ctx->loc_chunks = chunks;          // kept for a possible re-use by step 2 of the same disco_tango_enhance call
     ctx->loc_M = M;
+    ctx->loc_X = X;
+    ctx->loc_mask = mask_z;
     return check_launch(ctx, "k_stft_cov");
 }
 
@@ -905,6 +925,8 @@ extern "C" int disco_step2_cov_fused_reuse(disco_ctx* ctx, const disco_c32* X, c
     DISCO_ENTER(ctx);
     if (ctx->loc_M != ctx->cfg.mics || ctx->cfg.nodes < 2 || ctx->Kl != ctx->cfg.nodes)
         return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused_reuse: no step-1 partial sums of disco_stft_cov_fused are held by this context");
+    if (ctx->loc_X != X || ctx->loc_mask != mask_w)
+        return fail(ctx, DISCO_E_ARG, "disco_step2_cov_fused_reuse: X / mask_w are not the arrays the held step-1 partial sums were computed from");
     int chunks = 1;
     return step2_cov_partials(ctx, X, mask_w, w_loc, z_out, &chunks, s, true);
 }
@@ -1376,6 +1398,8 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
     a.init_diag = init_diag;
     a.mu = (double)mu;
     a.n_prob = (long long)c.rooms * ctx->Kl * ctx->F;
+    a.zblk = ctx->zblk;
+    a.R = c.rooms;
     hipStream_t st = (hipStream_t)s;
     switch (P) {
 #define C_(P_)                                                                                                          \

@@ -9,7 +9,8 @@ namespace disco {
 template <int M, int KR>
 __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const c32* __restrict__ Z,
                                                 const c32* __restrict__ w, c32* __restrict__ out,
-                                                int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0) {
+                                                int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0, int zblk,
+                                                long long R) {
     constexpr int P = M + KR;
     const long long g = blockIdx.x / blocks_per_node;            // local unit r*Kl + kl (see CovArgs)
     const int b = (int)(blockIdx.x % blocks_per_node);
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const 
 #pragma unroll
         for (int jj = 0; jj < KR; ++jj) {
             const int j = jj < k ? jj : jj + 1;
-            const c32 x = Z[(r * K + j) * TF + tf];
+            const c32 x = Z[z_plane(r, j, K, R, zblk) * TF + tf];
             const c32 ww = make_float2(wf[M + jj].x, sgn * wf[M + jj].y);
             ar = fmaf(ww.x, x.x, fmaf(-ww.y, x.y, ar));
             ai = fmaf(ww.x, x.y, fmaf(ww.y, x.x, ai));
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const 
 template <int M>
 __global__ __launch_bounds__(64) void k_apply_m(const c32* __restrict__ X, const c32* __restrict__ Z,
                                                  const c32* __restrict__ w, c32* __restrict__ out, int KR,
-                                                 int K, int T, int F, int conj_w, int tiles, int t_chunks, int Kl, int k0) {
+                                                 int K, int T, int F, int conj_w, int tiles, int t_chunks, int Kl, int k0, int zblk,
+                                                 long long R) {
     const int P = M + KR;
     const int per_node = tiles * t_chunks;
     const long long g = blockIdx.x / per_node;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(64) void k_apply_m(const c32* __restrict__ X, const
     for (int i = 0; i < M; ++i) wl[i] = make_float2(wf[i].x, sgn * wf[i].y);
 #pragma unroll
     for (int jj = 0; jj < 15; ++jj) wr[jj] = jj < KR ? make_float2(wf[M + jj].x, sgn * wf[M + jj].y) : make_float2(0.f, 0.f);
-    const c32* Zr = Z ? Z + (r * K) * TF : nullptr;
+
     for (int t = t0; t < t1; ++t) {
         const long long tf = (long long)t * F + f;
         const c32* xp = X + (g * TF + tf) * M;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(64) void k_apply_m(const c32* __restrict__ X, const
         for (int jj = 0; jj < 15; ++jj) {
             if (jj < KR) {
                 const int j = jj < k ? jj : jj + 1;
-                const c32 z = Zr[j * TF + tf];
+                const c32 z = Z[z_plane(r, j, K, R, zblk) * TF + tf];
                 ar = fmaf(wr[jj].x, z.x, fmaf(-wr[jj].y, z.y, ar));
                 ai = fmaf(wr[jj].x, z.y, fmaf(wr[jj].y, z.x, ai));
             }

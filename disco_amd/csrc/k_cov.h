@@ -48,6 +48,9 @@ struct CovArgs {
     // indexed by the LOCAL unit g = r*Kl + kl; only the remote rows Zs/Zn are indexed by global node (they come from the
     // all-gather of z).  Kl == K, k0 == 0 when all nodes of a room live here.
     int Kl, k0;
+    // layout of Zs / Zn: planes [K / zblk][R][zblk] (zblk = K: the plain [R][K]; see z_plane in common.h)
+    int zblk;
+    long long R;
 };
 
 template <int M, int KR, bool SAMEZ>
@@ -77,7 +80,7 @@ __device__ __forceinline__ void cov_walk(const CovArgs& a, long long g, int f, i
 #pragma unroll
             for (int jj = 0; jj < KR; ++jj) {
                 const int j = jj < k ? jj : jj + 1;               // concatenate_signals order: z_j (j<k), z_j (j>k)
-                const long long zo = ((r * K + j) * T) * (long long)F + tf;
+                const long long zo = (z_plane(r, j, K, a.R, a.zblk) * T) * (long long)F + tf;
                 const c32 zs = a.Zs[zo];
                 const c32 zn = SAMEZ ? zs : a.Zn[zo];
                 vs[M + jj] = make_float2(gs * zs.x, gs * zs.y);
@@ -173,7 +176,7 @@ __device__ __forceinline__ void cov_big_walk(const CovArgs& a, int M, int KR, lo
             } else if (i < P) {
                 const int jj = i - M;
                 const int j = jj < k ? jj : jj + 1;
-                const long long zo = ((r * K + j) * T) * (long long)F + tf_;
+                const long long zo = (z_plane(r, j, K, a.R, a.zblk) * T) * (long long)F + tf_;
                 xs_[i] = a.Zs[zo];
                 if (!SAMEZ) xn_[i] = a.Zn[zo];
             } else {
@@ -352,7 +355,7 @@ __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, in
 #pragma unroll
         for (int jj = 0; jj < KR; ++jj) {
             const int j = jj < k ? jj : jj + 1;                                  // concatenate_signals order
-            zp[jj] = a.Zs + ((r * K + j) * T) * (long long)F;
+            zp[jj] = a.Zs + (z_plane(r, j, K, a.R, a.zblk) * T) * (long long)F;
         }
         c32 acc_s[NPAIR], acc_n[NPAIR];
 #pragma unroll

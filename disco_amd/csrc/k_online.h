@@ -29,6 +29,8 @@ struct OnlineArgs {
     float lambda_cor, init_diag;
     double mu;
     long long n_prob;    // R * Kl * F
+    int zblk;            // layout of Z: planes [K / zblk][R][zblk] (zblk = K: plain [R][K]; z_plane in common.h)
+    long long R;
 };
 
 #ifndef DISCO_ONLINE_WPE
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
 
     // row c of v_t: local channels first, then the other nodes' z in node order (tango.py:150-153)
     const c32* xb = a.X + ((g * a.T) * a.F + f) * (long long)M;
-    const c32* zb = a.Z ? a.Z + ((r * a.K) * a.T) * a.F + f : nullptr;
+    const c32* zb = a.Z ? a.Z + f : nullptr;
     const long long TF = (long long)a.T * a.F;
     const float* mp = a.mask + (g * a.T) * a.F + f;
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
                 v[c] = xb[(long long)t * a.F * M + c];
             } else {
                 const int jn = (c - M) < k ? (c - M) : (c - M) + 1;        // skip the node's own z
-                v[c] = zb ? zb[jn * TF + (long long)t * a.F] : make_float2(0.f, 0.f);
+                v[c] = zb ? zb[z_plane(r, jn, a.K, a.R, a.zblk) * TF + (long long)t * a.F] : make_float2(0.f, 0.f);
             }
         }
         const float m = mp[(long long)t * a.F];
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(SOLVE_SMALL_THREADS) void k_online_mwf_thread(Onlin
     const int k = a.k0 + (int)(g % a.Kl);
     const int M = a.M;
     const c32* xb = a.X + ((g * a.T) * a.F + f) * (long long)M;
-    const c32* zb = a.Z ? a.Z + ((r * a.K) * a.T) * a.F + f : nullptr;
+    const c32* zb = a.Z ? a.Z + f : nullptr;
     const long long TF = (long long)a.T * a.F;
     const float* mp = a.mask + (g * a.T) * a.F + f;
     float a_d[P], b_d[P];
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(SOLVE_SMALL_THREADS) void k_online_mwf_thread(Onlin
                 v[c] = xb[(long long)t * a.F * M + c];
             } else {
                 const int jn = (c - M) < k ? (c - M) : (c - M) + 1;        // skip the node's own z
-                v[c] = zb ? zb[jn * TF + (long long)t * a.F] : make_float2(0.f, 0.f);
+                v[c] = zb ? zb[z_plane(r, jn, a.K, a.R, a.zblk) * TF + (long long)t * a.F] : make_float2(0.f, 0.f);
             }
         }
         const float m = mp[(long long)t * a.F];

@@ -78,6 +78,7 @@ class Engine:
             raise DiscoError(f'disco_create failed ({rc}): {self.lib.disco_last_error(None).decode()}')
         self.R, self.K, self.M, self.Lsamp = rooms, nodes, mics, length
         self.Kl, self.k0 = nodes, 0                     # node shard held by this engine (all nodes by default)
+        self.zblk = nodes                               # layout of exchanged-signal arguments (set_z_blocks)
         self.T = self.lib.disco_n_frames(self.ctx)
         self.F = self.lib.disco_n_freq(self.ctx)
         self.stream = None
@@ -199,6 +200,12 @@ class Engine:
         methods then take / return `node_count` nodes per room, while Zs / Zn / Z keep all K nodes (all-gathered z)."""
         self._chk(self.lib.disco_set_node_shard(self.ctx, first_node, node_count))
         self.k0, self.Kl = first_node, node_count
+
+    def set_z_blocks(self, nodes_per_block):
+        """The exchanged-signal arguments (Zs / Zn / Z) are laid out [K / nodes_per_block][R][nodes_per_block][T][F]: what an
+        all-gather over ranks holding `nodes_per_block` nodes each delivers.  nodes_per_block = K: the plain [R][K][T][F]."""
+        self._chk(self.lib.disco_set_z_blocks(self.ctx, nodes_per_block))
+        self.zblk = nodes_per_block
 
     def set_tuning(self, stft_frames_per_wave=0, cov_chunks=0, step2_chunks=0, istft_pairs=0):
         """Pin the launch geometry (0 = batch-size heuristic): lets a small batch run the code path of a large one."""

@@ -21,7 +21,7 @@ def node_range(rank, world, K):
     return rank * kl, kl
 
 
-def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=None, out=None):
+def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=None, out=None, z_shape=None):
     """Shared data flow.  z_out / yf_out: caller-owned device arrays for this rank's z / yf (or None: DevBuf);
     gather(z_local) -> z of ALL nodes (R, K, T, F), numpy or device array."""
     if iters < 1:
@@ -41,7 +41,7 @@ def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=
         z_loc = eng.apply(X, w_loc, out=z_out)
         # the exchange (tango.py:378-386): one all-gather of the compressed signals
         z_all = gather(z_loc)
-        assert tuple(z_all.shape) == (R, eng.K, eng.T, eng.F)
+        assert tuple(z_all.shape) == (z_shape or (R, eng.K, eng.T, eng.F))
         # step 2, local again (tango.py:411-450)
         if eng.K > 1:
             eng.cov_masked(X, mask_w_local, z_all, z_all, mask_remote=True, Rss_out=False)
@@ -100,9 +100,14 @@ def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, g
         if timed:
             e1.record()
             gather_events.append((e0, e1))
-        # (W, R, Kl, T, F) -> (R, W*Kl, T, F): one on-device transpose copy (HBM speed, far below the link time)
-        return parts.permute(1, 0, 2, 3, 4).reshape(R, K, eng.T, eng.F).contiguous()
-    return _run(eng, y_local, mask_z_local, mask_w_local, iters, z_loc, gather, yf_out=yf, out=out)
+        return parts              # rank-major [W][R][Kl][T][F]: consumed as it arrives (Engine.set_z_blocks), no transposing copy
+    eng.set_z_blocks(Kl)
+    try:
+        out_, yf_, z_rank_major = _run(eng, y_local, mask_z_local, mask_w_local, iters, z_loc, gather, yf_out=yf, out=out, z_shape=(W, R, Kl, eng.T, eng.F))
+    finally:
+        eng.set_z_blocks(K)
+    # the documented return value keeps global node order (R, K, T, F): a view-free copy made only for the caller's benefit
+    return out_, yf_, z_rank_major.permute(1, 0, 2, 3, 4).reshape(R, K, eng.T, eng.F)
 
 
 def torch_all_gather(world):

@@ -95,6 +95,13 @@ size_t disco_workspace_bytes(const disco_ctx* ctx);
  * disco_tango_enhance need all nodes on one GPU and return DISCO_E_UNSUPPORTED while a shard is active. */
 int  disco_set_node_shard(disco_ctx* ctx, int first_node, int node_count);
 
+/* Layout of the exchanged signals handed to the STAGED entry points (Zs / Zn of disco_cov_masked, Z of disco_apply and
+ * disco_online_mwf).  Default: [R][K][T][F].  After an all-gather over W = K / nodes_per_block ranks the signals arrive rank-major,
+ * [W][R][nodes_per_block][T][F]; disco_set_z_blocks(ctx, nodes_per_block) makes the kernels read that layout directly, so the
+ * node-sharded driver needs no transposing copy between the collective and step 2.  nodes_per_block = cfg.nodes restores the
+ * default.  Outputs (z written by disco_apply for the LOCAL nodes) keep [R][count][T][F]: that IS a rank's block. */
+int  disco_set_z_blocks(disco_ctx* ctx, int nodes_per_block);
+
 /* Launch geometry.  By default every kernel derives its work split from the batch size (long per-wave frame runs and single
  * covariance chunks once R*K fills the chip, short runs and up to 8 chunks for small batches).  This call pins it, so that a
  * SMALL batch can be run -- and checked against the oracle -- on exactly the code path a large production batch takes:

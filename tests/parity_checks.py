@@ -239,10 +239,12 @@ def check_step2_reuse(make_engine, R=1, K=3, M=2, L=6000):
     y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
     eng = make_engine(rooms=R, nodes=K, mics=M, length=L)
     T, F = eng.T, eng.F
-    mask = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F).numpy()
-    P = M + K - 1
+    mask = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F)    # stays on the device:
+    P = M + K - 1                                       # the re-use is granted for THE arrays the step-1 sums were computed from
     X, _, _ = eng.stft_cov_fused(y, mask)
     w_loc, _ = eng.gevd_mwf_r1_pending(M)
+    with pytest.raises(Exception):          # another mask array (even with equal contents) is not what step 1 saw
+        eng.step2_cov_fused_reuse(X, mask.numpy(), w_loc)
     z = eng.step2_cov_fused_reuse(X, mask, w_loc, want_z=True)
     w_a, t_a = eng.gevd_mwf_r1_pending(P, want_t1=True)
     Rss, Rnn, z_b = eng.step2_cov_fused(X, mask, w_loc, want_z=True)
