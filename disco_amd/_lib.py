@@ -104,5 +104,13 @@ def load():
             raise RuntimeError(
                 f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 '(hipcc --offload-arch=gfx950).  disco_amd has no CPU path.')
+        # One HIP / HSA runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and a process
+        # that initialises the system copy first (through this library) and torch's afterwards ends with torch reporting
+        # "No HIP GPUs are available".  Loaded first, torch's copy carries the soname this library needs, so the dynamic
+        # loader binds both to it -- which is also what makes zero-copy use of torch tensors legitimate.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = bind(C.CDLL(LIB_PATH))
     return _lib

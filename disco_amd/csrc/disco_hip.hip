@@ -766,14 +766,14 @@ extern "C" int disco_noise_residual(disco_ctx* ctx, const disco_c32* X, const di
 // ---------------------------------------------------------------------------------------------------------
 // STFT + step-1 covariance in one pass
 // ---------------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool STORE = true>
 static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, const float* mask, c32* X, float4* part,
                             const float* win, const c32* tw, int L, int T, int pad_mode, int chunks, int runw) {
     const dim3 block(64 * STFT_WAVES);
     switch (M) {
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_, STORE>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
                            chunks, runw);                                                                               \
         return true;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6)
@@ -783,7 +783,7 @@ static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, co
         switch (M) {
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_cov<N, M_, STORE>), grid, block, 0, st, y, mask, X, part, win, tw, L, T, pad_mode, \
                            chunks, runw);                                                                               \
         return true;
             C_(7) C_(8)
@@ -793,13 +793,16 @@ static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, co
     return false;
 }
 
-static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s) {
-    if (!y || !mask_z || !X) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
+// store = false (internal, single-node path): the spectra are not written (X may be NULL); only for shapes the fused kernel takes
+static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s,
+                             bool store = true) {
+    if (!y || !mask_z || (store && !X)) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics;
     if (M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: more than 8 mics per node");
     if (c.n_fft == 1024 && M > 6) {        // staged form of the same two operations
+        if (!store) return fail(ctx, DISCO_E_UNSUPPORTED, "stft_cov without store: shape needs the staged kernels");
         int rc0 = STAGE(ctx, s, "stft", disco_stft(ctx, y, (int64_t)c.rooms * c.nodes, M, X, s));
         if (rc0) return rc0;
         return STAGE(ctx, s, "cov1", cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s));
@@ -816,7 +819,13 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
     if (rc) return rc;
     if (G * chunks > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: batch too large");
     const dim3 grid((unsigned)(G * chunks));
-    const bool ok = STAGE(ctx, s, "stft_cov1", c.n_fft == 512
+    const bool ok = !store
+        ? STAGE(ctx, s, "stft_cov1_nostore", c.n_fft == 512
+            ? (launch_stft_cov<512, false>(M, grid, (hipStream_t)s, y, mask_z, nullptr, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
+                                           ctx->T, c.pad_mode, chunks, runw))
+            : (launch_stft_cov<1024, false>(M, grid, (hipStream_t)s, y, mask_z, nullptr, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
+                                            ctx->T, c.pad_mode, chunks, runw)))
+        : STAGE(ctx, s, "stft_cov1", c.n_fft == 512
         ? launch_stft_cov<512>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
                                ctx->T, c.pad_mode, chunks, runw)
         : launch_stft_cov<1024>(M, grid, (hipStream_t)s, y, mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length,
@@ -830,6 +839,7 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
     ctx->loc_M = M;
     ctx->loc_X = X;
     ctx->loc_mask = mask_z;
+    if (!store) ctx->loc_M = 0;       // nothing to pair these partial sums with later
     return check_launch(ctx, "k_stft_cov");
 }
 
@@ -1091,6 +1101,32 @@ static int acquire_ws(disco_ctx* ctx, void* workspace, size_t workspace_bytes, c
     return 0;
 }
 
+// Single node, enhanced output only: iSTFT(w^H STFT(y)) straight from the samples (k_stft_apply_istft), 512-point STFT, M <= 4
+static int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, float* out, disco_stream s) {
+    const disco_cfg& c = ctx->cfg;
+    const long long G = (long long)c.rooms * c.nodes;
+    const int n_seg = (c.length + c.hop - 1) / c.hop;
+    const long long runs_wanted = std::max<long long>(1, (8192 + G - 1) / G);          // >= ~8192 waves
+    int pairs = (int)(((n_seg + runs_wanted - 1) / runs_wanted + 2) / 2);
+    pairs = std::min(64, std::max(4, pairs));
+    if (ctx->tune_pairs > 0) pairs = ctx->tune_pairs;
+    const int runs = (n_seg + 2 * pairs - 2) / (2 * pairs - 1);
+    const long long items = G * runs;
+    if (stft_blocks(items) > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: batch too large for one launch");
+    const dim3 grid((unsigned)stft_blocks(items)), block(64 * STFT_WAVES);
+    switch (c.mics) {
+#define C_(M_)                                                                                                          \
+    case M_:                                                                                                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_apply_istft<512, M_>), grid, block, 0, (hipStream_t)s, y, (const c32*)w, out, ctx->d_win, \
+                           ctx->d_tw, c.length, ctx->T, c.pad_mode, runs, pairs, items);                                \
+        break;
+        C_(1) C_(2) C_(3) C_(4)
+#undef C_
+        default: return DISCO_E_UNSUPPORTED;
+    }
+    return check_launch(ctx, "k_stft_apply_istft");
+}
+
 extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
                                    disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
     DISCO_ENTER(ctx);
@@ -1110,8 +1146,15 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     const int64_t G = (int64_t)c.rooms * c.nodes;
     const int M = c.mics, P2 = c.mics + c.nodes - 1;
     int rc;
-    // step 1 (tango.py:326-376): STFT + covariance in one pass, solve straight from the partial sums
     int chunks1 = 1;
+    if (c.nodes == 1 && mask_w == mask_z && !z_y && !yf && c.n_fft == 512 && M <= 4) {
+        // single node, enhanced output only (config C2): nothing is materialised -- one pass over the samples for the
+        // statistics, one for filter + iSTFT with the spectra recomputed (get_z_signals.py:274-315 + tango.py:528)
+        if ((rc = stft_cov_partials(ctx, y, mask_z, nullptr, &chunks1, s, false))) return rc;
+        if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks1, M, w, s)))) return rc;
+        return STAGE(ctx, s, "stft_apply_istft", stft_apply_istft(ctx, y, w, out, s));
+    }
+    // step 1 (tango.py:326-376): STFT + covariance in one pass, solve straight from the partial sums
     if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks1, s))) return rc;
     if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks1, M, w, s)))) return rc;
     if (c.nodes == 1 && mask_w == mask_z && !z_y && !yf && c.n_fft == 512) {

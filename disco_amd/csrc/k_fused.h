@@ -419,4 +419,140 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
     }
 }
 
+// ---- single node: STFT -> filter -> iSTFT in one pass over the SAMPLES (config C2; get_z_signals.py:274-315 + tango.py:528) ------
+// With one node there is no exchange and step 2 repeats step 1, so after the statistics pass (k_stft_cov<.., STORE = false>)
+// and the solve, the output is iSTFT(w^H STFT(y)).  Reading the spectra back would move 8 M F bytes per node-frame; recomputing
+// them from the 4 M H bytes of samples they came from moves a quarter of that, and nothing but the time signal is written: the
+// pass is pure wave-local arithmetic (M/2 forward transforms per frame, one inverse per frame pair, no workgroup barrier).
+// A wave owns `pairs` frame pairs of one node (2 pairs - 1 hop segments; consecutive waves overlap by one frame, as in
+// k_step2_apply_istft); the half-window shared by consecutive frames is recycled in registers as in k_stft.
+template <int N, int M>
+__global__ __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_istft(const float* __restrict__ x, const c32* __restrict__ wf,
+                                                                                    float* __restrict__ out, const float* __restrict__ win,
+                                                                                    const c32* __restrict__ tw, int L, int T, int pad_mode,
+                                                                                    int runs_per_node, int pairs, long long n_witems) {
+    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2, EH = E / 2, NJ = EH + 1, CHP = (M + 1) / 2;
+    __shared__ StftShared<N> sh;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * STFT_WAVES + wave;
+    if (item >= n_witems) return;                  // no block-level synchronisation anywhere below
+    const long long g = item / runs_per_node;
+    const int s0 = (int)(item % runs_per_node) * (2 * pairs - 1);             // first hop segment == first frame
+    c32* buf = sh.buf[wave];
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
+    float w[E];
+    load_window<N>(w, win, lane);
+    c32 wg[NJ][M];                                  // the node's filter at this lane's bins (f = lane + 64 j; lane 0: Nyquist too)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int f = (j < EH) ? lane + 64 * j : F - 1;
+#pragma unroll
+        for (int i = 0; i < M; ++i) wg[j][i] = wf[(g * F + f) * M + i];
+    }
+    const float* xa[CHP];
+    const float* xb[CHP];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) {
+        xa[p] = x + (g * M + 2 * p) * (long long)L;
+        xb[p] = (2 * p + 1 < M) ? x + (g * M + 2 * p + 1) * (long long)L : xa[p];
+    }
+    c32 raw[CHP][E];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) load_frame_slots<N, 0, E>(raw[p], xa[p], xb[p], min(s0, T - 1), L, pad_mode, lane);
+    float carry[EH];
+#pragma unroll
+    for (int e = 0; e < EH; ++e) carry[e] = 0.f;
+    float* og = out + g * (long long)L;
+    for (int pr = 0; pr < pairs; ++pr) {
+        const int tA = s0 + 2 * pr;
+        c32 yf[2][NJ];
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+            const int t = tA + fr;
+            c32 nxt[CHP][EH];                        // the next frame's new half-window, in flight under this frame's transforms
+#pragma unroll
+            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], min(t + 1, T - 1), L, pad_mode, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) yf[fr][j] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < CHP; ++p) {
+                c32 v[E];
+                apply_window<N>(v, raw[p], w, 2 * p + 1 < M);
+                fft_wave<N>(v, wtw, buf, lane);
+                rfft_pair_untangle<N>(v, buf, lane, [&](int j, int, c32 a, c32 b) {
+                    // yf += conj(w_2p) X_2p + conj(w_2p+1) X_2p+1
+                    c32 acc = yf[fr][j];
+                    acc.x = fmaf(wg[j][2 * p].x, a.x, fmaf(wg[j][2 * p].y, a.y, acc.x));
+                    acc.y = fmaf(wg[j][2 * p].x, a.y, fmaf(-wg[j][2 * p].y, a.x, acc.y));
+                    if (2 * p + 1 < M) {
+                        acc.x = fmaf(wg[j][2 * p + 1].x, b.x, fmaf(wg[j][2 * p + 1].y, b.y, acc.x));
+                        acc.y = fmaf(wg[j][2 * p + 1].x, b.y, fmaf(-wg[j][2 * p + 1].y, b.x, acc.y));
+                    }
+                    yf[fr][j] = acc;
+                });
+            }
+            if (t >= T) {                            // frames past the signal contribute nothing
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) yf[fr][j] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int p = 0; p < CHP; ++p)
+#pragma unroll
+                for (int e = 0; e < EH; ++e) {
+                    DISCO_CONSUME(nxt[p][e].x);
+                    DISCO_CONSUME(nxt[p][e].y);
+                    raw[p][e] = raw[p][e + EH];
+                    raw[p][e + EH] = nxt[p][e];
+                }
+        }
+        // ---- V = A~ + i B~ (Hermitian extensions of the two filtered frames), conjugated for the inverse-by-forward trick
+        DISCO_LDS_WAR();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < EH || lane == 0) {
+                const int f = (j < EH) ? lane + 64 * j : F - 1;
+                c32 A = yf[0][j], B = yf[1][j];
+                if (f == 0 || f == N / 2) {          // irfft ignores the imaginary part of DC and Nyquist
+                    A.y = 0.f;
+                    B.y = 0.f;
+                }
+                buf[fft_pad<N>(f)] = make_float2(A.x - B.y, -(A.y + B.x));
+                if (f != 0 && f != N / 2) buf[fft_pad<N>(N - f)] = make_float2(A.x + B.y, A.y - B.x);
+            }
+        }
+        DISCO_LDS_RAW();
+        c32 v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = buf[fft_pad<N>(lane + 64 * e)];
+        fft_wave<N>(v, wtw, buf, lane);
+        const float inv = 1.0f / N;
+        float gA[E], gB[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            gA[e] = v[e].x * (w[e] * inv);
+            gB[e] = -v[e].y * (w[e] * inv);
+        }
+        // ---- overlap-add: segment (tA-1) = carry + gA[lo], segment tA = gA[hi] + gB[lo], carry <- gB[hi]
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int seg = tA - 1 + which;
+            const bool emit = (which == 1 || pr > 0) && seg >= 0 && seg < T;     // the run's first "carry" segment belongs to its predecessor
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const float hi = which == 0 ? carry[e] : gA[e + EH];
+                const float lo = which == 0 ? gA[e] : gB[e];
+                const long long pos = (long long)seg * H + lane + 64 * e;
+                float wss = w[e + EH] * w[e + EH];
+                if (seg + 1 < T) wss += w[e] * w[e];
+                float val = hi + lo;
+                if (wss > 1.17549435e-38f) val /= wss;
+                if (emit && pos < L) og[pos] = val;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EH; ++e) carry[e] = gB[e + EH];
+    }
+}
+
 }  // namespace disco

@@ -338,7 +338,9 @@ struct alignas(16) StftCovShared {
 #ifndef DISCO_SC_WPE
 #define DISCO_SC_WPE 3
 #endif
-template <int N, int M>
+// STORE = false: the spectra are reduced into the covariances and dropped (single-node path: the filter pass recomputes them
+// from the samples, k_stft_apply_istft, instead of reading 8 M F bytes per node-frame back)
+template <int N, int M, bool STORE = true>
 __global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WPE : 1) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
                                                                c32* __restrict__ X, float4* __restrict__ part,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
@@ -436,8 +438,8 @@ __global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WP
         for (int ww = 0; ww < STFT_WAVES; ++ww) {
             const int t2 = tb + ww * runw + it;
             if (t2 < min(T, tb + (ww + 1) * runw)) {          // workgroup-uniform
-                c32* Xo = X + ((g * T + t2) * (long long)F) * M;
-                if ((M & 1) == 0) {
+                c32* Xo = STORE ? X + ((g * T + t2) * (long long)F) * M : nullptr;
+                if (STORE && (M & 1) == 0) {
                     // even M: the tile row IS the X row (F*M complex, contiguous) -> straight 16-B-per-lane copy, every
                     // wave store covers 1 KiB of consecutive bytes (a per-bin store would touch each 128-B line twice)
                     const float4* src = reinterpret_cast<const float4*>(&sh.tile[ww][0][0]);
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WP
                         xv[2 * p] = make_float2(q4.x, q4.y);
                         xv[2 * p + 1] = make_float2(q4.z, q4.w);
                     }
-                    if ((M & 1) != 0) {
+                    if (STORE && (M & 1) != 0) {
 #pragma unroll
                         for (int i = 0; i < M; ++i) Xo[(long long)f * M + i] = xv[i];
                     }
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WP
                     cov_accumulate_shared<M>(xv, m * m, mc * mc, acc_s[b], acc_n[b]);
                 }
                 // Nyquist bin
-                if ((M & 1) != 0 && tid < M) Xo[(long long)(F - 1) * M + tid] = sh.tile[ww][F - 1][tid];
+                if (STORE && (M & 1) != 0 && tid < M) Xo[(long long)(F - 1) * M + tid] = sh.tile[ww][F - 1][tid];
                 if (tid < 2 * NP) {
                     const float m = (tid & 1) ? 1.f - mny[ww] : mny[ww];
                     const c32 a = sh.tile[ww][F - 1][ny_i], b2 = sh.tile[ww][F - 1][ny_j];
