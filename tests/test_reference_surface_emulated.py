@@ -124,3 +124,34 @@ def test_long_reference_golden_scene_direct_1e4(emulated_package, golden_dir):
             if f'{nm}{k}' in g.files:
                 e = relerr(res[i][k], g[f'{nm}{k}'])
                 assert e < (2e-5 if 'mask' in nm else 1e-4), (nm, k, e)
+
+
+def test_result_pickles(emulated_package, tmp_path):
+    """results_tango_* / results_mwf_* (tango.py:617-635): the reference's keys and file names; level metrics equal the
+    restatement of the reference's metrics.py; the mir_eval / pystoi keys are present and NaN."""
+    import pickle
+    from disco_amd.speech_enhancement import results_io as rio
+    from oracle import metrics_oracle as mor
+    rng = np.random.default_rng(3)
+    K, L, fs = 2, 16000 + 6000, 16000
+    s_in, n_in = 0.1 * rng.standard_normal((K, L)), 0.05 * rng.standard_normal((K, L))
+    sf_t, nf_t = 0.9 * s_in + 0.01 * rng.standard_normal((K, L)), 0.3 * n_in
+    szf_t, nzf_t = 0.8 * s_in, 0.5 * n_in
+    s_dry, n_dry = 0.2 * rng.standard_normal(L), 0.1 * rng.standard_normal(L)
+    res, resz = rio.room_results(s_in, n_in, sf_t, nf_t, szf_t, nzf_t, rnd_snrs=[3.0], s_dry=s_dry, n_dry=n_dry, fs=fs)
+    assert tuple(res) == rio.RESULT_KEYS_TANGO and tuple(resz) == rio.RESULT_KEYS_MWF
+    for k in rio.THIRD_PARTY_KEYS:
+        for r in (res, resz):
+            if k in r:
+                assert np.all(np.isnan(r[k])) and len(r[k]) == K
+    f32 = lambda a: np.asarray(a, np.float32)
+    for k in range(K):
+        assert abs(res['snr_out'][k] - mor.fw_snr(f32(sf_t[k, fs:]), f32(nf_t[k, fs:]), fs)[1]) < 1e-3
+        assert abs(resz['snr_out'][k] - mor.fw_snr(f32(szf_t[k, fs:]), f32(nzf_t[k, fs:]), fs)[1]) < 1e-3
+        assert abs(res['snr_in_cnv'][k] - mor.fw_snr(f32(s_in[k, fs:]), f32(n_in[k, fs:]), fs)[1]) < 1e-3
+        assert abs(res['fw_sd_cnv'][k] - mor.fw_sd(f32(sf_t[k, fs:]), f32(s_in[k, fs:]), fs)[1]) < 1e-3
+        assert abs(res['fw_sd_dry'][k] - mor.fw_sd(f32(sf_t[k, fs:]), f32(s_dry[fs:]), fs)[1]) < 1e-3
+    files = rio.write_result_pickles(str(tmp_path), 11001, 'ssn', res, resz)
+    assert [os.path.basename(f) for f in files] == ['results_tango_11001_ssn.p', 'results_mwf_11001_ssn.p']
+    back = pickle.load(open(files[0], 'rb'))
+    assert set(back) == set(rio.RESULT_KEYS_TANGO) and np.allclose(back['snr_out'], res['snr_out'])
