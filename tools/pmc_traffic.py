@@ -9,21 +9,43 @@ Both corrections were re-calibrated in the same runs on kernels whose traffic is
   (reads every spectrum once plus the 8/7 frame overlap; writes exactly R*K*L*4 bytes).
 Usage: tools/pmc_traffic.py gpurun_out/pmc_raw.json profiles/pmc_traffic.json"""
 import json
+import re
 import sys
 
+import hashlib
+import os
+
+# kernel-name prefix -> the library's stage name (disco_stage_report / bench.py `stages`); several kernels can serve one stage
 STAGE_OF = {'k_stft_cov<': 'stft_cov1', 'k_stft<': 'stft', 'k_mask_oracle<': 'mask_oracle', 'k_istft<': 'istft',
-            'k_step2_cov_fused<': 'step2_cov', 'k_step2_apply_istft<': 'step2_apply_istft', 'k_step2_apply_fused<': 'step2_apply', 'k_cov<': 'cov', 'k_apply<': 'apply',
-            'k_gevd_mwf_r1<': 'solve'}
+            'k_step2_cov_fused<': 'step2_cov', 'k_step2_apply_istft<': 'step2_apply_istft', 'k_step2_apply_fused<': 'step2_apply',
+            'k_stft_apply_istft<': 'stft_apply_istft', 'k_cov_split<': 'cov_split', 'k_cov_big<': 'cov_big', 'k_cov<': 'cov',
+            'k_apply_m<': 'apply_m', 'k_apply<': 'apply', 'k_gevd_mwf_r1_thread<': 'solve_thread', 'k_gevd_mwf_r1<': 'solve'}
+
+
+def csrc_digest():
+    """Same digest as bench.py: identifies the kernel sources the counters were measured on."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(repo, 'disco_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
 
 raw = json.load(open(sys.argv[1]))
 out = {'_method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) on '
                   '`bench.py --steps 1 --warmup 0 --no-stage-timing`; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024',
-       '_calibration': {}}
+       '_calibration': {}, '_csrc_digest': csrc_digest()}
 for k, v in raw.items():
     if k.startswith('_'):
         continue
     if 'AbsFunctor' in k:
         out['_calibration']['torch_abs_1.28GB'] = {c: x['per_dispatch'] * 1024 for c, x in v.items()}
+    if 'neg' in k.lower() and 'disco::' not in k and max(x['per_dispatch'] for x in v.values()) * 1024 > 1e9:
+        # bench.py --pmc-calibrate: torch.neg over 2^30 floats = 4 GiB read + 4 GiB written by one kernel, known exactly
+        out['_calibration']['torch_neg_4GiB'] = dict({c: x['per_dispatch'] * 1024 for c, x in v.items()}, known_bytes_each_way=4 * 2 ** 30,
+                                                      kernel=k[:80])
     if 'disco::' not in k:
         continue
     name = k.replace('void disco::', '')
@@ -35,8 +57,15 @@ for k, v in raw.items():
     if f is not None and w is not None:
         ent['hbm_bytes_per_launch'] = 2 * f * 1024 + w * 1024
     stage = next((s for p, s in STAGE_OF.items() if name.startswith(p)), name)
-    if stage == 'solve':
-        stage = 'solve1' if '<4,' in name else 'solve2'
+    # bench.py looks the dominant stage up by ITS name: map kernels to the stage they serve in the profiled configuration
+    if stage == 'stft_cov1' and ', false>' in name:
+        stage = 'stft_cov1_nostore'
+    if stage in ('solve', 'solve_thread'):
+        stage = 'solve1' if (stage == 'solve_thread' or '<4,' in name or '<8,' in name) else 'solve2'
+    if stage == 'cov_split':
+        stage = 'cov1' if re.search(r'<\d+, 0,', name) else 'cov2'
+    if stage in out and 'hbm_bytes_per_launch' in out[stage] and 'hbm_bytes_per_launch' in ent:
+        continue          # first (largest-share) kernel of a stage wins
     out[stage] = ent
 json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print(json.dumps({k: (round(v['hbm_bytes_per_launch'] / 1e9, 2) if isinstance(v, dict) and 'hbm_bytes_per_launch' in v else None)
