@@ -385,8 +385,6 @@ def main(argv=None):
             achieved = launch_bytes / (launch_ms * 1e-3)
             traffic, traffic_note = None, None
             tfile = os.path.join(REPO, 'profiles', f'pmc_traffic_{args.config}.json')
-            if not os.path.exists(tfile) and args.config == 'C3':
-                tfile = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
             if os.path.exists(tfile):
                 try:
                     tj = json.load(open(tfile))
