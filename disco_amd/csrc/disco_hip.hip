@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -348,12 +349,19 @@ template <int N>
 static bool launch_stft(int chp, dim3 grid, hipStream_t st, const float* x, c32* X, const float* win, const c32* tw, int chans,
                         int L, int T, int pad_mode, int runs, long long n_items) {
     const dim3 block(64 * STFT_WAVES);
+    // one channel pair per wave (k_stft_pairs) where k_stft's all-pairs-in-registers form drops to one wave per SIMD (measured:
+    // N = 1024 from 2 pairs on, N = 512 from 3); the grid is (group, run) then, not waves
+    if (chp >= (N == 1024 ? 2 : 3) && chp <= STFT_WAVES && n_items <= 0x7fffffffLL) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_pairs<N>), dim3((unsigned)n_items), block, 0, st, x, X, win, tw, chans, L, T, pad_mode,
+                           runs);
+        return true;
+    }
     switch (chp) {
 #define C_(P_)                                                                                                          \
     case P_:                                                                                                            \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<N, P_>), grid, block, 0, st, x, X, win, tw, chans, L, T, pad_mode, runs, n_items); \
         return true;
-        C_(1) C_(2) C_(3) C_(4)
+        C_(1) C_(2)
 #undef C_
     }
     return false;
@@ -485,6 +493,16 @@ static int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco
 
 template <int M, int KR>
 static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {
+    if constexpr (KR > 0 && M % 2 == 0) {
+        static const bool staged = [] { const char* e = getenv("DISCO_COV_LDS"); return !e || atoi(e) != 0; }();
+        if (staged && (a.F - 1) % 64 == 0) {               // frames staged through LDS once per workgroup (k_cov.h)
+            if (skiploc)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+            return;
+        }
+    }
     if constexpr (KR > 0) {
         if (skiploc) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
@@ -1120,7 +1138,7 @@ static int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_apply_istft<512, M_>), grid, block, 0, (hipStream_t)s, y, (const c32*)w, out, ctx->d_win, \
                            ctx->d_tw, c.length, ctx->T, c.pad_mode, runs, pairs, items);                                \
         break;
-        C_(1) C_(2) C_(3) C_(4)
+        C_(1) C_(2)
 #undef C_
         default: return DISCO_E_UNSUPPORTED;
     }
@@ -1450,7 +1468,7 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
         const long long grid = (a.n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;                              \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf_thread<P_>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, st, a); \
     } break;
-        C_(1) C_(2) C_(3) C_(4)
+        C_(1) C_(2)
 #undef C_
 #define C_(P_)                                                                                                          \
     case P_: {                          /* a group of 8 / 16 lanes per (room, node, bin) */                             \

@@ -306,6 +306,8 @@ struct CovSplitRole {
     // components [X0, X1) and [Y0, Y1) of v = [x_0..x_{M-1}, z_0..z_{KR-1}]; TRI: the two upper triangles, else the X x Y block
     static constexpr int NX = X1 - X0, NY = Y1 - Y0;
     static constexpr int NPAIR = TRI ? NX * (NX + 1) / 2 + NY * (NY + 1) / 2 : NX * NY;
+    static constexpr int x0 = X0, x1 = X1, y0 = Y0, y1 = Y1;
+    static constexpr bool tri = TRI;
 };
 
 template <int M, int KR, int C0, int C1>
@@ -330,6 +332,88 @@ __device__ __forceinline__ void cov_split_fetch(c32* u, const c32* __restrict__ 
     }
 #pragma unroll
     for (int c = ZA; c < C1; ++c) u[c - C0] = zp[c - M][tf];
+}
+
+// acc += (wa, wb) x { u_i conj(u_j) } over the role's pairs (TRI: the two upper triangles of X and Y, else the X x Y block)
+#ifndef DISCO_COV_PK
+#define DISCO_COV_PK 0
+#endif
+#if DISCO_COV_PK && DISCO_PK && defined(__clang__)
+// packed form: (pr, pi) = a conj(b) as v_pk_mul + v_pk_fma, then one v_pk_fma per part on the pair (Rss, Rnn) of sums -- 4
+// instructions per pair of components instead of 8; the sums live as (acc_s.x, acc_n.x), (acc_s.y, acc_n.y)
+__device__ __forceinline__ void cov_pair_acc(const c32 a, const c32 b, const float wa, const float wb, c32& as, c32& an) {
+    const v2f w2 = {wa, wb};
+    const v2f p = __builtin_elementwise_fma(v2f{a.x, a.x}, v2f{b.x, -b.y}, v2f{a.y, a.y} * v2f{b.y, b.x});
+    const v2f re = __builtin_elementwise_fma(w2, v2f{p.x, p.x}, v2f{as.x, an.x});
+    const v2f im = __builtin_elementwise_fma(w2, v2f{p.y, p.y}, v2f{as.y, an.y});
+    as = make_float2(re.x, im.x);
+    an = make_float2(re.y, im.y);
+}
+#else
+__device__ __forceinline__ void cov_pair_acc(const c32 a, const c32 b, const float wa, const float wb, c32& as, c32& an) {
+    const float pr = fmaf(a.x, b.x, a.y * b.y);          // a conj(b)
+    const float pi = fmaf(a.x, -b.y, a.y * b.x);
+    as.x = fmaf(wa, pr, as.x);
+    an.x = fmaf(wb, pr, an.x);
+    as.y = fmaf(wa, pi, as.y);
+    an.y = fmaf(wb, pi, an.y);
+}
+#endif
+__device__ __forceinline__ void cov_diag_acc(const c32 a, const float wa, const float wb, c32& as, c32& an) {
+    const float pr = fmaf(a.x, a.x, a.y * a.y);
+    as.x = fmaf(wa, pr, as.x);
+    an.x = fmaf(wb, pr, an.x);
+}
+
+template <class Role, bool TRI, int NX, int NY>
+__device__ __forceinline__ void cov_split_accumulate(const c32* ux, const c32* uy, const float wa, const float wb, c32* acc_s,
+                                                     c32* acc_n) {
+    int q = 0;
+    if constexpr (TRI) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = i; j < NX; ++j, ++q) {
+                if (j == i) cov_diag_acc(ux[i], wa, wb, acc_s[q], acc_n[q]);
+                else cov_pair_acc(ux[i], ux[j], wa, wb, acc_s[q], acc_n[q]);
+            }
+#pragma unroll
+        for (int i = 0; i < NY; ++i)
+#pragma unroll
+            for (int j = i; j < NY; ++j, ++q) {
+                if (j == i) cov_diag_acc(uy[i], wa, wb, acc_s[q], acc_n[q]);
+                else cov_pair_acc(uy[i], uy[j], wa, wb, acc_s[q], acc_n[q]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NY; ++j, ++q) cov_pair_acc(ux[i], uy[j], wa, wb, acc_s[q], acc_n[q]);      // i in X, j in Y
+    }
+}
+
+// the role's sums -> their places in the upper triangle of the (chunk, bin) partial block o[NP]
+template <int P, int X0, int Y0, bool TRI, int NX, int NY>
+__device__ __forceinline__ void cov_split_store(float4* o, const c32* acc_s, const c32* acc_n) {
+    int q = 0;
+    if constexpr (TRI) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = i; j < NX; ++j, ++q)
+                o[tri_index<P>(X0 + i, X0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+#pragma unroll
+        for (int i = 0; i < NY; ++i)
+#pragma unroll
+            for (int j = i; j < NY; ++j, ++q)
+                o[tri_index<P>(Y0 + i, Y0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NY; ++j, ++q)                 // X precedes Y in v: (X0 + i, Y0 + j) is in the upper triangle
+            o[tri_index<P>(X0 + i, Y0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+    }
 }
 
 template <int M, int KR, int X0, int X1, int Y0, int Y1, bool TRI>
@@ -377,47 +461,7 @@ __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, in
             const bool ok = live && (tu + t_off) < t1;
             const float m = ok ? mcur : 0.f, mc = ok ? 1.f - mcur : 0.f;
             const float wa = m * m, wb = mc * mc;
-            int q = 0;
-            if constexpr (TRI) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-#pragma unroll
-                    for (int j = i; j < NX; ++j, ++q) {
-                        const float pr = fmaf(ux[i].x, ux[j].x, ux[i].y * ux[j].y);
-                        acc_s[q].x = fmaf(wa, pr, acc_s[q].x);
-                        acc_n[q].x = fmaf(wb, pr, acc_n[q].x);
-                        if (j != i) {
-                            const float pi = fmaf(ux[i].y, ux[j].x, -(ux[i].x * ux[j].y));
-                            acc_s[q].y = fmaf(wa, pi, acc_s[q].y);
-                            acc_n[q].y = fmaf(wb, pi, acc_n[q].y);
-                        }
-                    }
-#pragma unroll
-                for (int i = 0; i < NY; ++i)
-#pragma unroll
-                    for (int j = i; j < NY; ++j, ++q) {
-                        const float pr = fmaf(uy[i].x, uy[j].x, uy[i].y * uy[j].y);
-                        acc_s[q].x = fmaf(wa, pr, acc_s[q].x);
-                        acc_n[q].x = fmaf(wb, pr, acc_n[q].x);
-                        if (j != i) {
-                            const float pi = fmaf(uy[i].y, uy[j].x, -(uy[i].x * uy[j].y));
-                            acc_s[q].y = fmaf(wa, pi, acc_s[q].y);
-                            acc_n[q].y = fmaf(wb, pi, acc_n[q].y);
-                        }
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-#pragma unroll
-                    for (int j = 0; j < NY; ++j, ++q) {
-                        const float pr = fmaf(ux[i].x, uy[j].x, ux[i].y * uy[j].y);          // u_i conj(u_j), i in X, j in Y
-                        const float pi = fmaf(ux[i].y, uy[j].x, -(ux[i].x * uy[j].y));
-                        acc_s[q].x = fmaf(wa, pr, acc_s[q].x);
-                        acc_n[q].x = fmaf(wb, pr, acc_n[q].x);
-                        acc_s[q].y = fmaf(wa, pi, acc_s[q].y);
-                        acc_n[q].y = fmaf(wb, pi, acc_n[q].y);
-                    }
-            }
+            cov_split_accumulate<Role, TRI, NX, NY>(ux, uy, wa, wb, acc_s, acc_n);
 #pragma unroll
             for (int i = 0; i < NX; ++i) ux[i] = nx[i];
 #pragma unroll
@@ -437,25 +481,7 @@ __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, in
         }
         if (live && (!nyq || lane == 0)) {
             float4* o = a.part + (((g * a.chunks + c) * F) + f) * (long long)NP;
-            int q = 0;
-            if constexpr (TRI) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-#pragma unroll
-                    for (int j = i; j < NX; ++j, ++q)
-                        o[tri_index<P>(X0 + i, X0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
-#pragma unroll
-                for (int i = 0; i < NY; ++i)
-#pragma unroll
-                    for (int j = i; j < NY; ++j, ++q)
-                        o[tri_index<P>(Y0 + i, Y0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-#pragma unroll
-                    for (int j = 0; j < NY; ++j, ++q)                 // X precedes Y in v: (X0 + i, Y0 + j) is in the upper triangle
-                        o[tri_index<P>(X0 + i, Y0 + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
-            }
+            cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
         }
     }
 }
@@ -465,11 +491,30 @@ __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, in
 template <int KR, bool SKIPLOC>
 constexpr int cov_split_waves() { return (KR > 0 ? 6 : 0) + (SKIPLOC ? 0 : 2); }
 
+// role of wave `role` of a workgroup: fn(CovSplitRole<...>{}) with the block of pairs it owns
+template <int M, int KR, bool SKIPLOC, class Fn>
+__device__ __forceinline__ void cov_split_roles(const int role, Fn&& fn) {
+    constexpr int MA = (M + 1) / 2, KB = (KR + 1) / 2, P = M + KR;
+    switch (role) {
+        case 0: fn(CovSplitRole<M, KR, 0, MA, M, M + KB, false>{}); break;
+        case 1: fn(CovSplitRole<M, KR, 0, MA, M + KB, P, false>{}); break;
+        case 2: fn(CovSplitRole<M, KR, MA, M, M, M + KB, false>{}); break;
+        case 3: fn(CovSplitRole<M, KR, MA, M, M + KB, P, false>{}); break;
+        case 4: fn(CovSplitRole<M, KR, M, M + KB, M + KB, P, true>{}); break;
+        case 5: fn(CovSplitRole<M, KR, M, M + KB, M + KB, P, false>{}); break;
+        case 6:
+            if constexpr (!SKIPLOC) fn(CovSplitRole<M, KR, 0, MA, MA, M, true>{});
+            break;
+        default:
+            if constexpr (!SKIPLOC) fn(CovSplitRole<M, KR, 0, MA, MA, M, false>{});
+            break;
+    }
+}
+
 // grid = R*Kl * (tiles + 1) * chunks blocks of 64 * cov_split_waves() threads; Zs == Zn and mask_remote != 0 are the caller's contract
 template <int M, int KR, bool SKIPLOC>
 __global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_split(CovArgs a) {
     static_assert(KR > 0 || !SKIPLOC, "nothing to compute");
-    constexpr int MA = (M + 1) / 2, KB = (KR + 1) / 2, P = M + KR;
     const int nbin = a.F - 1, tiles = (nbin + 63) / 64;
     int bid = blockIdx.x;
     const int c = bid % a.chunks;
@@ -478,20 +523,168 @@ __global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_s
     const long long g = bid / (tiles + 1);
     const int lane = threadIdx.x & 63;
     const int role = wave_id() + (KR > 0 ? 0 : 6);
-    switch (role) {
-        case 0: cov_split_wave<M, KR, 0, MA, M, M + KB, false>(a, g, c, tile, lane); break;
-        case 1: cov_split_wave<M, KR, 0, MA, M + KB, P, false>(a, g, c, tile, lane); break;
-        case 2: cov_split_wave<M, KR, MA, M, M, M + KB, false>(a, g, c, tile, lane); break;
-        case 3: cov_split_wave<M, KR, MA, M, M + KB, P, false>(a, g, c, tile, lane); break;
-        case 4: cov_split_wave<M, KR, M, M + KB, M + KB, P, true>(a, g, c, tile, lane); break;
-        case 5: cov_split_wave<M, KR, M, M + KB, M + KB, P, false>(a, g, c, tile, lane); break;
-        case 6:
-            if constexpr (!SKIPLOC) cov_split_wave<M, KR, 0, MA, MA, M, true>(a, g, c, tile, lane);
-            break;
-        default:
-            if constexpr (!SKIPLOC) cov_split_wave<M, KR, 0, MA, MA, M, false>(a, g, c, tile, lane);
-            break;
+    cov_split_roles<M, KR, SKIPLOC>(role, [&](auto tag) {
+        using R_ = decltype(tag);
+        cov_split_wave<M, KR, R_::x0, R_::x1, R_::y0, R_::y1, R_::tri>(a, g, c, tile, lane);
+    });
+}
+
+// ---- the same partition with the frames staged through LDS ---------------------------------------------------------------------
+// In k_cov_split every wave fetches the (up to two) half-groups of v its block of pairs touches: 2.9 x the tile's bytes leave
+// L1/L2, and because the waves of a workgroup drift apart, 1.36 x reach the fabric (PMC, C5).  Here the workgroup's waves share
+// the fetch: DISCO_COV_STAGE_FRAMES frames of the tile (mics as they lie in X, the remote rows plane by plane, the mask) are
+// loaded ONCE, 64 lanes x 16 / 8 / 4 bytes per wave-slot dealt round-robin to the waves, parked in registers during the
+// arithmetic on the previous stage, written to the other of two LDS buffers and published by one barrier per stage.  Needs
+// M even (16-byte granules of X) and F - 1 a multiple of 64 (every n_fft this library supports); the Nyquist tile, one bin
+// over many frames, keeps the direct path of cov_split_wave.
+#ifndef DISCO_COV_STAGE_FRAMES
+#define DISCO_COV_STAGE_FRAMES 2
+#endif
+#ifndef DISCO_COV_LDS_WPE
+#define DISCO_COV_LDS_WPE 3           // waves per SIMD the register allocation leaves room for
+#endif
+
+template <int M, int KR, int S>
+struct alignas(16) CovStage {
+    static constexpr int XP = M + 2;          // pitch of a bin's mic row: (M + 2) * 8 B keeps the lanes' ds_read_b128 off each other's banks
+    c32 xs[S][64][XP];
+    c32 zs[S][KR][64];
+    float ms[S][64];
+};
+
+template <int M, int KR, int S, int NW>
+struct CovStageLoader {
+    static constexpr int XH = M / 2, WSX = S * XH, WSZ = S * KR, WS = WSX + WSZ + S, NS = (WS + NW - 1) / NW;
+    float4 r[NS];
+    // wave-slot `slot` (wave-uniform): X granules first, then the remote rows, then the mask
+    __device__ __forceinline__ void load(const CovArgs& a, const long long g, const int f0, const int ts, const int t1, const int wid,
+                                         const int lane) {
+        const int T = a.T, F = a.F;
+        const long long r_ = g / a.Kl;
+        const int k = a.k0 + (int)(g % a.Kl);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int slot = wid + n * NW;
+            if (slot < WSX) {
+                int t = ts + slot / XH;
+                t = t < t1 ? t : t1 - 1;
+                const float4* src = reinterpret_cast<const float4*>(a.X + ((g * T + t) * (long long)F + f0) * M);
+                r[n] = src[(slot % XH) * 64 + lane];
+            } else if (slot < WSX + WSZ) {
+                const int zz = slot - WSX, jj = zz % KR;
+                int t = ts + zz / KR;
+                t = t < t1 ? t : t1 - 1;
+                const int j = jj < k ? jj : jj + 1;                              // concatenate_signals order
+                const c32 v = a.Zs[(z_plane(r_, j, a.K, a.R, a.zblk) * T + t) * (long long)F + f0 + lane];
+                r[n] = make_float4(v.x, v.y, 0.f, 0.f);
+            } else if (slot < WS) {
+                int t = ts + (slot - WSX - WSZ);
+                t = t < t1 ? t : t1 - 1;
+                r[n] = make_float4(a.mask[(g * T + t) * (long long)F + f0 + lane], 0.f, 0.f, 0.f);
+            }
+        }
     }
+    __device__ __forceinline__ void store(CovStage<M, KR, S>& st, const int wid, const int lane) const {
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int slot = wid + n * NW;
+            if (slot < WSX) {
+                const int i = (slot % XH) * 64 + lane;                           // float4 granule i of the frame's [64][M] block
+                *reinterpret_cast<float4*>(&st.xs[slot / XH][i / XH][2 * (i % XH)]) = r[n];
+            } else if (slot < WSX + WSZ) {
+                const int zz = slot - WSX;
+                st.zs[zz / KR][zz % KR][lane] = make_float2(r[n].x, r[n].y);
+            } else if (slot < WS) {
+                st.ms[slot - WSX - WSZ][lane] = r[n].x;
+            }
+        }
+    }
+};
+
+// components [C0, C1) of the lane's bin in frame s_ of a stage
+template <int M, int KR, int S, int C0, int C1>
+__device__ __forceinline__ void cov_stage_read(c32* u, const CovStage<M, KR, S>& st, const int s_, const int lane) {
+    constexpr int XA = C0 < M ? C0 : M, XB = C1 < M ? C1 : M, ZA = C0 > M ? C0 : M;
+    if constexpr (XB > XA) {
+        if constexpr (XA % 2 == 0 && (XB - XA) % 2 == 0) {
+#pragma unroll
+            for (int p = 0; p < (XB - XA) / 2; ++p) {
+                const float4 q = *reinterpret_cast<const float4*>(&st.xs[s_][lane][XA + 2 * p]);
+                u[XA - C0 + 2 * p] = make_float2(q.x, q.y);
+                u[XA - C0 + 2 * p + 1] = make_float2(q.z, q.w);
+            }
+        } else {
+#pragma unroll
+            for (int c = XA; c < XB; ++c) u[c - C0] = st.xs[s_][lane][c];
+        }
+    }
+#pragma unroll
+    for (int c = ZA; c < C1; ++c) u[c - C0] = st.zs[s_][c - M][lane];
+}
+
+template <int M, int KR, int NW, class Role>
+__device__ __forceinline__ void cov_split_wave_lds(const CovArgs& a, const long long g, const int c, const int tile, const int lane,
+                                                   const int wid, CovStage<M, KR, DISCO_COV_STAGE_FRAMES>* sh) {
+    constexpr int S = DISCO_COV_STAGE_FRAMES, P = M + KR, NP = P * (P + 1) / 2;
+    constexpr int NX = Role::NX, NY = Role::NY, NPAIR = Role::NPAIR, NPA = NPAIR > 0 ? NPAIR : 1;
+    const int T = a.T, F = a.F;
+    const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
+    const int f0 = tile * 64;
+    c32 acc_s[NPA], acc_n[NPA];
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
+    CovStageLoader<M, KR, S, NW> ld;
+    ld.load(a, g, f0, t0, t1, wid, lane);
+    ld.store(sh[0], wid, lane);
+    __syncthreads();
+    int b = 0;
+    for (int ts = t0; ts < t1; ts += S, b ^= 1) {          // every wave of the workgroup walks the same stages: the barriers match
+        const bool more = ts + S < t1;
+        if (more) ld.load(a, g, f0, ts + S, t1, wid, lane);          // in flight during the arithmetic below
+        if constexpr (NPAIR > 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < S; ++s_) {
+                c32 ux[NX > 0 ? NX : 1], uy[NY > 0 ? NY : 1];
+                cov_stage_read<M, KR, S, Role::x0, Role::x1>(ux, sh[b], s_, lane);
+                cov_stage_read<M, KR, S, Role::y0, Role::y1>(uy, sh[b], s_, lane);
+                const float mk = sh[b].ms[s_][lane];
+                const bool ok = ts + s_ < t1;
+                const float m = ok ? mk : 0.f, mc = ok ? 1.f - mk : 0.f;
+                cov_split_accumulate<Role, Role::tri, NX, NY>(ux, uy, m * m, mc * mc, acc_s, acc_n);
+            }
+        }
+        if (more) ld.store(sh[b ^ 1], wid, lane);
+        __syncthreads();
+    }
+    if constexpr (NPAIR > 0) {
+        float4* o = a.part + (((g * a.chunks + c) * F) + f0 + lane) * (long long)NP;
+        cov_split_store<P, Role::x0, Role::y0, Role::tri, NX, NY>(o, acc_s, acc_n);
+    }
+}
+
+template <int M, int KR, bool SKIPLOC>
+__global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>()), DISCO_COV_LDS_WPE) void k_cov_split_lds(CovArgs a) {
+    static_assert(KR > 0 && M % 2 == 0, "remote rows and 16-byte granules of X");
+    constexpr int NW = cov_split_waves<KR, SKIPLOC>();
+    __shared__ CovStage<M, KR, DISCO_COV_STAGE_FRAMES> sh[2];
+    const int nbin = a.F - 1, tiles = nbin / 64;          // the launcher checks nbin % 64 == 0
+    int bid = blockIdx.x;
+    const int c = bid % a.chunks;
+    bid /= a.chunks;
+    const int tile = bid % (tiles + 1);
+    const long long g = bid / (tiles + 1);
+    const int lane = threadIdx.x & 63;
+    const int wid = wave_id();
+    if (tile == tiles) {                                   // the Nyquist bin: lanes are frames there, no barrier on that path
+        cov_split_roles<M, KR, SKIPLOC>(wid, [&](auto tag) {
+            using R_ = decltype(tag);
+            cov_split_wave<M, KR, R_::x0, R_::x1, R_::y0, R_::y1, R_::tri>(a, g, c, tile, lane);
+        });
+        return;
+    }
+    cov_split_roles<M, KR, SKIPLOC>(wid, [&](auto tag) {
+        cov_split_wave_lds<M, KR, NW, decltype(tag)>(a, g, c, tile, lane, wid, sh);
+    });
 }
 
 // part [n_gf/F][chunks][F][NP] -> Rss, Rnn [n_gf][P][P], mean over T, Hermitian mirror.

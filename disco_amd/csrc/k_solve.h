@@ -21,11 +21,16 @@ namespace disco {
 #ifndef DISCO_SOLVE_PACKED
 #define DISCO_SOLVE_PACKED 1
 #endif
-// squaring stops one step after 1 - tr(B^2) fell below this: the sub-dominant weight rho is then < 5e-7 and the next
-// square, the one that is kept, carries rho^2 < 3e-13 (1e-8 instead of 1e-6 costs half a squaring on average and buys nothing
-// a float32 filter can show)
+// Squaring stops with the square whose tau = tr(B^2) came within DISCO_SQUARING_DONE of 1: 1 - tau ~ 2 rho (rho = the
+// sub-dominant weight (d1/d0)^(2^k) of the matrix that was squared), so the square that is kept carries rho^2 < 0.017.  The
+// rest of the way is covered by DISCO_POWER_STEPS power steps v <- B v on the column picked from it: each costs 1/P of a
+// squaring and multiplies the sub-dominant content by rho^2, leaving < 4 (0.017)^6 ~ 1e-10.  (Round 2 first ran the squaring
+// itself down to 1 - tau < 1e-6: three more squarings for every wave, since a wave leaves with its slowest pencil.)
 #ifndef DISCO_SQUARING_DONE
-#define DISCO_SQUARING_DONE 1e-6
+#define DISCO_SQUARING_DONE 0.2
+#endif
+#ifndef DISCO_POWER_STEPS
+#define DISCO_POWER_STEPS 5
 #endif
 #ifndef DISCO_SQ_ROWS
 #define DISCO_SQ_ROWS 1
@@ -280,6 +285,33 @@ __device__ __forceinline__ bool group_dominant(c64* g, c64 (*Ym)[SolveGeom<P>::Y
         if (have) v0[i] = zscale(v0[i], rb);
         else v0[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
     }
+    // ---- power steps on the kept square: (B v)[j] = sum_i conj(B[i][j]) v[i] (B is Hermitian), lane j from its own column;
+    // the new vector goes round the group through row 0 of Ym.  The top eigenvalue of the trace-normalised B is >= 1/P, so
+    // the length can wait until the end.
+#pragma unroll 1
+    for (int s = 0; s < DISCO_POWER_STEPS; ++s) {
+        c64 u = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            u.x = fma(g[i].x, v0[i].x, fma(g[i].y, v0[i].y, u.x));
+            u.y = fma(g[i].x, v0[i].y, fma(-g[i].y, v0[i].x, u.y));
+        }
+        DISCO_GROUP_SYNC();
+        if (j < P) Ym[0][j] = u;
+        DISCO_GROUP_SYNC();
+        if (have) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) v0[i] = Ym[0][i];
+        }
+    }
+    if (DISCO_POWER_STEPS > 0 && have) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) n2 = fma(v0[i].x, v0[i].x, fma(v0[i].y, v0[i].y, n2));
+        const double rn = rsqrt64(n2);
+#pragma unroll
+        for (int i = 0; i < P; ++i) v0[i] = zscale(v0[i], rn);
+    }
     return have;
 }
 
@@ -363,10 +395,10 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     // ---- dominant eigenpair of C by repeated squaring.  rank = 1 keeps only (d0, v0) (internal_formulas.py:63-69), so
     // the full diagonalisation a Jacobi solver performs (what this kernel did before: 5-7 sweeps of P(P-1)/2 rotations)
     // is not needed: with B_0 = C / tr C,  B_{k+1} = B_k^2 / tr(B_k^2)  converges to v0 v0^H and the sub-dominant
-    // directions decay like (d1/d0)^(2^k) -- 6-8 squarings for the ratios 0.5-0.9 met on real covariances, P^2 complex
+    // directions decay like (d1/d0)^(2^k) -- 3-6 squarings for the ratios 0.5-0.9 met on real covariances, P^2 complex
     // multiply-adds per lane each (a Jacobi SWEEP costs ~5 P^2).  tau_k = tr(B_k^2) = ||B_k||_F^2 <= 1 doubles as the
-    // normaliser and the convergence measure: 1 - tau ~ 2 (d1/d0)^(2^k), so once it is below DISCO_SQUARING_DONE the NEXT square is
-    // rank one to rounding.  Lane j owns column j; the columns meet through the group's LDS matrix Ym (wave-level
+    // normaliser and the convergence measure: 1 - tau ~ 2 (d1/d0)^(2^k); once it is below DISCO_SQUARING_DONE a few power
+    // steps on the square just formed finish the job at 1/P of the price of a squaring each.  Lane j owns column j; the columns meet through the group's LDS matrix Ym (wave-level
     // fences only: a group never spans waves).  An exactly repeated top eigenvalue never converges (tau -> 1/m) and
     // stops at the iteration cap with a vector of the dominant subspace, which is all any solver can return there.
     // The loop is wave-uniform (vote on the exit): groups that are done keep their B and idle.

@@ -157,6 +157,36 @@ __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a
     const double rb = have ? rsqrt64(best) : 0.0;
 #pragma unroll
     for (int i = 0; i < P; ++i) v0[i] = have ? zscale(v0[i], rb) : make_double2(i == 0 ? 1.0 : 0.0, 0.0);
+    // ---- power steps v <- B v on the kept square (k_solve.h: DISCO_POWER_STEPS), then unit length
+    if (P > 1) {
+#pragma unroll 1
+        for (int s = 0; s < DISCO_POWER_STEPS; ++s) {
+            c64 u[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                c64 a = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const c64 b = B.at(i, k);
+                    a.x = fma(b.x, v0[k].x, fma(-b.y, v0[k].y, a.x));
+                    a.y = fma(b.x, v0[k].y, fma(b.y, v0[k].x, a.y));
+                }
+                u[i] = a;
+            }
+            if (have) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) v0[i] = u[i];
+            }
+        }
+        if (DISCO_POWER_STEPS > 0 && have) {
+            double n2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) n2 = fma(v0[i].x, v0[i].x, fma(v0[i].y, v0[i].y, n2));
+            const double rn = rsqrt64(n2);
+#pragma unroll
+            for (int i = 0; i < P; ++i) v0[i] = zscale(v0[i], rn);
+        }
+    }
     // ---- q = L^-H v0, d0 = q^H Rxx q (q^H Rnn q = 1), t1 = q L[0][0] conj(v0[0]), w = t1 d0 / (d0 + mu)
     c64 q[P];
 #pragma unroll

@@ -152,6 +152,66 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restric
     }
 }
 
+// More than 4 channels: k_stft<N, CHP> keeps every channel pair's window AND spectrum of a frame in registers (N = 1024, CHP = 4:
+// 256 VGPRs + 214 AGPR copies, one wave per SIMD -- 7.5 ms on the C5 batch).  Here the waves of a workgroup split the pairs
+// instead: wave p streams channel pair p of the same (signal group, run of frames), so a frame's [F][chans] block is still
+// written by one workgroup within one transform's time (16 bytes per lane at a pitch of chans * 8; the lines fill up in L2).
+template <int N>
+__global__ __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* __restrict__ x, c32* __restrict__ X,
+                                                                    const float* __restrict__ win, const c32* __restrict__ tw,
+                                                                    int chans, int L, int T, int pad_mode, int runs_per_sig) {
+    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, NJ = E / 2 + 1, EH = E / 2;
+    __shared__ StftShared<N> sh;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
+    if (2 * wave >= chans) return;                 // no block-level synchronisation anywhere below
+    const long long g = blockIdx.x / runs_per_sig;
+    const int t0 = (int)(blockIdx.x % runs_per_sig) * STFT_RUN;
+    const int t1 = min(T, t0 + STFT_RUN);
+    const bool two = 2 * wave + 1 < chans;
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
+    float w[E];
+    load_window<N>(w, win, lane);
+    const float* xa = x + (g * chans + 2 * wave) * (long long)L;
+    const float* xb = two ? xa + L : xa;
+    c32 raw[E];
+    load_frame_slots<N, 0, E>(raw, xa, xb, t0, L, pad_mode, lane);
+    for (int t = t0; t < t1; ++t) {
+        c32 nxt[EH];
+        load_frame_slots<N, EH, E>(nxt, xa, xb, min(t + 1, T - 1), L, pad_mode, lane);
+        c32 A[NJ], B[NJ];
+        {
+            c32 v[E];
+            apply_window<N>(v, raw, w, two);
+            fft_wave<N>(v, wtw, sh.buf[wave], lane);
+            rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int j, int, c32 a, c32 b) {
+                A[j] = a;
+                B[j] = b;
+            });
+        }
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {                 // consume the prefetch before the stores (see k_stft)
+            DISCO_CONSUME(nxt[e].x);
+            DISCO_CONSUME(nxt[e].y);
+            raw[e] = raw[e + EH];
+            raw[e + EH] = nxt[e];
+        }
+        c32* Xo = X + ((g * T + t) * (long long)F) * chans + 2 * wave;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < NJ - 1 || lane == 0) {
+                c32* o = Xo + (long long)(lane + 64 * j) * chans;
+                if ((chans & 1) == 0) {
+                    *reinterpret_cast<float4*>(o) = make_float4(A[j].x, A[j].y, B[j].x, B[j].y);
+                } else {
+                    o[0] = A[j];
+                    if (two) o[1] = B[j];
+                }
+            }
+        }
+    }
+}
+
 // tf_mask (dnn/utils.py:57-67) on one bin.  v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE div/sqrt expansions:
 // ~12 instructions instead of ~60 per bin, error 2-3 ulp on a mask that is compared at 1e-5.
 __device__ __forceinline__ float ipow(float r, int p) {

@@ -30,7 +30,8 @@ def test_native_library_is_loaded(make_engine):
     assert 'libdisco_hip.so' in maps
 
 
-@pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 160000, 4), (1024, 2600, 1), (1024, 40000, 8)])
+@pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 160000, 4), (1024, 2600, 1), (1024, 40000, 8), (1024, 30000, 3),
+                                           (512, 20000, 5), (512, 45000, 8), (1024, 21000, 4), (1024, 30000, 7)])
 @pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
 def test_stft(make_engine, n_fft, L, chans, pad_mode):
     pc.check_stft(make_engine, n_sig=3, chans=chans, L=L, n_fft=n_fft, pad_mode=pad_mode)
@@ -47,7 +48,9 @@ def test_masks(make_engine):
 
 @pytest.mark.parametrize('R,K,M,same_z,mask_remote', [(2, 2, 2, True, True), (3, 3, 2, False, False), (5, 1, 4, True, True),
                                                      (4, 4, 4, True, True), (2, 2, 5, True, True), (1, 1, 8, True, True),
-                                                     (2, 5, 3, False, True), (2, 8, 8, True, True), (1, 3, 7, False, False), (2, 6, 5, True, True)])
+                                                     (2, 5, 3, False, True), (2, 8, 8, True, True), (1, 3, 7, False, False), (2, 6, 5, True, True),
+                                                     (2, 6, 4, True, True), (1, 13, 4, True, True), (2, 8, 2, True, True), (1, 15, 2, True, True),
+                                                     (1, 9, 8, True, True), (2, 2, 8, True, True)])
 def test_cov_solve_apply(make_engine, R, K, M, same_z, mask_remote):
     pc.check_cov_solve_apply(make_engine, R=R, K=K, M=M, L=16000, same_z=same_z, mask_remote=mask_remote)
 

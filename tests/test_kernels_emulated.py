@@ -20,7 +20,8 @@ def make_engine():
     return mk
 
 
-@pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 2048, 2), (1024, 2600, 1), (512, 9000, 4)])
+@pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 2048, 2), (1024, 2600, 1), (512, 9000, 4), (1024, 2600, 3), (1024, 9000, 8),
+                                           (512, 2000, 5), (512, 4500, 8), (1024, 2100, 4)])
 @pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
 def test_emu_stft(make_engine, n_fft, L, chans, pad_mode):
     print(pc.check_stft(make_engine, n_sig=2, chans=chans, L=L, n_fft=n_fft, pad_mode=pad_mode))

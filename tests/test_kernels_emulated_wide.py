@@ -25,6 +25,13 @@ def test_emu_cov_solve_apply_gpu_shapes(make_engine, R, K, M, same_z, mask_remot
     print(pc.check_cov_solve_apply(make_engine, R=R, K=K, M=M, L=3072, same_z=same_z, mask_remote=mask_remote))
 
 
+@pytest.mark.parametrize('K,M,n_fft', [(8, 8, 512), (6, 4, 512), (8, 2, 512), (3, 8, 1024)])
+def test_emu_cov_split_shapes(make_engine, K, M, n_fft):
+    """P > 8: the block-partitioned covariance with its frames staged through LDS (k_cov_split_lds), incl. an odd number of frames
+    per stage and the Nyquist tile's direct path."""
+    print(pc.check_cov_solve_apply(make_engine, R=1, K=K, M=M, L=(2 * (M + K) + 3) * (n_fft // 2), n_fft=n_fft))
+
+
 @pytest.mark.parametrize('R,K,M,L,n_fft', [(3, 4, 4, 24000, 512), (2, 2, 3, 30000, 512), (2, 1, 8, 20000, 512), (2, 2, 2, 25000, 1024)])
 def test_emu_stft_cov_fused_gpu_shapes(make_engine, R, K, M, L, n_fft):
     print(pc.check_stft_cov_fused(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft))
