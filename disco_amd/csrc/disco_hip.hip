@@ -493,23 +493,17 @@ static int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco
 
 template <int M, int KR>
 static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {
-    if constexpr (KR > 0 && M % 2 == 0) {
-        static const bool staged = [] { const char* e = getenv("DISCO_COV_LDS"); return !e || atoi(e) != 0; }();
-        if (staged && (a.F - 1) % 64 == 0) {               // frames staged through LDS once per workgroup (k_cov.h)
-            if (skiploc)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
-            return;
-        }
-    }
     if constexpr (KR > 0) {
-        if (skiploc) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
-            return;
-        }
+        // shapes with remote rows (all have an even M, and F - 1 is a multiple of 64 for both FFT sizes): frames staged through
+        // LDS once per workgroup (k_cov.h; 7.3 ms per C5 launch, the per-wave fetches of k_cov_split: 9.6 ms)
+        static_assert(M % 2 == 0, "k_cov_split_lds fetches X in 16-byte granules");
+        if (skiploc)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
 }
 
 static bool cov_split_shape(int M, int KR) {
@@ -535,7 +529,7 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     const int NP = P * (P + 1) / 2;
     const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
     const bool same = (Zs == Zn);
-    const bool split = (KR == 0 || (P > 8 && same && mask_remote)) && cov_split_shape(M, KR);
+    const bool split = (KR == 0 || (P > 8 && same && mask_remote && (ctx->F - 1) % 64 == 0)) && cov_split_shape(M, KR);
     skiploc = skiploc && split && KR > 0 && ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask;
     int rc = 0;
     if (skiploc) {
@@ -1138,7 +1132,7 @@ static int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_apply_istft<512, M_>), grid, block, 0, (hipStream_t)s, y, (const c32*)w, out, ctx->d_win, \
                            ctx->d_tw, c.length, ctx->T, c.pad_mode, runs, pairs, items);                                \
         break;
-        C_(1) C_(2)
+        C_(1) C_(2) C_(3) C_(4)
 #undef C_
         default: return DISCO_E_UNSUPPORTED;
     }
@@ -1468,7 +1462,7 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
         const long long grid = (a.n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;                              \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf_thread<P_>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, st, a); \
     } break;
-        C_(1) C_(2)
+        C_(1) C_(2) C_(3) C_(4)
 #undef C_
 #define C_(P_)                                                                                                          \
     case P_: {                          /* a group of 8 / 16 lanes per (room, node, bin) */                             \
@@ -1477,6 +1471,7 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
     } break;
         C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
 #undef C_
+        default: return fail(ctx, DISCO_E_UNSUPPORTED, "disco_online_mwf: no kernel for this P");
     }
     return check_launch(ctx, "k_online_mwf");
 }

@@ -152,41 +152,49 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restric
     }
 }
 
-// More than 4 channels: k_stft<N, CHP> keeps every channel pair's window AND spectrum of a frame in registers (N = 1024, CHP = 4:
-// 256 VGPRs + 214 AGPR copies, one wave per SIMD -- 7.5 ms on the C5 batch).  Here the waves of a workgroup split the pairs
-// instead: wave p streams channel pair p of the same (signal group, run of frames), so a frame's [F][chans] block is still
-// written by one workgroup within one transform's time (16 bytes per lane at a pitch of chans * 8; the lines fill up in L2).
+// More than 4 channels (and N = 1024 from 3 on): k_stft<N, CHP> keeps every channel pair's window AND spectrum of a frame in
+// registers (N = 1024, CHP = 4: 256 VGPRs + 214 AGPR copies, one wave per SIMD -- 7.5 ms on the C5 batch).  Here the waves of a
+// workgroup split the pairs instead: wave p transforms channel pair p of the same (signal group, run of frames) and parks its
+// two spectra in column p of an LDS tile laid out exactly like the frame's [F][chans] block of X; after a barrier the whole
+// workgroup copies the tile out linearly (1 KiB of consecutive bytes per wave store; storing each pair's 16 bytes per bin
+// straight from its wave, at a pitch of chans * 8, measured 40 % SLOWER than k_stft: four partial writes per 64-byte line).
+template <int N>
+struct alignas(16) StftPairsShared {
+    c32 buf[STFT_WAVES][fft_buf_len<N>()];
+    c32 tile[N / 2 + 1][2 * STFT_WAVES];
+};
+
 template <int N>
 __global__ __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* __restrict__ x, c32* __restrict__ X,
                                                                     const float* __restrict__ win, const c32* __restrict__ tw,
                                                                     int chans, int L, int T, int pad_mode, int runs_per_sig) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, NJ = E / 2 + 1, EH = E / 2;
-    __shared__ StftShared<N> sh;
-    const int wave = wave_id(), lane = threadIdx.x & 63;
-    if (2 * wave >= chans) return;                 // no block-level synchronisation anywhere below
+    __shared__ StftPairsShared<N> sh;
+    const int wave = wave_id(), lane = threadIdx.x & 63, tid = threadIdx.x;
+    const bool mine = 2 * wave < chans;            // waves without a pair still take part in the barriers and the copy
+    const bool two = 2 * wave + 1 < chans;
+    const int chp = (chans + 1) / 2;
     const long long g = blockIdx.x / runs_per_sig;
     const int t0 = (int)(blockIdx.x % runs_per_sig) * STFT_RUN;
     const int t1 = min(T, t0 + STFT_RUN);
-    const bool two = 2 * wave + 1 < chans;
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     float w[E];
     load_window<N>(w, win, lane);
-    const float* xa = x + (g * chans + 2 * wave) * (long long)L;
+    const float* xa = x + (g * chans + (mine ? 2 * wave : 0)) * (long long)L;
     const float* xb = two ? xa + L : xa;
     c32 raw[E];
     load_frame_slots<N, 0, E>(raw, xa, xb, t0, L, pad_mode, lane);
+    c32* tile = &sh.tile[0][0];                    // row pitch 2 * chp: the frame's X block when chans is even
     for (int t = t0; t < t1; ++t) {
         c32 nxt[EH];
         load_frame_slots<N, EH, E>(nxt, xa, xb, min(t + 1, T - 1), L, pad_mode, lane);
-        c32 A[NJ], B[NJ];
-        {
+        if (mine) {
             c32 v[E];
             apply_window<N>(v, raw, w, two);
             fft_wave<N>(v, wtw, sh.buf[wave], lane);
-            rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int j, int, c32 a, c32 b) {
-                A[j] = a;
-                B[j] = b;
+            rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
+                *reinterpret_cast<float4*>(&tile[(f * chp + wave) * 2]) = make_float4(a.x, a.y, b.x, b.y);
             });
         }
 #pragma unroll
@@ -196,19 +204,16 @@ __global__ __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* 
             raw[e] = raw[e + EH];
             raw[e + EH] = nxt[e];
         }
-        c32* Xo = X + ((g * T + t) * (long long)F) * chans + 2 * wave;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (j < NJ - 1 || lane == 0) {
-                c32* o = Xo + (long long)(lane + 64 * j) * chans;
-                if ((chans & 1) == 0) {
-                    *reinterpret_cast<float4*>(o) = make_float4(A[j].x, A[j].y, B[j].x, B[j].y);
-                } else {
-                    o[0] = A[j];
-                    if (two) o[1] = B[j];
-                }
-            }
+        __syncthreads();
+        c32* Xo = X + ((g * T + t) * (long long)F) * chans;
+        if ((chans & 1) == 0) {
+            const float4* src = reinterpret_cast<const float4*>(tile);
+            float4* dst = reinterpret_cast<float4*>(Xo);
+            for (int i = tid; i < F * chp; i += 64 * STFT_WAVES) dst[i] = src[i];
+        } else {
+            for (int i = tid; i < F * chans; i += 64 * STFT_WAVES) Xo[i] = tile[(i / chans) * 2 * chp + i % chans];
         }
+        __syncthreads();                               // the tile is rewritten by the next frame
     }
 }
 
