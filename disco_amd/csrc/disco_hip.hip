@@ -497,10 +497,11 @@ static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const 
         // shapes with remote rows (all have an even M, and F - 1 is a multiple of 64 for both FFT sizes): frames staged through
         // LDS once per workgroup (k_cov.h; 7.3 ms per C5 launch, the per-wave fetches of k_cov_split: 9.6 ms)
         static_assert(M % 2 == 0, "k_cov_split_lds fetches X in 16-byte granules");
+        const unsigned nb = DISCO_COV_XCD ? (nblk + DISCO_COV_XCD - 1) / DISCO_COV_XCD * DISCO_COV_XCD : nblk;      // see the kernel's id -> item map
         if (skiploc)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nb), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, false>), dim3(nb), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
     }

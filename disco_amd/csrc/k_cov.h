@@ -540,6 +540,9 @@ __global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_s
 #ifndef DISCO_COV_STAGE_FRAMES
 #define DISCO_COV_STAGE_FRAMES 2
 #endif
+#ifndef DISCO_COV_XCD
+#define DISCO_COV_XCD 8               // XCDs the workgroup ids are dealt over (0: plain tile-fastest ids)
+#endif
 #ifndef DISCO_COV_LDS_WPE
 #define DISCO_COV_LDS_WPE 3           // waves per SIMD the register allocation leaves room for
 #endif
@@ -668,11 +671,27 @@ __global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>()), DISCO_COV_LD
     constexpr int NW = cov_split_waves<KR, SKIPLOC>();
     __shared__ CovStage<M, KR, DISCO_COV_STAGE_FRAMES> sh[2];
     const int nbin = a.F - 1, tiles = nbin / 64;          // the launcher checks nbin % 64 == 0
+    // Which workgroup does what: the Kl nodes of a room read the same K - 1 remote rows of a (tile, chunk), so they are made
+    // NEIGHBOURS ON ONE XCD (one L2): the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, hence id b is
+    // logical item (b % 8) * (grid / 8) + b / 8, and logical items run node-fastest.  (Tile-fastest ids, as k_cov_split's,
+    // spread the 8 nodes of a room over 8 L2s and every remote row crosses the fabric up to K - 1 times.)
+#if DISCO_COV_XCD
+    const long long n_items = (long long)a.R * a.Kl * (tiles + 1) * a.chunks;
+    long long item = (long long)(blockIdx.x % DISCO_COV_XCD) * (gridDim.x / DISCO_COV_XCD) + blockIdx.x / DISCO_COV_XCD;
+    if (item >= n_items) return;                           // the grid is padded to a multiple of 8
+    const int kl = (int)(item % a.Kl);
+    item /= a.Kl;
+    const int c = (int)(item % a.chunks);
+    item /= a.chunks;
+    const int tile = (int)(item % (tiles + 1));
+    const long long g = (item / (tiles + 1)) * a.Kl + kl;
+#else
     int bid = blockIdx.x;
     const int c = bid % a.chunks;
     bid /= a.chunks;
     const int tile = bid % (tiles + 1);
     const long long g = bid / (tiles + 1);
+#endif
     const int lane = threadIdx.x & 63;
     const int wid = wave_id();
     if (tile == tiles) {                                   // the Nyquist bin: lanes are frames there, no barrier on that path

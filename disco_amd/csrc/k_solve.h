@@ -111,22 +111,26 @@ __device__ __forceinline__ void solve_load_row(const SolveSrc& src, long long pi
             rn[c] = src.Rnn[pid * P * P + j * P + c];
         }
     } else {
+        // the 64-bit part of every address once per lane (problem base in both sources, chunk stride), 32-bit triangle offsets per entry
         constexpr int NP = P * (P + 1) / 2;
         const long long g = pid / src.F;
         const int f = (int)(pid % src.F);
+        const int ML = src.M_loc, NPL = ML * (ML + 1) / 2;
+        const float4* pb = src.part + ((g * src.chunks) * src.F + f) * (long long)NP;
+        const float4* pl = ML > 0 ? src.part_loc + ((g * src.chunks_loc) * src.F + f) * (long long)NPL : pb;
+        const int cs = src.F * NP, csl = src.F * NPL;                // chunk strides (float4 units)
 #pragma unroll
         for (int c = 0; c < P; ++c) {
             const bool up = c >= j;
             const int lo_ = up ? j : c, hi_ = up ? c : j;            // upper-triangle coordinates (lo_, hi_)
-            const bool loc = hi_ < src.M_loc;
-            const int Pq = loc ? src.M_loc : P;
-            const int q = lo_ * Pq - (lo_ * (lo_ - 1)) / 2 + (hi_ - lo_);
-            const float4* base = loc ? src.part_loc : src.part;
+            const bool loc = hi_ < ML;
+            const int q = lo_ * (loc ? ML : P) - (lo_ * (lo_ - 1)) / 2 + (hi_ - lo_);
+            const float4* ptr = (loc ? pl : pb) + q;
+            const int stride = loc ? csl : cs;
             const int nch = loc ? src.chunks_loc : src.chunks;
-            const long long npq = loc ? (long long)(src.M_loc * (src.M_loc + 1) / 2) : (long long)NP;
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int ch = 0; ch < nch; ++ch) {
-                const float4 v = base[(((g * nch + ch) * src.F) + f) * npq + q];
+                const float4 v = ptr[(long long)ch * stride];
                 s.x += v.x;
                 s.y += v.y;
                 s.z += v.z;

@@ -20,7 +20,8 @@ extern "C" float cov_bench(int variant, const void* X, const void* mask, const v
     a.part = (float4*)part;
     a.K = K; a.T = T; a.F = F; a.chunks = chunks; a.mask_remote = 1; a.Kl = K; a.k0 = 0; a.zblk = K; a.R = R;
     const int tiles = (F - 1 + 63) / 64;
-    const unsigned nblk = (unsigned)((long long)R * K * (tiles + 1) * chunks);
+    unsigned nblk = (unsigned)((long long)R * K * (tiles + 1) * chunks);
+    const unsigned nblk_lds = DISCO_COV_XCD ? (nblk + 7) / 8 * 8 : nblk;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -28,7 +29,7 @@ extern "C" float cov_bench(int variant, const void* X, const void* mask, const v
         if (variant == 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<KB_M, KB_KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KB_KR, true>()), 0, 0, a);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<KB_M, KB_KR, true>), dim3(nblk), dim3(64 * cov_split_waves<KB_KR, true>()), 0, 0, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<KB_M, KB_KR, true>), dim3(nblk_lds), dim3(64 * cov_split_waves<KB_KR, true>()), 0, 0, a);
     };
     launch();
     hipDeviceSynchronize();
