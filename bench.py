@@ -362,18 +362,23 @@ def main(argv=None):
         reps = max(2, min(args.steps, 5))
         step()                                  # the event objects are created inside the library: warm that path once
         torch.cuda.synchronize()
-        eng.stage_timing(True)
+        # one report per step, and the MEDIAN over the steps: an event pair also spans whatever the host does between the two
+        # records, and a single descheduled launch call (seen once: 85 ms inside one 7 ms stage) would otherwise own the mean
+        per_rep = []
         for _ in range(reps):
+            eng.stage_timing(True)
             step()
-        rep = eng.stage_report()
+            per_rep.append(eng.stage_report())
         eng.stage_timing(False)
         kab = kernel_alg_bytes(M, K, F, H)
         stages = {}
-        for name, (ms_total, launches) in rep.items():
-            per_step = ms_total / reps
-            ent = {'ms': round(per_step, 4), 'launches_per_step': launches / reps}
+        for name in per_rep[0]:
+            ms_list = sorted(r_[name][0] for r_ in per_rep if name in r_)
+            per_step = ms_list[len(ms_list) // 2] if len(ms_list) % 2 else 0.5 * (ms_list[len(ms_list) // 2 - 1] + ms_list[len(ms_list) // 2])
+            launches = per_rep[0][name][1]
+            ent = {'ms': round(per_step, 4), 'launches_per_step': float(launches), 'ms_min': round(ms_list[0], 4), 'ms_max': round(ms_list[-1], 4)}
             if name in kab:
-                ent['alg_bytes'] = kab[name] * R * K * T * launches // reps     # per step (all launches of the stage)
+                ent['alg_bytes'] = kab[name] * R * K * T * launches     # per step (all launches of the stage)
                 ent['GBps'] = round(ent['alg_bytes'] / (per_step * 1e-3) / 1e9, 1)
             stages[name] = ent
         if args.online_every == 0:

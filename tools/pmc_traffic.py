@@ -18,7 +18,7 @@ import os
 # kernel-name prefix -> the library's stage name (disco_stage_report / bench.py `stages`); several kernels can serve one stage
 STAGE_OF = {'k_stft_cov<': 'stft_cov1', 'k_stft<': 'stft', 'k_mask_oracle<': 'mask_oracle', 'k_istft<': 'istft',
             'k_step2_cov_fused<': 'step2_cov', 'k_step2_apply_istft<': 'step2_apply_istft', 'k_step2_apply_fused<': 'step2_apply',
-            'k_stft_apply_istft<': 'stft_apply_istft', 'k_cov_split<': 'cov_split', 'k_cov_big<': 'cov_big', 'k_cov<': 'cov',
+            'k_stft_apply_istft<': 'stft_apply_istft', 'k_cov_split<': 'cov_split', 'k_cov_split_lds<': 'cov_split', 'k_stft_pairs<': 'stft', 'k_cov_big<': 'cov_big', 'k_cov<': 'cov',
             'k_apply_m<': 'apply_m', 'k_apply<': 'apply', 'k_gevd_mwf_r1_thread<': 'solve_thread', 'k_gevd_mwf_r1<': 'solve'}
 
 
@@ -44,7 +44,8 @@ for k, v in raw.items():
         out['_calibration']['torch_abs_1.28GB'] = {c: x['per_dispatch'] * 1024 for c, x in v.items()}
     if 'neg' in k.lower() and 'disco::' not in k and max(x['per_dispatch'] for x in v.values()) * 1024 > 1e9:
         # bench.py --pmc-calibrate: torch.neg over 2^30 floats = 4 GiB read + 4 GiB written by one kernel, known exactly
-        out['_calibration']['torch_neg_4GiB'] = dict({c: x['per_dispatch'] * 1024 for c, x in v.items()}, known_bytes_each_way=4 * 2 ** 30,
+        out['_calibration']['torch_neg_4GiB'] = dict({c: x['per_dispatch'] * 1024 for c, x in v.items()}, known_bytes_each_way_per_dispatch=2 * 2 ** 30,
+                                                      note='torch splits the 4 GiB tensor into two dispatches of 2 GiB (32-bit indexing): FETCH_SIZE x2 and WRITE_SIZE x1 reproduce 2 GiB each way',
                                                       kernel=k[:80])
     if 'disco::' not in k:
         continue
