@@ -2,8 +2,9 @@
 // problem.  Same algorithm and the same float64 arithmetic as k_solve.h (Cholesky whitening, dominant eigenpair by
 // repeated squaring, back substitution; internal_formulas.py:56-73) -- but at this size a group of 4 lanes spends more
 // instructions on hand-offs (LDS round trips, fences, shuffle reductions) than on arithmetic, so everything lives in the
-// registers of one thread: no LDS, no shuffles, 64 problems per wave instead of 16.  The Hermitian matrices are held as
-// (real diagonal, strict lower triangle); B^2 is formed on that half only, which also keeps B exactly Hermitian.
+// registers of one thread: no LDS or shuffles in the arithmetic (only the wave-cooperative fetch of the partial sums goes
+// through LDS), 64 problems per wave instead of 16.  The Hermitian matrices are held as (real diagonal, strict lower
+// triangle); B^2 is formed on that half only, which also keeps B exactly Hermitian.
 #pragma once
 #include "k_solve.h"
 
@@ -267,7 +268,62 @@ __global__ __launch_bounds__(SOLVE_SMALL_THREADS) void k_gevd_mwf_r1_thread(Solv
     const bool live = pid < n_prob;
     float a_d[P], b_d[P];
     c32 a_o[NO], b_o[NO];
-    if (live) {
+    bool loaded = false;
+    if constexpr (FROM_PART) {
+        // The partial sums of a wave's 64 pencils are 64 * NP consecutive float4 per chunk (pencils are (g, f)-major like the
+        // partial array): fetched lane-linearly, summed over the chunks, and handed over through LDS -- a thread loading its own
+        // NP entries reads 16 bytes of every 160, ten times over, and the lines do not survive in L1/L2 between the ten
+        // (PMC, C3: 2.07 GB fetched for 0.33 GB of partial sums).  Blocks that carry a step-1 block (M_loc) keep the direct path.
+        constexpr int NP = P * (P + 1) / 2;
+        __shared__ float4 s_tile[SOLVE_SMALL_THREADS / 64][64 * NP];
+        if (src.M_loc == 0) {                                             // block-uniform
+            const int lane = threadIdx.x & 63, wv = wave_id();
+            const long long pc = live ? pid : n_prob - 1;                 // dead lanes stand in for the last pencil
+            const long long off = ((pc / src.F) * src.chunks * src.F + pc % src.F) * (long long)NP;      // chunk 0 of this lane's pencil
+            const int off_lo = (int)(unsigned)(off & 0xffffffffLL), off_hi = (int)(off >> 32);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int e = lane + 64 * k, pe = e / NP, q = e % NP;     // element e of the wave's block belongs to lane pe's pencil
+                const long long o = ((long long)__shfl(off_hi, pe) << 32) | (unsigned)__shfl(off_lo, pe);
+                const float4* ptr = src.part + o + q;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int ch = 0; ch < src.chunks; ++ch) {
+                    const float4 v = ptr[(long long)ch * src.F * NP];
+                    sum.x += v.x;
+                    sum.y += v.y;
+                    sum.z += v.z;
+                    sum.w += v.w;
+                }
+                s_tile[wv][e] = sum;
+            }
+            DISCO_GROUP_SYNC();                                           // wave-local hand-over
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int k = 0; k <= i; ++k) {
+                    const float4 v = s_tile[wv][lane * NP + (k * P - (k * (k - 1)) / 2 + (i - k))];      // stored (k, i): R[i][k] = conj
+                    if (i == k) {
+                        a_d[i] = v.x * src.inv_T;
+                        b_d[i] = v.z * src.inv_T;
+                    } else {
+                        a_o[i * (i - 1) / 2 + k] = make_float2(v.x * src.inv_T, -v.y * src.inv_T);
+                        b_o[i * (i - 1) / 2 + k] = make_float2(v.z * src.inv_T, -v.w * src.inv_T);
+                    }
+                }
+            loaded = true;
+        }
+    }
+    if (loaded) {
+        if (!live) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                a_d[i] = 0.f;
+                b_d[i] = 1.f;
+            }
+#pragma unroll
+            for (int q = 0; q < NO; ++q) a_o[q] = b_o[q] = make_float2(0.f, 0.f);
+        }
+    } else if (live) {
         solve_load_tri<P, FROM_PART>(src, pid, a_d, a_o, b_d, b_o);
     } else {
 #pragma unroll

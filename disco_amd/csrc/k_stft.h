@@ -209,7 +209,9 @@ __global__ __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* 
         if ((chans & 1) == 0) {
             const float4* src = reinterpret_cast<const float4*>(tile);
             float4* dst = reinterpret_cast<float4*>(Xo);
-            for (int i = tid; i < F * chp; i += 64 * STFT_WAVES) dst[i] = src[i];
+            const int shift = (int)((reinterpret_cast<unsigned long long>(dst) >> 4) & 7);      // whole 128-byte lines per wave store (see k_stft_cov)
+            for (int i = tid - shift; i < F * chp; i += 64 * STFT_WAVES)
+                if (i >= 0) dst[i] = src[i];
         } else {
             for (int i = tid; i < F * chans; i += 64 * STFT_WAVES) Xo[i] = tile[(i / chans) * 2 * chp + i % chans];
         }
@@ -507,9 +509,14 @@ __global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WP
                 if (STORE && (M & 1) == 0) {
                     // even M: the tile row IS the X row (F*M complex, contiguous) -> straight 16-B-per-lane copy, every
                     // wave store covers 1 KiB of consecutive bytes (a per-bin store would touch each 128-B line twice)
+                    // The rows are 8 * M * F bytes long (8224 for M = 4), so they start 0 / 32 / 64 / 96 bytes into a 128-byte line: the
+                    // copy is shifted by that much, every wave store then covers whole lines (PMC: stores that straddle lines
+                    // at both ends cost a fill read per partial line, +2.8 GB of reads per C3 launch).
                     const float4* src = reinterpret_cast<const float4*>(&sh.tile[ww][0][0]);
                     float4* dst = reinterpret_cast<float4*>(Xo);
-                    for (int i = tid; i < F * M / 2; i += 64 * STFT_WAVES) dst[i] = src[i];
+                    const int shift = (int)((reinterpret_cast<unsigned long long>(dst) >> 4) & 7);
+                    for (int i = tid - shift; i < F * M / 2; i += 64 * STFT_WAVES)
+                        if (i >= 0) dst[i] = src[i];
                 }
 #pragma unroll
                 for (int b = 0; b < BPT; ++b) {
