@@ -65,6 +65,7 @@ def kernel_alg_bytes(M, K, F, H):
         'step2_apply': M * F * 8 + F * 8,                     # X in, yf out
         'step2_apply_istft': M * F * 8 + H * 4,               # X in, hop samples out (yf stays on chip)
         'stft_apply_istft': M * H * 4 + H * 4,                # samples in, hop samples out (single node, nothing materialised)
+        'step2_stft_apply_istft': M * H * 4 + H * 4,          # samples in, hop samples out (spectra re-transformed, z / yf on chip)
         'istft': F * 8 + H * 4,                               # yf in, hop samples out
     }
 

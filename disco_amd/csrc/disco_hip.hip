@@ -23,6 +23,15 @@
 
 using namespace disco;
 
+// Step 2 of the whole-path entry point (512-point STFT, <= 4 mics, <= 4 nodes): 1 = the filter + iSTFT pass re-transforms the
+// samples (k_step2_stft_apply_istft) instead of reading the stored spectra back; the environment variable
+// DISCO_STEP2_FROM_SAMPLES overrides it per context (A/B runs, tests of both paths).  Measured on C3: 5.9 ms from the
+// samples against 4.5-4.8 ms from the spectra (two more forward transforms per node-frame cost more LDS-write time than
+// the 10 GB of HBM reads they save) -> default 0.
+#ifndef DISCO_STEP2_FROM_SAMPLES_DEFAULT
+#define DISCO_STEP2_FROM_SAMPLES_DEFAULT 0
+#endif
+
 struct disco_ctx {
     disco_cfg cfg;
     int T, F;
@@ -44,6 +53,7 @@ struct disco_ctx {
     int k0, Kl;                      // node shard: this context holds nodes [k0, k0 + Kl) of every room (default 0, K)
     int zblk;                        // layout of the exchanged-signal arguments Zs / Zn / Z (disco_set_z_blocks; default K = plain)
     int tune_runw, tune_cov_chunks, tune_step2_chunks, tune_pairs;   // disco_set_tuning overrides (0 = batch-size heuristic)
+    int from_samples;                // whole-path step-2 kernels re-transform the samples instead of reading X back (env DISCO_STEP2_FROM_SAMPLES)
     // per-stage hipEvent timers of the whole-path entry points (disco_stage_timing / disco_stage_report)
     struct StageRec {
         char name[32];
@@ -197,6 +207,10 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->Kl = cfg->nodes;
     ctx->zblk = cfg->nodes;
     ctx->tune_runw = ctx->tune_cov_chunks = ctx->tune_step2_chunks = ctx->tune_pairs = 0;
+    {
+        const char* e = getenv("DISCO_STEP2_FROM_SAMPLES");
+        ctx->from_samples = e ? atoi(e) : DISCO_STEP2_FROM_SAMPLES_DEFAULT;
+    }
     ctx->stage_on = false;
     ctx->scratch2 = nullptr;
     ctx->scratch2_bytes = 0;
@@ -1053,6 +1067,37 @@ extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X,
     return check_launch(ctx, "k_step2_apply_istft");
 }
 
+// the same pass from the samples (k_step2_stft_apply_istft): 512-point STFT, M <= 4, 2 <= K <= 4
+static bool from_samples_shape(const disco_cfg& c) { return c.n_fft == 512 && c.mics <= 4 && c.nodes >= 2 && c.nodes <= 4; }
+
+static int step2_stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w_loc, const disco_c32* w_glo, float* out,
+                                  disco_stream s) {
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes;
+    if (!from_samples_shape(c)) return DISCO_E_UNSUPPORTED;
+    const int n_seg = (c.length + c.hop - 1) / c.hop;
+    const long long units = (long long)c.rooms * K;
+    const long long bpr_wanted = std::max<long long>(1, (8192 + units - 1) / units);
+    int pairs = (int)(((n_seg + bpr_wanted - 1) / bpr_wanted + 2) / 2);
+    pairs = std::min(64, std::max(4, pairs));
+    if (ctx->tune_pairs > 0) pairs = ctx->tune_pairs;
+    const int bpr = (n_seg + 2 * pairs - 2) / (2 * pairs - 1);
+    const long long nblk = (long long)c.rooms * bpr;
+    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: batch too large for one launch");
+    bool launched = false;
+#define X_(M_, K_)                                                                                                        \
+    if (!launched && M == M_ && K == K_) {                                                                                \
+        launched = true;                                                                                                  \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_stft_apply_istft<512, M_, K_>), dim3((unsigned)nblk), dim3(64 * K_), 0,   \
+                           (hipStream_t)s, y, (const c32*)w_loc, (const c32*)w_glo, out, ctx->d_win, ctx->d_tw, c.length, ctx->T, \
+                           c.pad_mode, bpr, pairs);                                                                       \
+    }
+    X_(1, 2) X_(1, 3) X_(1, 4) X_(2, 2) X_(2, 3) X_(2, 4) X_(3, 2) X_(3, 3) X_(3, 4) X_(4, 2) X_(4, 3) X_(4, 4)
+#undef X_
+    if (!launched) return DISCO_E_UNSUPPORTED;
+    return check_launch(ctx, "k_step2_stft_apply_istft");
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // whole path
 // ---------------------------------------------------------------------------------------------------------
@@ -1213,6 +1258,10 @@ static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask
     if (rc) return rc;
     if ((rc = STAGE(ctx, s, "solve2", solve_from_partials(ctx, chunks, P2, w_glo, s)))) return rc;
     if (!yf && c.n_fft == 512) {           // yf not asked for: filter + iSTFT in one pass, yf stays on chip
+        if (ctx->from_samples && from_samples_shape(c)) {       // ... and the spectra are re-transformed, not read back
+            rc = STAGE(ctx, s, "step2_stft_apply_istft", step2_stft_apply_istft(ctx, y, w_loc, w_glo, out, s));
+            if (rc != DISCO_E_UNSUPPORTED) return rc;
+        }
         rc = STAGE(ctx, s, "step2_apply_istft", disco_step2_apply_istft_fused(ctx, X, w_loc, w_glo, out, s));
         if (rc != DISCO_E_UNSUPPORTED) return rc;
     }
@@ -1407,6 +1456,17 @@ extern "C" int disco_maxpool_last4(disco_ctx* ctx, const float* x, const float* 
     const long long total = (long long)n_rows * (row_len / 4);
     hipLaunchKernelGGL(k_maxpool_last4, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)s, x, bias, out,
                        (long long)n_rows, row_len, rows_per_channel > 0 ? rows_per_channel : 1, channels > 0 ? channels : 1);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
+}
+
+extern "C" int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco_c32* b, const disco_c32* c, int64_t n,
+                                 disco_c32* out_hw, disco_c32* out_ref, disco_stream s) {
+    static_assert(PK_SELFTEST_OPS == DISCO_PK_SELFTEST_OPS, "header and kernel disagree");
+    if (!a || !b || !c || !out_hw || !out_ref || n < 1) return ctx ? fail(ctx, DISCO_E_ARG, "disco_selftest_pk: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    hipLaunchKernelGGL(k_pk_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, (const c32*)a, (const c32*)b, (const c32*)c,
+                       (long long)n, (c32*)out_hw, (c32*)out_ref);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
 }

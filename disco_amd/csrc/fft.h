@@ -9,6 +9,7 @@
 // X[l + 64 e] in slot e (natural order), so global loads/stores of consecutive lanes are contiguous.
 #pragma once
 #include "common.h"
+#include "pk.h"
 
 namespace disco {
 
@@ -43,32 +44,33 @@ template <int N>
 constexpr int fft_buf_len() { return N + (N >> FftPlan<N>::PADSH); }
 
 // ---- small DFTs, forward sign exp(-2 pi i / R), natural-order output, in place ------------------------
+// Written on the packed primitives of pk.h: every +-i rotation rides the add's operand selectors, the 1/sqrt2 rotations of
+// the radix-8 step are one packed add (1 -+ i) + one packed fma against the partner each.  dft4: 8 instructions,
+// dft8: 26, no moves, no sign flips.
 __device__ __forceinline__ void dft4(c32& u0, c32& u1, c32& u2, c32& u3) {
-    c32 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = cmul_mi(csub(u1, u3));
+    const c32 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), d = csub(u1, u3);
     u0 = cadd(a0, a2);
     u2 = csub(a0, a2);
-    u1 = cadd(a1, a3);
-    u3 = csub(a1, a3);
+    u1 = cadd_mi(a1, d);        // a1 + (-i) d
+    u3 = cadd_pi(a1, d);        // a1 - (-i) d
 }
 
 __device__ __forceinline__ void dft8(c32* u) {
-    const float h = 0.70710678118654752440f;
+    const c32 hh = make_float2(0.70710678118654752440f, 0.70710678118654752440f);
     c32 e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6];
     c32 o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
     dft4(e0, e1, e2, e3);
     dft4(o0, o1, o2, o3);
-    // W8^k * O[k]
-    c32 t1 = make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));     // (1 - i)/sqrt2
-    c32 t2 = cmul_mi(o2);                                           // -i
-    c32 t3 = make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));    // (-1 - i)/sqrt2
+    // W8^k O[k]:  W8 = (1 - i)/sqrt2,  W8^2 = -i,  W8^3 = -(1 + i)/sqrt2
+    const c32 s1 = cmul_1mi(o1), s3 = cmul_1pi(o3);
     u[0] = cadd(e0, o0);
     u[4] = csub(e0, o0);
-    u[1] = cadd(e1, t1);
-    u[5] = csub(e1, t1);
-    u[2] = cadd(e2, t2);
-    u[6] = csub(e2, t2);
-    u[3] = cadd(e3, t3);
-    u[7] = csub(e3, t3);
+    u[1] = cfma_scale(s1, hh, e1);
+    u[5] = cfms_scale(s1, hh, e1);
+    u[2] = cadd_mi(e2, o2);
+    u[6] = cadd_pi(e2, o2);
+    u[3] = cfms_scale(s3, hh, e3);
+    u[7] = cfma_scale(s3, hh, e3);
 }
 
 __device__ __forceinline__ void dft16(c32* u) {
@@ -80,16 +82,28 @@ __device__ __forceinline__ void dft16(c32* u) {
     }
     dft8(e);
     dft8(o);
-    // W16^k = exp(-2 pi i k / 16), k = 0..7
+    // W16^k = exp(-2 pi i k / 16): k = 0, 4 are free, k = 2, 6 the 1/sqrt2 rotations, the odd k full products with constants
     const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
-    const c32 w[8] = {make_float2(1.f, 0.f),  make_float2(c1, -s1), make_float2(h, -h),  make_float2(s1, -c1),
-                      make_float2(0.f, -1.f), make_float2(-s1, -c1), make_float2(-h, -h), make_float2(-c1, -s1)};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        c32 t = cmul(o[k], w[k]);
-        u[k] = cadd(e[k], t);
-        u[k + 8] = csub(e[k], t);
-    }
+    const c32 hh = make_float2(h, h);
+    u[0] = cadd(e[0], o[0]);
+    u[8] = csub(e[0], o[0]);
+    u[4] = cadd_mi(e[4], o[4]);
+    u[12] = cadd_pi(e[4], o[4]);
+    const c32 r2 = cmul_1mi(o[2]), r6 = cmul_1pi(o[6]);
+    u[2] = cfma_scale(r2, hh, e[2]);
+    u[10] = cfms_scale(r2, hh, e[2]);
+    u[6] = cfms_scale(r6, hh, e[6]);
+    u[14] = cfma_scale(r6, hh, e[6]);
+    const c32 t1 = cmul_pk_sb(o[1], make_float2(c1, -s1)), t3 = cmul_pk_sb(o[3], make_float2(s1, -c1));
+    const c32 t5 = cmul_pk_sb(o[5], make_float2(-s1, -c1)), t7 = cmul_pk_sb(o[7], make_float2(-c1, -s1));
+    u[1] = cadd(e[1], t1);
+    u[9] = csub(e[1], t1);
+    u[3] = cadd(e[3], t3);
+    u[11] = csub(e[3], t3);
+    u[5] = cadd(e[5], t5);
+    u[13] = csub(e[5], t5);
+    u[7] = cadd(e[7], t7);
+    u[15] = csub(e[7], t7);
 }
 
 template <int R>
@@ -97,6 +111,69 @@ __device__ __forceinline__ void dftR(c32* u) {
     if constexpr (R == 4) dft4(u[0], u[1], u[2], u[3]);
     else if constexpr (R == 8) dft8(u);
     else dft16(u);
+}
+
+// ---- 512 points with ONE trip through LDS ------------------------------------------------------------------------------
+// Measured on the MI355X (tools/gpu/kbench/fft_rate.hip): the two LDS exchanges of the Stockham schedule below cost 275 ns per
+// transform and SIMD, the butterflies 250 ns -- the wave transforms are LDS-BANDWIDTH-bound (118 of the CU's 128 B/clk).
+// fft_wave_xlane runs the same three radix-8 passes as a decimation in frequency on n = 64 n2 + 8 n1 + n0 (slot = n2,
+// lane = 8 n1 + n0), k = k0 + 8 k1 + 64 k2:
+//   pass 1 over the slots (n2 -> k0), twiddle W_512^(k0 lane);
+//   8 x 8 transpose between the slot index and lane bits 5:3 WITHOUT LDS: v_permlane32_swap / v_permlane16_swap (the 2 x 2 block
+//   transposes of gfx950) for lane bits 5 and 4, a DPP row rotate by 8 with bank masks for lane bit 3  (slot = n1, lane = 8 k0 + n0);
+//   pass 2 over the slots (n1 -> k1), twiddle W_64^(k1 n0);
+//   one LDS exchange that also undoes the digit order (lane = k0 + 8 k1, slot = n0);
+//   pass 3 over the slots (n0 -> k2): lane holds X[lane + 64 slot], the natural order of fft_wave.
+// MEASURED SLOWER and therefore off: 408 ns per transform and SIMD at 4 waves/SIMD against 363 ns for the Stockham schedule
+// (442 vs 390 at 3 waves): the 16 permlane swaps + 16 DPP moves cost more VALU time than the LDS exchange they replace
+// frees.  Kept (checked against the oracle on the emulated build, and on the MI355X by fft_rate's check) as the record of it.
+#ifndef DISCO_FFT_XLANE
+#define DISCO_FFT_XLANE 0
+#endif
+template <int N>
+constexpr bool fft_xlane_plan() { return DISCO_FFT_XLANE && N == 512; }
+
+// 2 x 2 transpose between two registers and lane bit BIT (8, 16 or 32): lanes with the bit set receive the partner's b in a,
+// lanes with it clear receive the partner's a in b (partner = lane ^ BIT).
+template <int BIT>
+__device__ __forceinline__ void xlane_swap(float& a, float& b, int lane) {
+#if defined(__clang__)
+    (void)lane;
+    if constexpr (BIT == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]);
+        b = __uint_as_float(r[1]);
+    } else if constexpr (BIT == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]);
+        b = __uint_as_float(r[1]);
+    } else {
+        static_assert(BIT == 8, "lane bit");
+        const int ai = __float_as_int(a), bi = __float_as_int(b);
+        // row_ror:8 (0x128): lane i of a 16-lane row reads lane i - 8 (mod 16); bank_mask picks lanes 8..15 (0xc) / 0..7 (0x3)
+        a = __int_as_float(__builtin_amdgcn_update_dpp(ai, bi, 0x128, 0xf, 0xc, false));
+        b = __int_as_float(__builtin_amdgcn_update_dpp(bi, ai, 0x128, 0xf, 0x3, false));
+    }
+#else
+    const float pa = __shfl_xor(a, BIT), pb = __shfl_xor(b, BIT);
+    if (lane & BIT) a = pb;
+    else b = pa;
+#endif
+}
+template <int BIT>
+__device__ __forceinline__ void xlane_swap(c32& a, c32& b, int lane) {
+    xlane_swap<BIT>(a.x, b.x, lane);
+    xlane_swap<BIT>(a.y, b.y, lane);
+}
+// slot index <-> lane bits 5:3
+__device__ __forceinline__ void xlane_transpose8(c32* v, int lane) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xlane_swap<32>(v[s], v[s + 4], lane);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if ((s & 2) == 0) xlane_swap<16>(v[s], v[s + 2], lane);
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) xlane_swap<8>(v[s], v[s + 1], lane);
 }
 
 // Per-lane twiddle factors of passes 2 and 3, gathered once per kernel from the N-entry table
@@ -110,6 +187,14 @@ struct WaveTw {
     c32 t1[Q1 * (Pl::R1 - 1)];
     c32 t2[Q2 * (Pl::R2 - 1)];
     __device__ __forceinline__ void init(const c32* __restrict__ tw, int lane) {
+        if constexpr (fft_xlane_plan<N>()) {      // decimation in frequency, see fft_wave_xlane
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                t1[r - 1] = tw[r * lane];                   // W_512^(k0 (8 n1 + n0))
+                t2[r - 1] = tw[8 * r * (lane & 7)];         // W_64^(k1 n0)
+            }
+            return;
+        }
         constexpr int P1 = Pl::R0, P2 = Pl::R0 * Pl::R1;
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
@@ -146,7 +231,7 @@ __device__ __forceinline__ void fft_pass(c32* v, const c32* tw, c32* buf, int la
         const int k = i & (P_ - 1);
         if constexpr (P_ > 1) {                    // tw = this pass' register twiddles W_{P_ R}^{k r}, r = 1..R-1
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[q * (R - 1) + r - 1]);
+            for (int r = 1; r < R; ++r) v[q * R + r] = cmul_pk(v[q * R + r], tw[q * (R - 1) + r - 1]);
         }
         dftR<R>(v + q * R);
         if constexpr (!LAST) {
@@ -170,8 +255,33 @@ __device__ __forceinline__ void fft_pass(c32* v, const c32* tw, c32* buf, int la
 // Forward complex FFT of the wave's N points.  In: v[e] = x[lane + 64 e].  Out: v[e] = X[lane + 64 e].
 // `buf` = wave-private LDS of fft_buf_len<N>() c32.
 template <int N>
+__device__ __forceinline__ void fft_wave_xlane(c32* v, const WaveTw<N>& tw, c32* buf, int lane) {
+    static_assert(N == 512, "cross-lane plan: 512 points");
+    dft8(v);                                                     // n2 -> k0
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul_pk(v[r], tw.t1[r - 1]);
+    xlane_transpose8(v, lane);                                   // slot = n1, lane = 8 k0 + n0
+    dft8(v);                                                     // n1 -> k1
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul_pk(v[r], tw.t2[r - 1]);
+    DISCO_LDS_WAR();        // the previous user of `buf` is done in every lane
+    const int w0 = (lane >> 3) + 64 * (lane & 7);                // element (k0, n0; k1 = r) -> position k0 + 8 k1 + 64 n0
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[fft_pad<N>(w0 + 8 * r)] = v[r];
+    DISCO_LDS_RAW();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = buf[fft_pad<N>(lane + 64 * e)];
+    DISCO_LDS_WAR();
+    dft8(v);                                                     // n0 -> k2: v[e] = X[lane + 64 e]
+}
+
+template <int N>
 __device__ __forceinline__ void fft_wave(c32* v, const WaveTw<N>& tw, c32* buf, int lane) {
     using Pl = FftPlan<N>;
+    if constexpr (fft_xlane_plan<N>()) {
+        fft_wave_xlane<N>(v, tw, buf, lane);
+        return;
+    }
     DISCO_LDS_WAR();        // the previous user of `buf` (an earlier item's untangle reads) is done in every lane
     fft_pass<N, Pl::R0, 1, true, false>(v, nullptr, buf, lane);
     fft_pass<N, Pl::R1, Pl::R0, false, false>(v, tw.t1, buf, lane);
@@ -181,23 +291,57 @@ __device__ __forceinline__ void fft_wave(c32* v, const WaveTw<N>& tw, c32* buf, 
 // Spectra of two real sequences a, b from Z = FFT(a + i b):  A[f] = (Z[f] + conj Z[N-f]) / 2,
 // B[f] = (Z[f] - conj Z[N-f]) / (2i).  Lane receives f = lane + 64 j (j < E/2) through emit(j, f, A, B);
 // lane 0 additionally receives the Nyquist bin f = N/2.
+// The division by two is NOT done here: the callers transform (a + i b) / 2 -- the factor rides the analysis window
+// (load_window_half) or a later weight, exactly (a power of two) -- so A = Z + conj Z', B = -i (Z - conj Z') are one packed
+// add each (8 instructions per bin before).
+// The partner Z[N - f] of f = lane + 64 j sits in slot E-1-j of lane 64 - lane: it is fetched with one cross-lane read per
+// dword (ds_bpermute_b32: the LDS crossbar, no LDS memory, a quarter of the bytes of the write-all / read-pairs round trip
+// through the exchange buffer that was here -- the wave transforms are LDS-bandwidth-bound, tools/gpu/kbench/fft_rate.hip).
+// Lane 0 is its own partner (f = 64 j pairs with N - 64 j = slot E - j, f = 0 with itself).  Every lane of the wave must call.
 template <int N, class Emit>
 __device__ __forceinline__ void rfft_pair_untangle(c32* v, c32* buf, int lane, Emit emit) {
-    constexpr int E = FftPlan<N>::E;
-    DISCO_LDS_WAR();
+    (void)buf;
+    constexpr int E = FftPlan<N>::E, EH = E / 2;
+    const int src = (64 - lane) & 63;
+    c32 zc[EH];
 #pragma unroll
-    for (int e = 0; e < E; ++e) buf[fft_pad<N>(lane + 64 * e)] = v[e];
-    DISCO_LDS_RAW();
+    for (int j = 0; j < EH; ++j) {
+        const c32 snd = v[E - 1 - j];
+        zc[j] = make_float2(__shfl(snd.x, src), __shfl(snd.y, src));
+    }
+    if (lane == 0) {
+        zc[0] = v[0];
 #pragma unroll
-    for (int j = 0; j <= E / 2; ++j) {
-        const int f = lane + 64 * j;
-        if (j < E / 2 || lane == 0) {
-            const c32 z = buf[fft_pad<N>(f)];
-            const c32 zc = buf[fft_pad<N>((N - f) & (N - 1))];
-            const c32 A = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
-            const c32 B = make_float2(0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x));
-            emit(j, f, A, B);
-        }
+        for (int j = 1; j < EH; ++j) zc[j] = v[E - j];
+    }
+#pragma unroll
+    for (int j = 0; j < EH; ++j) emit(j, lane + 64 * j, cadd_conj(v[j], zc[j]), csub_conj_mi(v[j], zc[j]));
+    if (lane == 0) emit(EH, N / 2, cadd_conj(v[EH], v[EH]), csub_conj_mi(v[EH], v[EH]));
+}
+
+// The reverse packing for the inverse transform of two real frames at once: A[j], B[j] = the two spectra at f = lane + 64 j
+// (j < E/2; j = E/2: the Nyquist bin, valid in lane 0) -> v[e] = conj(V[lane + 64 e]) with V = A~ + i B~ the sum of the
+// Hermitian extensions; FFT(v) then carries frame A in its real and -frame B in its imaginary part (inverse by forward
+// transform of the conjugate, scale 1/N left to the caller).  irfft ignores the imaginary parts of DC and Nyquist.
+// Upper half n = N - f: conj(V[n]) = conj(conj(A[f]) + i conj(B[f])) = A[f] - i B[f], computed where f lives and fetched from
+// lane 64 - lane like the untangle's partner.  Every lane of the wave must call.
+template <int N>
+__device__ __forceinline__ void irfft_pair_pack(const c32* A, const c32* B, c32* v, int lane) {
+    constexpr int E = FftPlan<N>::E, EH = E / 2;
+    const int src = (64 - lane) & 63;
+    c32 W[EH];
+#pragma unroll
+    for (int j = 0; j < EH; ++j) {
+        v[j] = cadd_pi_conj(A[j], B[j]);         // conj(A + i B)
+        W[j] = cadd_mi(A[j], B[j]);              // A - i B
+    }
+#pragma unroll
+    for (int e = EH; e < E; ++e) v[e] = make_float2(__shfl(W[E - 1 - e].x, src), __shfl(W[E - 1 - e].y, src));
+    if (lane == 0) {
+        v[0] = make_float2(A[0].x - 0.f, -B[0].x);                  // DC: imaginary parts dropped -> conj(A.x + i B.x)
+        v[EH] = make_float2(A[EH].x, -B[EH].x);                     // Nyquist likewise
+#pragma unroll
+        for (int e = EH + 1; e < E; ++e) v[e] = W[E - e];
     }
 }
 

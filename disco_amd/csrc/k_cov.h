@@ -7,6 +7,7 @@
 // shuffle reduction.  Chunk partials are summed, scaled by 1/T and mirrored by k_cov_finalize.
 #pragma once
 #include "common.h"
+#include "pk.h"
 
 namespace disco {
 
@@ -20,18 +21,22 @@ __device__ __forceinline__ constexpr int tri_index(int i, int j) { return i * P 
 // step 1 already accumulated with the same mask).
 template <int P, int JMIN = 0>
 __device__ __forceinline__ void cov_accumulate_shared(const c32* u, float a, float b, c32* acc_s, c32* acc_n) {
+    // off the diagonal: p = u_i conj(u_j) in two packed instructions (pk.h), then one packed fma per statistic with the weight
+    // broadcast from the pair (a, b) by the operand selectors: 4 instructions per entry instead of 8
+    const c32 ab = make_float2(a, b);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
 #pragma unroll
         for (int j = (i > JMIN ? i : JMIN); j < P; ++j) {
             const int q = tri_index<P>(i, j);
-            const float pr = fmaf(u[i].x, u[j].x, u[i].y * u[j].y);
-            acc_s[q].x = fmaf(a, pr, acc_s[q].x);
-            acc_n[q].x = fmaf(b, pr, acc_n[q].x);
             if (j != i) {
-                const float pi = fmaf(u[i].y, u[j].x, -(u[i].x * u[j].y));
-                acc_s[q].y = fmaf(a, pi, acc_s[q].y);
-                acc_n[q].y = fmaf(b, pi, acc_n[q].y);
+                const c32 p = cmul_aconjb(u[i], u[j]);
+                acc_s[q] = fma_by_half<0>(p, ab, acc_s[q]);
+                acc_n[q] = fma_by_half<1>(p, ab, acc_n[q]);
+            } else {
+                const float pr = fmaf(u[i].x, u[i].x, u[i].y * u[i].y);
+                acc_s[q].x = fmaf(a, pr, acc_s[q].x);
+                acc_n[q].x = fmaf(b, pr, acc_n[q].x);
             }
         }
     }
@@ -338,7 +343,15 @@ __device__ __forceinline__ void cov_split_fetch(c32* u, const c32* __restrict__ 
 #ifndef DISCO_COV_PK
 #define DISCO_COV_PK 0
 #endif
-#if DISCO_COV_PK && DISCO_PK && defined(__clang__)
+#if DISCO_COV_PK == 2
+// on the instruction forms of pk.h: u_i conj(u_j) in two packed instructions, one packed fma per statistic (weights broadcast
+// from the pair (wa, wb) by the operand selectors) -- as cov_accumulate_shared
+__device__ __forceinline__ void cov_pair_acc(const c32 a, const c32 b, const float wa, const float wb, c32& as, c32& an) {
+    const c32 p = cmul_aconjb(a, b), w2 = make_float2(wa, wb);
+    as = fma_by_half<0>(p, w2, as);
+    an = fma_by_half<1>(p, w2, an);
+}
+#elif DISCO_COV_PK && DISCO_PK && defined(__clang__)
 // packed form: (pr, pi) = a conj(b) as v_pk_mul + v_pk_fma, then one v_pk_fma per part on the pair (Rss, Rnn) of sums -- 4
 // instructions per pair of components instead of 8; the sums live as (acc_s.x, acc_n.x), (acc_s.y, acc_n.y)
 __device__ __forceinline__ void cov_pair_acc(const c32 a, const c32 b, const float wa, const float wb, c32& as, c32& an) {

@@ -52,13 +52,10 @@ __device__ __forceinline__ Step2Geom step2_geom(const Step2Args& a, int lane) {
 
 template <int M>
 __device__ __forceinline__ c32 filt_conj(const c32* w, const c32* x) {      // sum_i conj(w_i) x_i
-    float zr = 0.f, zi = 0.f;
+    c32 z = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-        zr = fmaf(w[i].x, x[i].x, fmaf(w[i].y, x[i].y, zr));
-        zi = fmaf(w[i].x, x[i].y, fmaf(-w[i].y, x[i].x, zi));
-    }
-    return make_float2(zr, zi);
+    for (int i = 0; i < M; ++i) z = cfma_conj(w[i], x[i], z);       // two packed fmas per term (pk.h)
+    return z;
 }
 
 #ifndef DISCO_S2_U_COV
@@ -238,6 +235,72 @@ namespace disco {
 
 // frame pairs per workgroup are a launch parameter (`pairs`): 2*pairs - 1 hop segments per workgroup
 
+// ---- synthesis window + overlap-add of one inverse transform (two frames A = tA, B = tA + 1 ride it: time frame A is
+// Re v, frame B is -Im v; v = FFT(conj V), n = lane + 64 e) ------------------------------------------------------------
+// out[seg H + n] = (frame seg's upper half + frame seg+1's lower half) / (w[n+H]^2 + w[n]^2), each half weighted by the
+// window and 1/N.  All three factors depend on the lane only, so they are folded into two weights per sample position once
+// per kernel (cA: lower-half contributions, cB: upper-half): an output sample is one multiply and one fma -- the
+// per-sample window products, the sum of squares and an IEEE division (~14 instructions) were spent here before.  The last
+// segment of a signal has no successor frame and is normalised by w[n+H]^2 alone: corrected on that segment only.
+template <int N>
+struct OlaWeights {
+    static constexpr int EH = FftPlan<N>::E / 2;
+    float cA[EH], cB[EH];
+    __device__ __forceinline__ void init(const float* __restrict__ win, int lane) {
+        const float inv = 1.0f / N;
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {
+            const float wl = win[lane + 64 * e], wh = win[lane + 64 * (e + EH)];
+            const float s = wh * wh + wl * wl;
+            const float rn = s > 1.17549435e-38f ? 1.0f / s : 1.0f;
+            cA[e] = wl * inv * rn;
+            cB[e] = wh * inv * rn;
+        }
+    }
+};
+template <int N>
+__device__ __forceinline__ float ola_last_segment_factor(const float* __restrict__ win, int lane, int e) {
+    constexpr int EH = FftPlan<N>::E / 2;
+    const float wl = win[lane + 64 * e], wh = win[lane + 64 * (e + EH)];
+    const float a = wh * wh, s = a + wl * wl;
+    const float rn = s > 1.17549435e-38f ? 1.0f / s : 1.0f;
+    const float rl = a > 1.17549435e-38f ? 1.0f / a : 1.0f;
+    return rl / rn;
+}
+// emits hop segments tA - 1 (carry + lower half of A; skipped for a run's first pair, it belongs to the predecessor) and tA
+// (upper half of A + lower half of B); carry <- upper half of B
+template <int N>
+__device__ __forceinline__ void ola_emit_pair(const c32* v, float* carry, const OlaWeights<N>& ow, float* __restrict__ og,
+                                              const float* __restrict__ win, int tA, bool first_pair, int T, int L, int lane) {
+    constexpr int EH = FftPlan<N>::E / 2, H = N / 2;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int seg = tA - 1 + which;
+        const bool emit = (which == 1 || !first_pair) && seg >= 0 && seg < T;       // wave-uniform
+        float val[EH];
+#pragma unroll
+        for (int e = 0; e < EH; ++e)
+            val[e] = which == 0 ? fmaf(v[e].x, ow.cA[e], carry[e]) : fmaf(-v[e].y, ow.cA[e], v[e + EH].x * ow.cB[e]);
+        if (emit) {
+            if (seg + 1 >= T) {
+#pragma unroll
+                for (int e = 0; e < EH; ++e) val[e] *= ola_last_segment_factor<N>(win, lane, e);
+            }
+            float* o = og + (long long)seg * H + lane;
+            if ((long long)(seg + 1) * H <= L) {
+#pragma unroll
+                for (int e = 0; e < EH; ++e) o[64 * e] = val[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < EH; ++e)
+                    if ((long long)seg * H + lane + 64 * e < L) o[64 * e] = val[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EH; ++e) carry[e] = -v[e + EH].y * ow.cB[e];
+}
+
 #ifndef DISCO_AI_PREFETCH
 #define DISCO_AI_PREFETCH 1
 #endif
@@ -277,8 +340,8 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
     }
     WaveTw<N> wtw;
     wtw.init(tw, lane);
-    float w[E];
-    load_window<N>(w, win, lane);
+    OlaWeights<N> ow;
+    ow.init(win, lane);
     float carry[EH];
 #pragma unroll
     for (int e = 0; e < EH; ++e) carry[e] = 0.f;
@@ -322,7 +385,7 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
                     c32 v;
                     if constexpr (PF) v = xr[PF ? fr : 0][PF ? j : 0][i];
                     else v = Xg[(tf0 + f) * M + i];
-                    x[i] = tv ? v : make_float2(0.f, 0.f);
+                    x[i] = v;                          // frames past the signal: clamped (finite) data, their yf is zeroed below
                 }
                 if constexpr (K > 1) {
                     c32 wl[M];
@@ -346,43 +409,24 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
                     const int jn = jj < k ? jj : jj + 1;
                     const c32 z = sh.zbuf[fr][jn][f];
                     const c32 ww = wg[j][M + jj];
-                    yf[fr][j].x = fmaf(ww.x, z.x, fmaf(ww.y, z.y, yf[fr][j].x));
-                    yf[fr][j].y = fmaf(ww.x, z.y, fmaf(-ww.y, z.x, yf[fr][j].y));
+                    yf[fr][j] = cfma_conj(ww, z, yf[fr][j]);
                 }
             }
+        }
+        if (tA + 1 >= T) {                           // wave-uniform, last pair of a signal only: frames past the end contribute nothing
+#pragma unroll
+            for (int fr = 0; fr < 2; ++fr)
+                if (tA + fr >= T) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) yf[fr][j] = make_float2(0.f, 0.f);
+                }
         }
         // ---- V = A~ + i B~ (Hermitian extensions of the two frames), conjugated for the inverse-by-forward trick
         c32* buf = sh.buf[k];
-        DISCO_LDS_WAR();
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (j < EH || lane == 0) {
-                const int f = (j < EH) ? lane + 64 * j : F - 1;
-                c32 A = yf[0][j], B = yf[1][j];
-                if (f == 0 || f == N / 2) {          // irfft ignores the imaginary part of DC and Nyquist
-                    A.y = 0.f;
-                    B.y = 0.f;
-                }
-                // conj(V[f]) with V[f] = A + iB = (A.x - B.y, A.y + B.x)
-                buf[fft_pad<N>(f)] = make_float2(A.x - B.y, -(A.y + B.x));
-                // conj(V[N-f]) with V[N-f] = conj(A) + i conj(B) = (A.x + B.y, -A.y + B.x)
-                if (f != 0 && f != N / 2) buf[fft_pad<N>(N - f)] = make_float2(A.x + B.y, A.y - B.x);
-            }
-        }
-        DISCO_LDS_RAW();
         c32 v[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = buf[fft_pad<N>(lane + 64 * e)];
+        irfft_pair_pack<N>(yf[0], yf[1], v, lane);       // cross-lane, no LDS round trip (fft.h)
         fetch_pair(tA + 2);                               // next pair, in flight during the FFT (harmless clamp at the end)
         fft_wave<N>(v, wtw, buf, lane);
-        // time frames: gA[n] = win[n] Re(conj(out))/N = win[n] v.x / N ; gB[n] = -win[n] v.y / N ;  n = lane + 64 e
-        const float inv = 1.0f / N;
-        float gA[E], gB[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            gA[e] = v[e].x * (w[e] * inv);
-            gB[e] = -v[e].y * (w[e] * inv);
-        }
         if constexpr (PF) {
 #pragma unroll
             for (int fr = 0; fr < 2; ++fr)
@@ -394,28 +438,147 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
                         DISCO_CONSUME(xr[PF ? fr : 0][PF ? j : 0][i].y);
                     }
         }
-        // ---- overlap-add: segment (tA-1) = carry + gA[lo], segment tA = gA[hi] + gB[lo], carry <- gB[hi]
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const int seg = tA - 1 + which;
-            const bool emit = (which == 1 || pr > 0) && seg >= 0 && seg < T;     // the block's first "carry" segment belongs to its predecessor
-#pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                const float hi = which == 0 ? carry[e] : gA[e + EH];
-                const float lo = which == 0 ? gA[e] : gB[e];
-                const long long pos = (long long)seg * H + lane + 64 * e;
-                float wss = w[e + EH] * w[e + EH];
-                if (seg + 1 < T) wss += w[e] * w[e];
-                float val = hi + lo;
-                if (wss > 1.17549435e-38f) val /= wss;
-                if (emit && pos < L) og[pos] = val;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EH; ++e) carry[e] = gB[e + EH];
+        // ---- window, overlap-add: segment (tA-1) = carry + A[lo], segment tA = A[hi] + B[lo], carry <- B[hi]
+        ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, L, lane);
         // zbuf is rewritten by the next pair only after every wave has passed the next __syncthreads... but a fast wave
         // could reach its z stores of pair pr+1 while a slow one still reads zbuf of pair pr: fence the reuse
         if constexpr (K > 1) __syncthreads();
+    }
+}
+
+// ---- step-2 filter + iSTFT straight from the SAMPLES (tango.py:335 + 445 + 528) ---------------------------------------
+// k_step2_apply_istft with the read of X (8 M F bytes per node-frame) replaced by the 4 M H bytes of samples the spectra came
+// from: wave k streams node k's frames two at a time -- M/2 forward transforms per frame on the packed butterflies of pk.h,
+// the half-window shared by consecutive frames recycled in registers as in k_stft -- and filters every channel pair as it
+// leaves the untangle (z_k and the local part of yf_k accumulate over the pairs).  z exchange, remote rows, the inverse
+// transform of the frame pair and the overlap-add are k_step2_apply_istft's.  SURVEY 8d prices the path this way
+// ("16 M H": every pass over the signals re-transforms the samples); it pays once a transform costs ~140 instructions.
+template <int N, int M, int K>
+__global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_stft_apply_istft(
+    const float* __restrict__ y, const c32* __restrict__ w_loc_g, const c32* __restrict__ w_glo_g, float* __restrict__ out,
+    const float* __restrict__ win, const c32* __restrict__ tw, int L, int T, int pad_mode, int blocks_per_room, int pairs) {
+    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, NJ = EH + 1, P = M + K - 1, CHP = (M + 1) / 2;
+    static_assert(K > 1, "single node: k_stft_apply_istft");
+    __shared__ ApplyIstftShared<N, M, K> sh;
+    const int k = wave_id(), lane = threadIdx.x & 63;
+    const long long r = blockIdx.x / blocks_per_room;
+    const int s0 = (int)(blockIdx.x % blocks_per_room) * (2 * pairs - 1);       // first hop segment == first frame
+    const long long g = r * K + k;
+    {
+        const c32* src = w_loc_g + (r * K) * (long long)F * M;
+        c32* dst = &sh.wl[0][0][0];
+        for (int i = threadIdx.x; i < K * F * M; i += 64 * K) dst[i] = src[i];
+    }
+    c32 wg[NJ][P];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int f = (j < EH) ? lane + 64 * j : F - 1;
+#pragma unroll
+        for (int i = 0; i < P; ++i) wg[j][i] = w_glo_g[(g * F + f) * P + i];
+    }
+    WaveTw<N> wtw;
+    wtw.init(tw, lane);
+    float w[E];
+    load_window_half<N>(w, win, lane);
+    OlaWeights<N> ow;
+    ow.init(win, lane);
+    const float* xa[CHP];
+    const float* xb[CHP];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) {
+        xa[p] = y + (g * M + 2 * p) * (long long)L;
+        xb[p] = (2 * p + 1 < M) ? y + (g * M + 2 * p + 1) * (long long)L : xa[p];
+    }
+    c32 raw[CHP][E];
+#pragma unroll
+    for (int p = 0; p < CHP; ++p) load_frame_slots<N, 0, E>(raw[p], xa[p], xb[p], min(s0, T - 1), L, pad_mode, lane);
+    float carry[EH];
+#pragma unroll
+    for (int e = 0; e < EH; ++e) carry[e] = 0.f;
+    float* og = out + g * (long long)L;
+    c32* buf = sh.buf[k];
+    __syncthreads();
+    for (int pr = 0; pr < pairs; ++pr) {
+        const int tA = s0 + 2 * pr;
+        c32 yf[2][NJ];
+        // ---- transform, local part of yf and z for both frames
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+            const int t = tA + fr;
+            c32 nxt[CHP][EH];                        // the next frame's new half-window, in flight under this frame's transforms
+#pragma unroll
+            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], min(t + 1, T - 1), L, pad_mode, lane);
+            c32 zl[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) yf[fr][j] = zl[j] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < CHP; ++p) {
+                c32 v[E];
+                apply_window<N>(v, raw[p], w, 2 * p + 1 < M);
+                fft_wave<N>(v, wtw, buf, lane);
+                rfft_pair_untangle<N>(v, buf, lane, [&](int j, int f, c32 a, c32 b) {
+                    c32 wla, wlb = make_float2(0.f, 0.f);
+                    if constexpr (M % 2 == 0) {        // (w_loc[2p], w_loc[2p+1]) as one 16-byte LDS read
+                        const float4 q4 = *reinterpret_cast<const float4*>(&sh.wl[k][f][2 * p]);
+                        wla = make_float2(q4.x, q4.y);
+                        wlb = make_float2(q4.z, q4.w);
+                    } else {
+                        wla = sh.wl[k][f][2 * p];
+                        if (2 * p + 1 < M) wlb = sh.wl[k][f][2 * p + 1];
+                    }
+                    c32 za = cfma_conj(wla, a, zl[j]);
+                    c32 ya = cfma_conj(wg[j][2 * p], a, yf[fr][j]);
+                    if (2 * p + 1 < M) {
+                        za = cfma_conj(wlb, b, za);
+                        ya = cfma_conj(wg[j][2 * p + 1], b, ya);
+                    }
+                    zl[j] = za;
+                    yf[fr][j] = ya;
+                });
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = (j < EH) ? lane + 64 * j : F - 1;
+                if (j < EH || lane == 0) sh.zbuf[fr][k][f] = zl[j];
+            }
+#pragma unroll
+            for (int p = 0; p < CHP; ++p)
+#pragma unroll
+                for (int e = 0; e < EH; ++e) {
+                    DISCO_CONSUME(nxt[p][e].x);
+                    DISCO_CONSUME(nxt[p][e].y);
+                    raw[p][e] = raw[p][e + EH];
+                    raw[p][e + EH] = nxt[p][e];
+                }
+        }
+        __syncthreads();
+        // ---- remote rows: yf += sum_jj conj(wg[M+jj]) z_j   (concatenate_signals order)
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = (j < EH) ? lane + 64 * j : F - 1;
+#pragma unroll
+                for (int jj = 0; jj < K - 1; ++jj) {
+                    const int jn = jj < k ? jj : jj + 1;
+                    yf[fr][j] = cfma_conj(wg[j][M + jj], sh.zbuf[fr][jn][f], yf[fr][j]);
+                }
+            }
+        }
+        if (tA + 1 >= T) {                           // wave-uniform, last pair of a signal only: frames past the end contribute nothing
+#pragma unroll
+            for (int fr = 0; fr < 2; ++fr)
+                if (tA + fr >= T) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) yf[fr][j] = make_float2(0.f, 0.f);
+                }
+        }
+        // ---- V = A~ + i B~ (Hermitian extensions of the two frames), conjugated for the inverse-by-forward trick
+        c32 v[E];
+        irfft_pair_pack<N>(yf[0], yf[1], v, lane);       // cross-lane, no LDS round trip (fft.h)
+        fft_wave<N>(v, wtw, buf, lane);
+        ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, L, lane);
+        __syncthreads();                             // zbuf is rewritten by the next pair
     }
 }
 
@@ -448,7 +611,12 @@ __global__ __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_
     for (int j = 0; j < NJ; ++j) {
         const int f = (j < EH) ? lane + 64 * j : F - 1;
 #pragma unroll
-        for (int i = 0; i < M; ++i) wg[j][i] = wf[(g * F + f) * M + i];
+        for (int i = 0; i < M; ++i) {
+            // at half weight: the forward transforms below run on the full-weight window (it is the synthesis window too), so
+            // the untangled spectra are 2 X (fft.h: rfft_pair_untangle leaves the division by two to its caller); exact
+            const c32 wv = wf[(g * F + f) * M + i];
+            wg[j][i] = make_float2(0.5f * wv.x, 0.5f * wv.y);
+        }
     }
     const float* xa[CHP];
     const float* xb[CHP];
@@ -460,6 +628,8 @@ __global__ __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_
     c32 raw[CHP][E];
 #pragma unroll
     for (int p = 0; p < CHP; ++p) load_frame_slots<N, 0, E>(raw[p], xa[p], xb[p], min(s0, T - 1), L, pad_mode, lane);
+    OlaWeights<N> ow;
+    ow.init(win, lane);
     float carry[EH];
 #pragma unroll
     for (int e = 0; e < EH; ++e) carry[e] = 0.f;
@@ -482,13 +652,8 @@ __global__ __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_
                 fft_wave<N>(v, wtw, buf, lane);
                 rfft_pair_untangle<N>(v, buf, lane, [&](int j, int, c32 a, c32 b) {
                     // yf += conj(w_2p) X_2p + conj(w_2p+1) X_2p+1
-                    c32 acc = yf[fr][j];
-                    acc.x = fmaf(wg[j][2 * p].x, a.x, fmaf(wg[j][2 * p].y, a.y, acc.x));
-                    acc.y = fmaf(wg[j][2 * p].x, a.y, fmaf(-wg[j][2 * p].y, a.x, acc.y));
-                    if (2 * p + 1 < M) {
-                        acc.x = fmaf(wg[j][2 * p + 1].x, b.x, fmaf(wg[j][2 * p + 1].y, b.y, acc.x));
-                        acc.y = fmaf(wg[j][2 * p + 1].x, b.y, fmaf(-wg[j][2 * p + 1].y, b.x, acc.y));
-                    }
+                    c32 acc = cfma_conj(wg[j][2 * p], a, yf[fr][j]);
+                    if (2 * p + 1 < M) acc = cfma_conj(wg[j][2 * p + 1], b, acc);
                     yf[fr][j] = acc;
                 });
             }
@@ -507,51 +672,11 @@ __global__ __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_
                 }
         }
         // ---- V = A~ + i B~ (Hermitian extensions of the two filtered frames), conjugated for the inverse-by-forward trick
-        DISCO_LDS_WAR();
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (j < EH || lane == 0) {
-                const int f = (j < EH) ? lane + 64 * j : F - 1;
-                c32 A = yf[0][j], B = yf[1][j];
-                if (f == 0 || f == N / 2) {          // irfft ignores the imaginary part of DC and Nyquist
-                    A.y = 0.f;
-                    B.y = 0.f;
-                }
-                buf[fft_pad<N>(f)] = make_float2(A.x - B.y, -(A.y + B.x));
-                if (f != 0 && f != N / 2) buf[fft_pad<N>(N - f)] = make_float2(A.x + B.y, A.y - B.x);
-            }
-        }
-        DISCO_LDS_RAW();
         c32 v[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = buf[fft_pad<N>(lane + 64 * e)];
+        irfft_pair_pack<N>(yf[0], yf[1], v, lane);       // cross-lane, no LDS round trip (fft.h)
         fft_wave<N>(v, wtw, buf, lane);
-        const float inv = 1.0f / N;
-        float gA[E], gB[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            gA[e] = v[e].x * (w[e] * inv);
-            gB[e] = -v[e].y * (w[e] * inv);
-        }
-        // ---- overlap-add: segment (tA-1) = carry + gA[lo], segment tA = gA[hi] + gB[lo], carry <- gB[hi]
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const int seg = tA - 1 + which;
-            const bool emit = (which == 1 || pr > 0) && seg >= 0 && seg < T;     // the run's first "carry" segment belongs to its predecessor
-#pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                const float hi = which == 0 ? carry[e] : gA[e + EH];
-                const float lo = which == 0 ? gA[e] : gB[e];
-                const long long pos = (long long)seg * H + lane + 64 * e;
-                float wss = w[e + EH] * w[e + EH];
-                if (seg + 1 < T) wss += w[e] * w[e];
-                float val = hi + lo;
-                if (wss > 1.17549435e-38f) val /= wss;
-                if (emit && pos < L) og[pos] = val;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EH; ++e) carry[e] = gB[e + EH];
+        // ---- window, overlap-add: segment (tA-1) = carry + A[lo], segment tA = A[hi] + B[lo], carry <- B[hi]
+        ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, L, lane);
     }
 }
 

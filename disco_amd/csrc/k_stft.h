@@ -32,12 +32,28 @@ __device__ __forceinline__ void load_window(float* w, const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < FftPlan<N>::E; ++e) w[e] = win[lane + 64 * e];
 }
-// (a, b) * (w, w) for a full channel pair, (a, b) * (w, 0) when the pair's second channel does not exist
+// The analysis window at HALF weight: the transforms below run on (a + i b) / 2, which is what lets rfft_pair_untangle
+// separate the two spectra with one packed add each (fft.h).  0.5 w is exact, so every spectrum is bit-for-bit what the
+// full-weight window followed by the division gives.
+template <int N>
+__device__ __forceinline__ void load_window_half(float* w, const float* __restrict__ win, int lane) {
+#pragma unroll
+    for (int e = 0; e < FftPlan<N>::E; ++e) w[e] = 0.5f * win[lane + 64 * e];
+}
+// (a, b) * (w, w) for a full channel pair, (a, 0) * w when the pair's second channel does not exist.  One packed multiply per
+// slot: the window registers are read as pairs (w[2m], w[2m+1]) and the slot's weight is broadcast by the operand selectors.
 template <int N>
 __device__ __forceinline__ void apply_window(c32* v, const c32* raw, const float* w, bool has_b) {
-    const float sb = has_b ? 1.f : 0.f;
 #pragma unroll
-    for (int e = 0; e < FftPlan<N>::E; ++e) v[e] = make_float2(raw[e].x * w[e], raw[e].y * (w[e] * sb));
+    for (int m = 0; m < FftPlan<N>::E / 2; ++m) {
+        const c32 wp = make_float2(w[2 * m], w[2 * m + 1]);
+        v[2 * m] = scale_by_half<0>(raw[2 * m], wp);
+        v[2 * m + 1] = scale_by_half<1>(raw[2 * m + 1], wp);
+        if (!has_b) {
+            v[2 * m].y = 0.f;
+            v[2 * m + 1].y = 0.f;
+        }
+    }
 }
 
 // Slots [E0, E1) of centre-padded frame t of the channel pair (xa, xb), un-windowed: v[e] = (a, b)[lane + 64 e].
@@ -87,7 +103,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restric
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     float w[E];
-    load_window<N>(w, win, lane);
+    load_window_half<N>(w, win, lane);
     const float* xa[CHP];
     const float* xb[CHP];
 #pragma unroll
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* 
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     float w[E];
-    load_window<N>(w, win, lane);
+    load_window_half<N>(w, win, lane);
     const float* xa = x + (g * chans + (mine ? 2 * wave : 0)) * (long long)L;
     const float* xb = two ? xa + L : xa;
     c32 raw[E];
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_mask_oracle(const float* __
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     float w[E];
-    load_window<N>(w, win, lane);
+    load_window_half<N>(w, win, lane);
     const float* xs = s_ref + g * (long long)L;
     const float* xn = n_ref + g * (long long)L;
     c32 raw[E];
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WP
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     float w[E];
-    load_window<N>(w, win, lane);
+    load_window_half<N>(w, win, lane);
     const float* xa[CHP];
     const float* xb[CHP];
 #pragma unroll

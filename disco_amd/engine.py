@@ -195,6 +195,17 @@ class Engine:
         self._chk(self.lib.disco_band_stats(self.ctx, px, n_sig, L, start, stop, pb, pa, b.shape[0], st.ptr, self.stream))
         return st
 
+    def selftest_pk(self, a, b, c):
+        """a, b, c (n,) complex64 -> (out_hw, out_ref), each (n, 16) complex64: the packed complex operations of
+        csrc/pk.h through the v_pk_* instruction forms and through their C++ statement (include/disco_hip.h)."""
+        n = a.shape[0]
+        pa, ka = self.to_device(a, np.complex64)
+        pb, kb = self.to_device(b, np.complex64)
+        pc, kc = self.to_device(c, np.complex64)
+        hw, ref = self.empty((n, 16), np.complex64), self.empty((n, 16), np.complex64)
+        self._chk(self.lib.disco_selftest_pk(self.ctx, pa, pb, pc, n, hw.ptr, ref.ptr, self.stream))
+        return hw, ref
+
     def set_node_shard(self, first_node, node_count):
         """Hold only nodes [first_node, first_node + node_count) of every room (the rest live on other GPUs): the staged
         methods then take / return `node_count` nodes per room, while Zs / Zn / Z keep all K nodes (all-gathered z)."""

@@ -373,6 +373,15 @@ int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorptio
                   int64_t n_room, int n_src, int n_mic, int max_order, float fs, float c_sound,
                   float* rir, int rir_len, disco_stream s);
 
+/* ---- self-test of the packed complex arithmetic the FFT / covariance / filter kernels are written on ---------------
+ * (disco_amd/csrc/pk.h: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers; no reference counterpart --
+ * it pins the instruction encodings against their C++ statement, which is what the CPU-side kernel tests execute.)
+ * a, b, c: [n] complex64 operands -> out_hw, out_ref: [n][DISCO_PK_SELFTEST_OPS] complex64, the same operations through
+ * the instruction forms and through plain C++.  ctx may be NULL. */
+#define DISCO_PK_SELFTEST_OPS 16
+int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco_c32* b, const disco_c32* c, int64_t n,
+                      disco_c32* out_hw, disco_c32* out_ref, disco_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -535,20 +535,35 @@ def check_solver_vs_reference_golden(make_engine, golden_dir):
     return worst
 
 
-def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-4, staged_step2=False, tuning=None):
+def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-4, staged_step2=False, tuning=None,
+                           from_samples=None):
     """Whole path through the C ABI vs the float64 oracle.  y, s, n: (R, K, M, L) float32.
     tuning = (stft_frames_per_wave, cov_chunks, step2_chunks, istft_pairs): pin the launch geometry (disco_set_tuning) to
     the one a large batch takes, and additionally check the `outputs=enhanced` call (no z / yf requested: the fused
     filter+iSTFT kernel, which is what bench.py times) against the same oracle.
+    from_samples = 0 | 1: which step-2 filter + iSTFT kernel the `outputs=enhanced` call takes -- the one reading the stored
+    spectra back or the one re-transforming the samples (the library reads DISCO_STEP2_FROM_SAMPLES when a context is
+    created); None: the library's default.
     Returns the per-output worst relative errors."""
+    import os
     R, K, M, L = y.shape
-    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask, staged_step2=staged_step2)
+    saved = os.environ.get('DISCO_STEP2_FROM_SAMPLES')
+    if from_samples is not None:
+        os.environ['DISCO_STEP2_FROM_SAMPLES'] = str(int(from_samples))
+    try:
+        eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask, staged_step2=staged_step2)
+    finally:
+        if from_samples is not None:
+            if saved is None:
+                del os.environ['DISCO_STEP2_FROM_SAMPLES']
+            else:
+                os.environ['DISCO_STEP2_FROM_SAMPLES'] = saved
     if tuning is not None:
         eng.set_tuning(*tuning)
     T, F = eng.T, eng.F
     m_dev = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F)
     out, z, yf = eng.tango_enhance(y, m_dev)
-    out_enh = eng.tango_enhance(y, m_dev, want_z=False, want_yf=False)[0].numpy() if tuning is not None else None
+    out_enh = eng.tango_enhance(y, m_dev, want_z=False, want_yf=False)[0].numpy()
     out, z, yf, m_gpu = out.numpy(), z.numpy(), yf.numpy(), m_dev.numpy()
     errs = {'mask': 0.0, 'mask_max': 0.0, 'z_y': 0.0, 'yf': 0.0, 'out': 0.0}
     for r in range(R):
@@ -788,4 +803,25 @@ def check_enhanced_path_vs_long_golden(make_engine, golden_dir, staged=False):
         ref_t = so.istft(g[f'yf{k}'], L, work_dtype=np.float64)
         errs[f'out{k}'] = relerr(out.numpy()[0, k], ref_t)
     assert max(errs.values()) < 1e-4, errs
+    return errs
+
+
+def check_pk_selftest(make_engine, n=4096, seed=11):
+    """csrc/pk.h: every packed complex operation through the v_pk_* instruction forms (on the emulated build: their C++
+    statement) must equal its C++ statement bit for bit, and both must mean what the operation's name says (NumPy)."""
+    rng = np.random.default_rng(seed)
+    a, b, c = [(rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) for _ in range(3)]
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    hw, ref = eng.selftest_pk(a, b, c)
+    hw, ref = hw.numpy(), ref.numpy()
+    assert np.array_equal(hw.view(np.uint32), ref.view(np.uint32)), 'instruction forms differ from their C++ statement'
+    A, B, C_ = a.astype(np.complex128), b.astype(np.complex128), c.astype(np.complex128)
+    h = 0.70710678118654752440
+    kt = 0.92387953251128675613 - 0.38268343236508977173j
+    want = [A + np.conj(B), -1j * (A - np.conj(B)), A - 1j * B, A + 1j * B, np.conj(A + 1j * B), (1 - 1j) * A, (1 + 1j) * A,
+            A * B, A * kt, A * np.conj(B), C_ + np.conj(A) * B, C_ + h * A, C_ - h * A, A * B.real, A * B.imag, C_ + A * B.imag]
+    errs = {}
+    for q, w in enumerate(want):
+        errs[q] = float(np.abs(hw[:, q] - w).max() / np.abs(w).max())
+    assert max(errs.values()) < 1e-6, errs
     return errs

@@ -30,6 +30,11 @@ def test_native_library_is_loaded(make_engine):
     assert 'libdisco_hip.so' in maps
 
 
+@pytest.mark.gpu
+def test_pk_instruction_forms(make_engine):
+    pc.check_pk_selftest(make_engine)
+
+
 @pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 160000, 4), (1024, 2600, 1), (1024, 40000, 8), (1024, 30000, 3),
                                            (512, 20000, 5), (512, 45000, 8), (1024, 21000, 4), (1024, 30000, 7)])
 @pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
@@ -148,6 +153,17 @@ def test_tango_end_to_end_vs_oracle(make_engine, K, M, L, n_fft, staged):
 def test_tango_bench_geometry(make_engine, R, K, M, L, n_fft, tuning):
     y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
     errs = pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, tuning=tuning)
+    print(errs)
+
+
+@pytest.mark.parametrize('from_samples', [0, 1])
+@pytest.mark.parametrize('R,K,M,L,tuning', [(2, 4, 4, 160000, (80, 1, 1, 64)), (2, 2, 3, 41000, None), (1, 3, 2, 25700, (80, 1, 1, 5)),
+                                            (2, 4, 1, 30000, None)])
+def test_step2_from_samples_and_from_spectra(make_engine, R, K, M, L, tuning, from_samples):
+    """Both step-2 filter + iSTFT kernels of the enhanced-only call: reading the stored spectra back (0) and re-transforming
+    the samples (1), at the bench geometry and at ragged ones."""
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    errs = pc.check_tango_end_to_end(make_engine, y, s, n, tol=1e-4, tuning=tuning, from_samples=from_samples)
     print(errs)
 
 

@@ -20,6 +20,10 @@ def make_engine():
     return mk
 
 
+def test_emu_pk_operations(make_engine):
+    pc.check_pk_selftest(make_engine, n=512)
+
+
 @pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 2048, 2), (1024, 2600, 1), (512, 9000, 4), (1024, 2600, 3), (1024, 9000, 8),
                                            (512, 2000, 5), (512, 4500, 8), (1024, 2100, 4)])
 @pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
@@ -123,6 +127,15 @@ def test_emu_tango_pinned_geometry(make_engine, K, M, L, n_fft, tuning):
     pairs per filter+iSTFT workgroup) pinned on a small batch through disco_set_tuning."""
     y, s, n = synth.make_rooms_numpy(2, K=K, M=M, L=L)
     print(pc.check_tango_end_to_end(make_engine, y, s, n, n_fft=n_fft, tol=1e-4, tuning=tuning))
+
+
+@pytest.mark.parametrize('from_samples', [0, 1])
+@pytest.mark.parametrize('K,M,L,tuning', [(4, 4, 5000, None), (2, 3, 9000, (80, 1, 1, 3)), (3, 2, 2304, (5, 2, 2, 2)), (2, 1, 700, None)])
+def test_emu_step2_from_samples_and_from_spectra(make_engine, K, M, L, tuning, from_samples):
+    """Both step-2 filter + iSTFT kernels of the enhanced-only call: reading the stored spectra back (0) and re-transforming
+    the samples (1); odd and even mic counts, signals that end inside a frame pair, one-pair workgroups."""
+    y, s, n = synth.make_rooms_numpy(2, K=K, M=M, L=L)
+    print(pc.check_tango_end_to_end(make_engine, y, s, n, tol=1e-4, tuning=tuning, from_samples=from_samples))
 
 
 @pytest.mark.parametrize('staged', [False, True])
