@@ -341,7 +341,7 @@ __device__ __forceinline__ void cov_split_fetch(c32* u, const c32* __restrict__ 
 
 // acc += (wa, wb) x { u_i conj(u_j) } over the role's pairs (TRI: the two upper triangles of X and Y, else the X x Y block)
 #ifndef DISCO_COV_PK
-#define DISCO_COV_PK 0
+#define DISCO_COV_PK 2
 #endif
 #if DISCO_COV_PK == 2
 // on the instruction forms of pk.h: u_i conj(u_j) in two packed instructions, one packed fma per statistic (weights broadcast

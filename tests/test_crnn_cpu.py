@@ -96,3 +96,17 @@ def test_frame_to_pred_last_and_normalisations(gold, golden_dir, tag, n_ch, ftp,
         model.predict_masks(mag, norm_type='pcen')
     with pytest.raises(ValueError):
         model.predict_masks(mag, frame_to_pred='all')
+
+
+def test_dnn_utils_normalization_vs_reference_golden(golden_dir):
+    """disco_amd/dnn/utils.py:normalization against outputs of the reference's own function (dnn/utils.py:14-41)."""
+    import os
+    from disco_amd.dnn.utils import normalization
+    g = np.load(os.path.join(golden_dir, 'dnn_normalization_ref.npz'))
+    x = torch.from_numpy(g['x'])
+    for nt in ('scale_to_unit_norm', 'scale_to_1', 'center_and_scale', 'none'):
+        for axis in (0, 1, 2):
+            got = normalization(x, None if nt == 'none' else nt, axis).numpy()
+            ref = g[f'{nt}_axis{axis}']
+            assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), (nt, axis)
+    assert normalization(x, 'something_else') is x          # unknown types pass through, as in the reference
