@@ -204,6 +204,9 @@ def parse_args(argv=None):
                     help='> 1: the DANSE-style iterated scheme (BASELINE configs[4]; disco_tango_enhance_iterated)')
     ap.add_argument('--shard', default='rooms', choices=['rooms', 'nodes'],
                     help="'nodes': split the nodes of every room over the ranks, one RCCL all-gather of z per step-2 iteration")
+    ap.add_argument('--graph', action='store_true',
+                    help='capture one step (mask + whole path) into a hipGraph on a side stream and time its replays: one launch per '
+                         'step instead of 6-20 (matters for small batches; oracle masks, room-sharded batch path only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the sampled-room oracle check after the timed region')
@@ -332,6 +335,27 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    eager_step = step
+    if args.graph:
+        if args.mask != 'oracle' or node_sharded or args.online_every:
+            raise SystemExit('--graph captures the room-sharded batch path with oracle masks')
+        eng.reserve(0)
+        step()                              # nothing is left to allocate inside the captured calls
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        hip_graph = torch.cuda.CUDAGraph()
+        h = side.cuda_stream
+        with torch.cuda.graph(hip_graph, stream=side):
+            eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), h))
+            if args.iters > 1:
+                eng._chk(lib.disco_tango_enhance_iterated(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), args.iters,
+                                                          out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), h))
+            else:
+                eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                                 None, None, ws.data_ptr(), ws.numel(), h))
+        torch.cuda.synchronize()
+        step = hip_graph.replay             # replays on the current (null) stream, the one the barriers drain
+
     if args.pmc_calibrate:
         src = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
         dst = torch.empty_like(src)
@@ -361,14 +385,14 @@ def main(argv=None):
     roofline, stages = None, None
     if rank == 0 and not args.no_stage_timing and args.mask == 'oracle' and not node_sharded:
         reps = max(2, min(args.steps, 5))
-        step()                                  # the event objects are created inside the library: warm that path once
+        eager_step()                            # the event objects are created inside the library: warm that path once
         torch.cuda.synchronize()
         # one report per step, and the MEDIAN over the steps: an event pair also spans whatever the host does between the two
         # records, and a single descheduled launch call (seen once: 85 ms inside one 7 ms stage) would otherwise own the mean
         per_rep = []
         for _ in range(reps):
             eng.stage_timing(True)
-            step()
+            eager_step()                        # (a captured graph carries no events: the stage pass always launches eagerly)
             per_rep.append(eng.stage_report())
         eng.stage_timing(False)
         kab = kernel_alg_bytes(M, K, F, H)
@@ -443,6 +467,7 @@ def main(argv=None):
                                    f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced'
                                    + (f', ONLINE mode lambda=0.95 update_every={args.online_every}' if args.online_every else '')
                                    + (f', {args.iters} step-2 iterations (DANSE-style)' if args.iters > 1 else ''),
+                       'launch': 'one hipGraph replay per step' if args.graph else 'eager kernel launches',
                        'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
                        'iters': args.iters, 'parallelism': par},
             'roofline': roofline, 'cpu_baseline': cpu, 'parity_sample': parity, 'stages': stages,

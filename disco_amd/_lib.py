@@ -14,6 +14,7 @@ E_ARG, E_UNSUPPORTED, E_HIP_BASE = -1, -2, -1000
 MASK_TYPES = {'irm': 0, 'ibm': 1, 'iam': 2}
 PAD_MODES = {'reflect': 0, 'constant': 1}
 FLAG_STAGED_STEP2 = 1
+FLAG_LAZY_SCRATCH = 2
 
 
 class DiscoCfg(C.Structure):
@@ -41,6 +42,8 @@ PROTOTYPES = {
     'disco_n_frames': (_int, [_vp]),
     'disco_n_freq': (_int, [_vp]),
     'disco_workspace_bytes': (_sz, [_vp]),
+    'disco_reserve': (_int, [_vp, _int]),
+    'disco_owned_bytes': (_sz, [_vp]),
     'disco_set_node_shard': (_int, [_vp, _int, _int]),
     'disco_set_z_blocks': (_int, [_vp, _int]),
     'disco_set_tuning': (_int, [_vp, _int, _int, _int, _int]),

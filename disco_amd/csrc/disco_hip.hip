@@ -162,6 +162,8 @@ extern "C" const char* disco_version(void) { return "disco_hip 0.2.0 (gfx950)"; 
 
 extern "C" const char* disco_last_error(const disco_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
 
+static int reserve_scratch(disco_ctx* ctx);
+
 extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     if (!out || !cfg) {
         snprintf(g_create_err, sizeof(g_create_err), "disco_create: null argument");
@@ -242,6 +244,15 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
         disco_destroy(ctx);
         return DISCO_E_HIP_BASE - (int)e;
     }
+    // the partial-sum blocks are sized here, so that no compute call allocates (or implicitly synchronises) on first use
+    if (!(cfg->flags & DISCO_FLAG_LAZY_SCRATCH)) {
+        const int rc = reserve_scratch(ctx);
+        if (rc) {
+            snprintf(g_create_err, sizeof(g_create_err), "disco_create: %s", ctx->err);
+            disco_destroy(ctx);
+            return rc;
+        }
+    }
     *out = ctx;
     return 0;
 }
@@ -310,6 +321,7 @@ extern "C" int disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int co
     ctx->tune_pairs = istft_pairs;
     ctx->pending_chunks = 0;           // partial sums of another geometry must not be re-used
     ctx->loc_M = 0;
+    if (!(ctx->cfg.flags & DISCO_FLAG_LAZY_SCRATCH)) return reserve_scratch(ctx);     // the new geometry may need larger blocks
     return 0;
 }
 
@@ -488,6 +500,18 @@ static int ensure_scratch(disco_ctx* ctx, size_t bytes) {
     return 0;
 }
 
+static int ensure_scratch2(disco_ctx* ctx, size_t bytes) {
+    if (ctx->scratch2_bytes >= bytes) return 0;
+    if (ctx->scratch2) {
+        HIPCHK(ctx, hipFree(ctx->scratch2));
+        ctx->scratch2 = nullptr;
+        ctx->scratch2_bytes = 0;
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->scratch2, bytes));
+    ctx->scratch2_bytes = bytes;
+    return 0;
+}
+
 static int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
     const long long n_gf = (long long)ctx->cfg.rooms * ctx->Kl * ctx->F;
     hipLaunchKernelGGL(k_cov_finalize, dim3((unsigned)std::min<long long>((n_gf + 127) / 128, 65535)), dim3(128), 0,
@@ -547,17 +571,7 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     const bool split = (KR == 0 || (P > 8 && same && mask_remote && (ctx->F - 1) % 64 == 0)) && cov_split_shape(M, KR);
     skiploc = skiploc && split && KR > 0 && ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask;
     int rc = 0;
-    if (skiploc) {
-        if (ctx->scratch2_bytes < need) {
-            if (ctx->scratch2) HIPCHK(ctx, hipFree(ctx->scratch2));
-            ctx->scratch2 = nullptr;
-            ctx->scratch2_bytes = 0;
-            HIPCHK(ctx, hipMalloc(&ctx->scratch2, need));
-            ctx->scratch2_bytes = need;
-        }
-    } else {
-        rc = ensure_scratch(ctx, need);
-    }
+    rc = skiploc ? ensure_scratch2(ctx, need) : ensure_scratch(ctx, need);
     if (rc) return rc;
     CovArgs a;
     a.X = (const c32*)X;
@@ -820,6 +834,18 @@ static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, co
     return false;
 }
 
+// frame chunks (= workgroups per node) of the fused STFT + covariance pass and the frames each of its waves streams: runs as long
+// as possible (<= 80 frames) while leaving >= ~2048 workgroups for the chip
+static int stft_cov_chunks(const disco_ctx* ctx, int* runw_out) {
+    const long long G = (long long)ctx->cfg.rooms * ctx->cfg.nodes;
+    const long long chunks_wanted = std::max<long long>(1, (2048 + G - 1) / G);
+    int runw = (int)((ctx->T + STFT_WAVES * chunks_wanted - 1) / (STFT_WAVES * chunks_wanted));
+    runw = std::min(80, std::max(8, runw));
+    if (ctx->tune_runw > 0) runw = ctx->tune_runw;
+    if (runw_out) *runw_out = runw;
+    return (ctx->T + STFT_WAVES * runw - 1) / (STFT_WAVES * runw);
+}
+
 // store = false (internal, single-node path): the spectra are not written (X may be NULL); only for shapes the fused kernel takes
 static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s,
                              bool store = true) {
@@ -835,12 +861,8 @@ static int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z
         return STAGE(ctx, s, "cov1", cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s));
     }
     const long long G = (long long)c.rooms * c.nodes;
-    // frames per wave: as long as possible (<= 80) while leaving >= ~2048 workgroups for the chip
-    const long long chunks_wanted = std::max<long long>(1, (2048 + G - 1) / G);
-    int runw = (int)((ctx->T + STFT_WAVES * chunks_wanted - 1) / (STFT_WAVES * chunks_wanted));
-    runw = std::min(80, std::max(8, runw));
-    if (ctx->tune_runw > 0) runw = ctx->tune_runw;
-    const int chunks = (ctx->T + STFT_WAVES * runw - 1) / (STFT_WAVES * runw);
+    int runw = 0;
+    const int chunks = stft_cov_chunks(ctx, &runw);
     const int NP = M * (M + 1) / 2;
     int rc = ensure_scratch(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
     if (rc) return rc;
@@ -909,17 +931,7 @@ static int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* m
     const int NP = P * (P + 1) / 2;
     const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
     int rc = 0;
-    if (skiploc) {
-        if (ctx->scratch2_bytes < need) {
-            if (ctx->scratch2) HIPCHK(ctx, hipFree(ctx->scratch2));
-            ctx->scratch2 = nullptr;
-            ctx->scratch2_bytes = 0;
-            HIPCHK(ctx, hipMalloc(&ctx->scratch2, need));
-            ctx->scratch2_bytes = need;
-        }
-    } else {
-        rc = ensure_scratch(ctx, need);
-    }
+    rc = skiploc ? ensure_scratch2(ctx, need) : ensure_scratch(ctx, need);
     if (rc) return rc;
     Step2Args a;
     a.X = (const c32*)X;
@@ -1185,6 +1197,21 @@ static int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, 
     return check_launch(ctx, "k_stft_apply_istft");
 }
 
+// Both partial-sum blocks at the largest size any covariance call of this context can ask for with the present geometry:
+// [R * Kl][chunks][F][P (P + 1) / 2] float4 with P = M + K - 1 and the largest of the three chunk counts.
+static int reserve_scratch(disco_ctx* ctx) {
+    const disco_cfg& c = ctx->cfg;
+    const size_t G = (size_t)c.rooms * ctx->Kl;
+    const size_t P = (size_t)std::min(c.mics + c.nodes - 1, 16);
+    const size_t NP = P * (P + 1) / 2;
+    int chunks = std::max(cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));
+    if (c.mics <= 8) chunks = std::max(chunks, stft_cov_chunks(ctx, nullptr));
+    const size_t need = G * (size_t)chunks * ctx->F * NP * sizeof(float4);
+    int rc = ensure_scratch(ctx, need);
+    if (!rc) rc = ensure_scratch2(ctx, need);
+    return rc;
+}
+
 extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
                                    disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
     DISCO_ENTER(ctx);
@@ -1305,6 +1332,29 @@ inline unsigned ew_grid(long long n) { return (unsigned)std::min<long long>((n +
 }  // namespace
 
 extern "C" size_t disco_reference_workspace_bytes(const disco_ctx* ctx) { return ctx ? ref_layout(ctx).total : 0; }
+
+extern "C" size_t disco_owned_bytes(const disco_ctx* ctx) {
+    return ctx ? ctx->scratch_bytes + ctx->scratch2_bytes + ctx->own_ws_bytes + ctx->conv_ws_bytes : 0;
+}
+
+extern "C" int disco_reserve(disco_ctx* ctx, int own_workspace) {
+    DISCO_ENTER(ctx);
+    if (own_workspace < 0 || own_workspace > 2) return fail(ctx, DISCO_E_ARG, "disco_reserve: own_workspace must be 0, 1 or 2");
+    int rc = reserve_scratch(ctx);
+    if (rc || !own_workspace) return rc;
+    size_t need = ws_layout(ctx).total;
+    if (own_workspace == 2) need = std::max(need, ref_layout(ctx).total);
+    if (ctx->own_ws_bytes < need) {
+        if (ctx->own_ws) {
+            HIPCHK(ctx, hipFree(ctx->own_ws));
+            ctx->own_ws = nullptr;
+            ctx->own_ws_bytes = 0;
+        }
+        HIPCHK(ctx, hipMalloc(&ctx->own_ws, need));
+        ctx->own_ws_bytes = need;
+    }
+    return 0;
+}
 
 extern "C" int disco_tango_reference(disco_ctx* ctx, const float* y, const float* s_img, const float* n_img, const float* mask_z_in,
                                      const float* mask_w_in, int mask_for_z, int steps, const disco_ref_outputs* out,

@@ -63,14 +63,14 @@ def parse_mask_type(mask):
 
 class Engine:
     def __init__(self, rooms, nodes, mics, length, n_fft=512, hop=None, ref_mic=0, mask='irm1', bin_thr=0.0,
-                 mu=1.0, pad_mode='reflect', device=0, lib=None, staged_step2=False):
+                 mu=1.0, pad_mode='reflect', device=0, lib=None, staged_step2=False, lazy_scratch=False):
         self.lib = lib if lib is not None else L.load()
         mt, mp = parse_mask_type(mask)
         hop = n_fft // 2 if hop is None else hop
         self.cfg = L.DiscoCfg(rooms=rooms, nodes=nodes, mics=mics, length=length, n_fft=n_fft, hop=hop,
                               ref_mic=ref_mic, mask_type=mt, mask_pow=mp, mask_bin_thr_db=bin_thr, mu=mu,
                               pad_mode=L.PAD_MODES[pad_mode], device=device,
-                              flags=L.FLAG_STAGED_STEP2 if staged_step2 else 0)
+                              flags=(L.FLAG_STAGED_STEP2 if staged_step2 else 0) | (L.FLAG_LAZY_SCRATCH if lazy_scratch else 0))
         ctx = C.c_void_p()
         rc = self.lib.disco_create(C.byref(ctx), C.byref(self.cfg))
         self.ctx = ctx.value if rc == 0 else None
@@ -205,6 +205,16 @@ class Engine:
         hw, ref = self.empty((n, 16), np.complex64), self.empty((n, 16), np.complex64)
         self._chk(self.lib.disco_selftest_pk(self.ctx, pa, pb, pc, n, hw.ptr, ref.ptr, self.stream))
         return hw, ref
+
+    def reserve(self, own_workspace=1):
+        """Allocate now what the whole-path calls would allocate on first use (0: partial-sum blocks only, 1: + the context's
+        own workspace of tango_enhance / _iterated / _online, 2: + tango_reference's).  Afterwards a call is a fixed sequence of
+        kernel launches on `self.stream` -- no allocation, no synchronisation -- and can be captured into a hipGraph."""
+        self._chk(self.lib.disco_reserve(self.ctx, int(own_workspace)))
+
+    def owned_bytes(self):
+        """Device bytes the context owns (unchanged across a call <=> the call allocated nothing)."""
+        return int(self.lib.disco_owned_bytes(self.ctx))
 
     def set_node_shard(self, first_node, node_count):
         """Hold only nodes [first_node, first_node + node_count) of every room (the rest live on other GPUs): the staged

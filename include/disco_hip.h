@@ -49,6 +49,9 @@ extern "C" {
 /* disco_cfg.flags: run step 2 of disco_tango_enhance through the staged kernels (z materialised in HBM, the form a
  * node-sharded multi-GPU run needs) instead of the default in-register exchange. */
 #define DISCO_FLAG_STAGED_STEP2 1
+/* disco_cfg.flags: do not size the covariance partial-sum blocks at disco_create; they are then allocated by the first call
+ * that needs them (a hipMalloc inside that call).  For contexts that only ever run the transforms / masks / metrics. */
+#define DISCO_FLAG_LAZY_SCRATCH 2
 
 #define DISCO_PAD_REFLECT  0   /* librosa < 0.10 (the reference's era)  */
 #define DISCO_PAD_CONSTANT 1   /* librosa >= 0.10                        */
@@ -86,6 +89,18 @@ int  disco_n_frames(const disco_ctx* ctx);               /* T = 1 + L/hop   (lib
 int  disco_n_freq(const disco_ctx* ctx);                 /* F = n_fft/2 + 1                            */
 /* Bytes of device workspace disco_tango_enhance needs for this cfg (STFT + z + yf + covariances). */
 size_t disco_workspace_bytes(const disco_ctx* ctx);
+
+/* Device memory the library owns.  disco_create sizes the two covariance partial-sum blocks for the cfg and the launch geometry
+ * (unless DISCO_FLAG_LAZY_SCRATCH); disco_set_tuning re-sizes them.  disco_reserve(ctx, 1) additionally allocates the context's
+ * own whole-path workspace (disco_workspace_bytes) that disco_tango_enhance / _iterated / _online fall back to when the caller
+ * passes workspace = NULL; disco_reserve(ctx, 2) sizes it for disco_tango_reference as well (disco_reference_workspace_bytes);
+ * disco_reserve(ctx, 0) only re-sizes the partial-sum blocks (e.g. after disco_set_node_shard).  After it, none of the whole-path or stage entry points allocates, frees or synchronises:
+ * a call is a fixed sequence of kernel launches on the caller's stream and can be captured into a hipGraph
+ * (hipStreamBeginCapture on that stream, stage timers off) and replayed.  (disco_rir_convolve keeps its own lazy workspace.) */
+int  disco_reserve(disco_ctx* ctx, int own_workspace);
+/* Bytes of device memory the context owns right now (partial-sum blocks + own workspace + convolution workspace): unchanged
+ * across a call <=> that call allocated nothing. */
+size_t disco_owned_bytes(const disco_ctx* ctx);
 
 /* Node-sharded operation (SURVEY 8e "finer sharding"): this context holds only nodes [first_node, first_node + count)
  * of every room; the other nodes live on other GPUs and their compressed signals arrive through an all-gather of z

@@ -825,3 +825,41 @@ def check_pk_selftest(make_engine, n=4096, seed=11):
         errs[q] = float(np.abs(hw[:, q] - w).max() / np.abs(w).max())
     assert max(errs.values()) < 1e-6, errs
     return errs
+
+
+def check_no_allocation_in_compute_calls(make_engine, K=3, M=2, L=6000, n_fft=512):
+    """include/disco_hip.h: disco_create sizes the partial-sum blocks, disco_reserve(ctx, 1|2) the context's own workspace;
+    afterwards no whole-path or stage call allocates (disco_owned_bytes is unchanged across every one of them), also after
+    disco_set_tuning picks another geometry.  With DISCO_FLAG_LAZY_SCRATCH nothing is owned until the first covariance call."""
+    from disco_amd import synth, _lib
+    y, s, n = synth.make_rooms_numpy(2, K=K, M=M, L=L)
+    eng = make_engine(rooms=2, nodes=K, mics=M, length=L, n_fft=n_fft)
+    assert eng.owned_bytes() > 0
+    eng.reserve(2)
+    own = eng.owned_bytes()
+    assert own >= eng.workspace_bytes()
+    m = eng.mask_oracle(s[:, :, 0].reshape(2 * K, L), n[:, :, 0].reshape(2 * K, L)).reshape(2, K, eng.T, eng.F)
+    eng.tango_enhance(y, m)
+    eng.tango_enhance(y, m, want_z=False, want_yf=False)
+    eng.tango_enhance_iterated(y, m, iters=2)
+    eng.tango_reference(y, s, n)
+    X = eng.stft(y.reshape(2 * K, M, L))
+    eng.cov_masked(X.reshape(2, K, eng.T, eng.F, M), m)
+    assert eng.owned_bytes() == own, (eng.owned_bytes(), own)
+    for tuning in ((8, 8, 8, 2), (80, 1, 1, 64), (0, 0, 0, 0)):
+        eng.set_tuning(*tuning)
+        own_t = eng.owned_bytes()
+        assert own_t >= own
+        eng.tango_enhance(y, m)
+        eng.tango_enhance_iterated(y, m, iters=2)
+        assert eng.owned_bytes() == own_t, (tuning, eng.owned_bytes(), own_t)
+    # opt-out: nothing is owned until a covariance call needs it
+    lazy = make_engine(rooms=2, nodes=K, mics=M, length=L, n_fft=n_fft, lazy_scratch=True)
+    assert lazy.owned_bytes() == 0
+    lazy.stft(y.reshape(2 * K, M, L))
+    assert lazy.owned_bytes() == 0
+    out_lazy = lazy.tango_enhance(y, m.numpy())[0].numpy()
+    assert lazy.owned_bytes() > 0
+    eng.set_tuning(0, 0, 0, 0)
+    assert np.array_equal(out_lazy, eng.tango_enhance(y, m)[0].numpy())
+    return own

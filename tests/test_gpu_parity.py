@@ -225,3 +225,7 @@ def test_full_size_properties(make_engine):
 @pytest.mark.parametrize('staged', [False, True])
 def test_enhanced_path_vs_long_reference_golden(make_engine, golden_dir, staged):
     print(pc.check_enhanced_path_vs_long_golden(make_engine, golden_dir, staged=staged))
+
+
+def test_no_allocation_in_compute_calls(make_engine):
+    print(pc.check_no_allocation_in_compute_calls(make_engine, K=4, M=4, L=20000))

@@ -141,3 +141,7 @@ def test_emu_step2_from_samples_and_from_spectra(make_engine, K, M, L, tuning, f
 @pytest.mark.parametrize('staged', [False, True])
 def test_emu_enhanced_path_vs_long_reference_golden(make_engine, golden_dir, staged):
     print(pc.check_enhanced_path_vs_long_golden(make_engine, golden_dir, staged=staged))
+
+
+def test_emu_no_allocation_in_compute_calls(make_engine):
+    print(pc.check_no_allocation_in_compute_calls(make_engine))
