@@ -60,6 +60,7 @@ def kernel_alg_bytes(M, K, F, H):
         'cov1': M * F * 8 + F * 4,                            # X + mask in (covariances: amortised over T)
         'apply1': M * F * 8 + F * 8,                          # X in, z out
         'cov2': M * F * 8 + F * 4 + (K - 1) * F * 8,          # X + mask + remote z in
+        'room_cov2': M * F * 8 + F * 4 + F * 8,               # X + mask in, z out (all nodes of a room in one workgroup: remote z's stay on chip)
         'apply2': M * F * 8 + (K - 1) * F * 8 + F * 8,        # X + remote z in, yf out
         'step2_cov': M * F * 8 + F * 4,                       # X + mask in (z stays on chip)
         'step2_apply': M * F * 8 + F * 8,                     # X in, yf out

@@ -18,6 +18,7 @@
 #include "k_solve.h"
 #include "k_metrics.h"
 #include "k_online.h"
+#include "k_room.h"
 #include "k_stft.h"
 #include "k_vad.h"
 
@@ -643,6 +644,62 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
     return check_launch(ctx, "k_cov");
 }
 
+// Wide shapes (P = M + K - 1 > 8), all nodes of a room on this GPU, mask_for_z = 'local', step-1 partial sums of THIS X with
+// THIS mask still in `scratch`: z of every node AND the step-2 partial sums of every node from ONE pass over X (k_room.h),
+// instead of disco_apply + cov_partials; room_cov_ok says whether the shape and the context's state qualify.
+#define DISCO_FOR_ROOM(X_) X_(8, 8) X_(8, 6) X_(8, 4) X_(8, 2) X_(4, 8) X_(4, 6)
+#ifndef DISCO_ROOM_COV
+#define DISCO_ROOM_COV 1
+#endif
+static bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes;
+    bool shape = false;
+#define X_(M_, K_) if (M == M_ && K == K_) shape = true;
+    DISCO_FOR_ROOM(X_)
+#undef X_
+    const char* env = getenv("DISCO_ROOM_COV");
+    const bool want = env ? atoi(env) != 0 : DISCO_ROOM_COV != 0;
+    if (!want || !shape || M + K - 1 <= 8 || sharded(ctx) || !X || !mask) return false;
+    if (!(ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask)) return false;       // the leading M x M block must be step 1's
+    return (long long)K * ctx->T * ctx->F * M <= 0x7fffffffLL;                               // 32-bit offsets inside a room
+}
+
+static int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
+                             int* chunks_out, disco_stream s) {
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes, P = M + K - 1;
+    if (!w_loc || !z || !room_cov_ok(ctx, X, mask)) return fail(ctx, DISCO_E_ARG, "room covariance: shape / state does not qualify");
+    const int chunks = cov_chunks(ctx);
+    const long long G = (long long)c.rooms * K;
+    const int NP = P * (P + 1) / 2;
+    int rc = ensure_scratch2(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
+    if (rc) return rc;
+    RoomArgs a;
+    a.X = (const c32*)X;
+    a.mask = mask;
+    a.w = (const c32*)w_loc;
+    a.z = (c32*)z;
+    a.part = (float4*)ctx->scratch2;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    a.chunks = chunks;
+    a.tiles = (ctx->F + 31) / 32;
+    a.R = c.rooms;
+    const long long nblk = (long long)c.rooms * a.tiles * chunks;
+    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
+#define X_(M_, K_)                                                                                                       \
+    if (M == M_ && K == K_)                                                                                              \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);
+    DISCO_FOR_ROOM(X_)
+#undef X_
+    *chunks_out = chunks;
+    ctx->pending_chunks = chunks;
+    ctx->pending_P = P;
+    ctx->pending_skiploc = 1;
+    return check_launch(ctx, "k_room_cov");
+}
+
 extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs,
                                 const disco_c32* Zn, int mask_remote, int P, disco_c32* Rss, disco_c32* Rnn,
                                 disco_stream s) {
@@ -777,8 +834,9 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     if (!launched) {
         const int tiles = (ctx->F + 63) / 64;
         int t_chunks = (int)std::min<long long>(std::max<long long>(1, (8192 + G * tiles - 1) / (G * tiles)), std::max(1, ctx->T / 8));
-        while (G * tiles * t_chunks > 0x7fffffffLL && t_chunks > 1) t_chunks >>= 1;
-        const dim3 grid_m((unsigned)(G * tiles * t_chunks));
+        while (G * tiles * t_chunks > 0x7ffffff0LL && t_chunks > 1) t_chunks >>= 1;
+        const long long items_m = G * tiles * t_chunks;
+        const dim3 grid_m((unsigned)((items_m + DISCO_APPLY_XCD - 1) / DISCO_APPLY_XCD * DISCO_APPLY_XCD));      // ids are dealt over the XCDs
         switch (M) {
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \
@@ -1247,7 +1305,8 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
         rc = STAGE(ctx, s, "step2_apply_istft", disco_step2_apply_istft_fused(ctx, X, w, w, out, s));
         if (rc != DISCO_E_UNSUPPORTED) return rc;
     }
-    if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w, M, 1, z, s)))) return rc;
+    const bool room = c.nodes > 1 && mask_w == mask_z && room_cov_ok(ctx, X, mask_w);       // wide shapes: z + step-2 statistics in one pass
+    if (!room && (rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w, M, 1, z, s)))) return rc;
     if (c.nodes == 1 && mask_w == mask_z) {
         // single node, same mask: step 2 would rebuild the very same statistics from the very same inputs
         // (P = M, nothing to append), so w_glo == w_loc and yf == z_y bit for bit (config C2).
@@ -1256,7 +1315,9 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     }
     // exchange + step 2 (tango.py:378-450), mask_for_z = 'local'
     int chunks2 = 1;              // partial sums stay pending; the local M x M block is step 1's when the mask is the same
-    if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, z, z, 1, P2, &chunks2, s, mask_w == mask_z)))) return rc;
+    if (room) {
+        if ((rc = STAGE(ctx, s, "room_cov2", room_cov_partials(ctx, X, mask_w, w, z, &chunks2, s)))) return rc;
+    } else if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, z, z, 1, P2, &chunks2, s, mask_w == mask_z)))) return rc;
     if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w, nullptr, s)))) return rc;
     if ((rc = STAGE(ctx, s, "apply2", disco_apply(ctx, X, z, w, P2, 1, yo, s)))) return rc;
     return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
@@ -1726,20 +1787,25 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     int chunks = 1;
     if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
     if ((rc = STAGE(ctx, s, "solve1", disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s)))) return rc;
-    if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
     for (int it = 0; it < iters; ++it) {
+        // compression with the current w_loc (step 1's, then the local part of the previous iteration's filter) and the step-2
+        // statistics: ONE pass over X for every node of a room where the shape allows it (k_room_cov), else the filter pass
+        // followed by the covariance pass that reads X again and the K - 1 remote z's
         int chunks2 = 1;
-        if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &chunks2, s,
-                                                     mask_w == mask_z && c.nodes > 1)))) return rc;
+        if (mask_w == mask_z && room_cov_ok(ctx, X, mask_w)) {
+            if ((rc = STAGE(ctx, s, "room_cov2", room_cov_partials(ctx, X, mask_w, w_loc, z, &chunks2, s)))) return rc;
+        } else {
+            if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
+            if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2,
+                                                         &chunks2, s, mask_w == mask_z && c.nodes > 1)))) return rc;
+        }
         if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s)))) return rc;
         if (it + 1 < iters) {
+            // yf of this iteration is not needed; the next one re-compresses with the local part of this iteration's filter
             const long long nb = (long long)G * ctx->F;
             hipLaunchKernelGGL(k_filter_head, dim3((unsigned)std::min<long long>((nb * M + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)s,
                                (const c32*)w_glo, (c32*)w_loc, nb, M, P2);
             if ((rc = check_launch(ctx, "k_filter_head"))) return rc;
-            // yf of this iteration is not needed; the next one needs the re-compressed z (computed from the OLD z's filter
-            // only through w_glo's local part, so z can be overwritten in place)
-            if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
         }
     }
     if ((rc = STAGE(ctx, s, "apply2", disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s)))) return rc;

@@ -863,3 +863,49 @@ def check_no_allocation_in_compute_calls(make_engine, K=3, M=2, L=6000, n_fft=51
     eng.set_tuning(0, 0, 0, 0)
     assert np.array_equal(out_lazy, eng.tango_enhance(y, m)[0].numpy())
     return own
+
+
+def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tuning=None, tol=1e-4):
+    """k_room_cov (csrc/k_room.h: z of every node + the step-2 statistics of every node of a room from ONE pass over X, wide
+    shapes P = M + K - 1 > 8) against (a) the route it replaces -- disco_apply + the split covariance kernels, selected with
+    DISCO_ROOM_COV=0 -- on the same context, and (b) the float64 oracle; both whole-path entry points."""
+    import os
+    from disco_amd import synth
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    if tuning is not None:
+        eng.set_tuning(*tuning)
+    m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F)
+    saved = os.environ.get('DISCO_ROOM_COV')
+    res = {}
+    try:
+        for mode in ('1', '0'):
+            os.environ['DISCO_ROOM_COV'] = mode
+            eng.stage_timing(True)
+            out_i, yf_i = eng.tango_enhance_iterated(y, m, iters=iters)
+            stages = set(eng.stage_report())
+            eng.stage_timing(False)
+            assert ('room_cov2' in stages) == (mode == '1'), (mode, stages)
+            out_e, z_e, yf_e = eng.tango_enhance(y, m)
+            res[mode] = (out_i.numpy(), yf_i.numpy(), out_e.numpy(), z_e.numpy(), yf_e.numpy())
+    finally:
+        if saved is None:
+            del os.environ['DISCO_ROOM_COV']
+        else:
+            os.environ['DISCO_ROOM_COV'] = saved
+    errs = {}
+    for name, a, b in zip(('out_iter', 'yf_iter', 'out', 'z_y', 'yf'), res['1'], res['0']):
+        errs[name + '_vs_staged'] = max(relerr(a[r, k], b[r, k]) for r in range(R) for k in range(K))
+    assert max(errs.values()) < 2e-5, errs
+    for r in range(R):
+        for it_, (o_idx, yf_idx) in ((iters, (0, 1)), (1, (2, 4))):
+            o = to.offline_tango_vec(y[r], s[r], n[r], vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh',
+                                     extra_iters=it_ - 1)
+            for k in range(K):
+                errs['yf_oracle'] = max(errs.get('yf_oracle', 0.0), relerr(res['1'][yf_idx][r, k].T, o['yf'][k]))
+                ref = so.istft(o['yf'][k], L, n_fft, n_fft // 2, work_dtype=np.float64)
+                errs['out_oracle'] = max(errs.get('out_oracle', 0.0), relerr(res['1'][o_idx][r, k], ref))
+                if it_ == 1:
+                    errs['z_oracle'] = max(errs.get('z_oracle', 0.0), relerr(res['1'][3][r, k].T, o['z_y'][k]))
+    assert errs['yf_oracle'] < tol and errs['out_oracle'] < tol and errs['z_oracle'] < tol, errs
+    return errs
