@@ -24,8 +24,28 @@ def build_hip(force=False, verbose=True):
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-shared', '-fPIC', '-o', OUT, SRC]
     if verbose:
         print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    # the resource-usage remarks go to stderr: k_room_cov_dma counts its vector-memory queue by hand (csrc/k_room.h) and a
+    # compiler spill inside its loop would shift that count -- a build whose LDS-DMA kernels use scratch is refused
+    p = subprocess.run(cmd + ['-Rpass-analysis=kernel-resource-usage'], stderr=subprocess.PIPE, text=True)
+    spilled = scratch_users(p.stderr, 'k_room_cov_dma')
+    if p.returncode != 0 or spilled:
+        sys.stderr.write(p.stderr[-8000:] if p.returncode != 0 else '')
+        if os.path.exists(OUT) and spilled:
+            os.remove(OUT)
+        raise RuntimeError(f'hipcc failed ({p.returncode})' if p.returncode != 0 else f'kernels that must not spill use scratch: {spilled}')
     return OUT
+
+
+def scratch_users(remarks, name_part):
+    """Names of kernels containing `name_part` whose 'ScratchSize [bytes/lane]' remark is not 0."""
+    bad, cur = [], None
+    for line in remarks.splitlines():
+        if 'Function Name:' in line:
+            cur = line.split('Function Name:')[1].split('[')[0].strip()
+        elif 'ScratchSize [bytes/lane]:' in line and cur and name_part in cur:
+            if int(line.split('ScratchSize [bytes/lane]:')[1].split('[')[0].strip()) != 0:
+                bad.append(cur)
+    return bad
 
 
 if __name__ == '__main__':

@@ -651,6 +651,9 @@ static int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, c
 #ifndef DISCO_ROOM_COV
 #define DISCO_ROOM_COV 1
 #endif
+#ifndef DISCO_ROOM_DMA
+#define DISCO_ROOM_DMA 1
+#endif
 static bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes;
@@ -688,9 +691,16 @@ static int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* ma
     a.R = c.rooms;
     const long long nblk = (long long)c.rooms * a.tiles * chunks;
     if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
+    // frames through an LDS-DMA ring three ahead (default), or staged through registers one ahead (DISCO_ROOM_DMA=0; k_room.h)
+    const char* env_dma = getenv("DISCO_ROOM_DMA");
+    const bool dma = env_dma ? atoi(env_dma) != 0 : DISCO_ROOM_DMA != 0;
 #define X_(M_, K_)                                                                                                       \
-    if (M == M_ && K == K_)                                                                                              \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);
+    if (M == M_ && K == K_) {                                                                                            \
+        if (dma)                                                                                                         \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a); \
+        else                                                                                                             \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);     \
+    }
     DISCO_FOR_ROOM(X_)
 #undef X_
     *chunks_out = chunks;

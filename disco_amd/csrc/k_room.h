@@ -233,4 +233,270 @@ __global__ __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM_WPE) void k_room_c
     else room_cov_run<M, K, false>(a, sh);
 }
 
+// ---- the same pass with the frames fetched by LDS-DMA ---------------------------------------------------------------------------
+// k_room_cov keeps ONE frame of the tile in flight per workgroup (registers: 112 of a lane's 168 are accumulators, a second
+// frame does not fit) and there is one workgroup per CU: 4.4 MB in flight over the chip, the pass is latency-bound (8.6 ms per C5
+// launch, an iteration lasts as long as a fetch).  Here the spectra and masks go from HBM straight into an LDS ring of
+// DISCO_ROOM_DEPTH frames (global_load_lds_dwordx4 / _dword: no registers), issued THREE frames ahead:
+//   iteration t:  issue frame t + 3  ->  fold frame t  ->  wait until only that issue is outstanding (frame t + 2 has landed)
+//                 ->  form z(t + 1) from the ring (own granule + taps, cross-lane sum), publish it  ->  barrier.
+// An LDS-DMA wave-load writes 64 lanes x 16 B to consecutive LDS bytes, so a lane's LDS position is fixed and the granule it
+// FETCHES is chosen instead: position (bin, lp') holds granule lp = lp' ^ swz(bin) -- an XOR swizzle that keeps the 16-byte
+// reads of the covariance lanes (same granule, 16 consecutive bins) on distinct banks without padding.
+// The waits are counted by hand (the instructions are inline asm: hipcc's own LDS-DMA tracking would wait for vmcnt(0) before every
+// LDS read, the ring index being a run-time value): after the wait of iteration t at most the loads of frame t + 3 are
+// outstanding; VMEM operations return in order, the z stores of the previous iteration are older than that issue.  The kernel
+// must not spill (a scratch access in the loop would shift the count): build.py checks the resource usage.
+#ifndef DISCO_ROOM_DEPTH
+#define DISCO_ROOM_DEPTH 4
+#endif
+
+// x + the value of lane (lane ^ 1) / (lane ^ 2) of the same quad: DPP quad_perm moves ride the VALU (a few cycles; the
+// ds_bpermute form of __shfl_xor is an LDS-crossbar round trip of ~100 cycles in the middle of a dependent chain)
+template <int XOR>
+__device__ __forceinline__ float quad_xor_add(float x) {
+#if defined(__clang__)
+    constexpr int ctrl = XOR == 1 ? 0xB1 : 0x4E;       // quad_perm [1,0,3,2] / [2,3,0,1]
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false);
+    return x + __int_as_float(y);
+#else
+    return x + __shfl_xor(x, XOR);
+#endif
+}
+
+template <int M, int K>
+struct alignas(16) RoomRing {
+    using Gm = RoomGeom<M, K>;
+    float4 xs[DISCO_ROOM_DEPTH][Gm::NITEMS];           // granules, linear in the loader's item index
+    float ms[DISCO_ROOM_DEPTH][K * Gm::NB];
+    c32 zs[2][K][Gm::NB];
+    c32 wt[K][Gm::NB][M];
+};
+
+// 64 lanes x 16 (4) bytes, each lane from its own address gsrc, to the LDS bytes [lds_wave, lds_wave + 1024 (256)) in lane order;
+// lds_wave is wave-uniform.  M0 (the LDS-DMA destination base) is compiler-reserved: saved, written and restored inside the one
+// statement that reads it.  hipcc neither counts these loads nor waits for them (vm_wait below does).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave, int lane) {
+#if defined(__clang__)
+    (void)lane;
+    const unsigned l = (unsigned)(unsigned long long)lds_wave;            // low half of a flat LDS address = the LDS byte address
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(l)
+                 : "memory");
+#else
+    reinterpret_cast<float4*>(lds_wave)[lane] = *reinterpret_cast<const float4*>(gsrc);
+#endif
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_wave, int lane) {
+#if defined(__clang__)
+    (void)lane;
+    const unsigned l = (unsigned)(unsigned long long)lds_wave;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(l)
+                 : "memory");
+#else
+    reinterpret_cast<float*>(lds_wave)[lane] = *reinterpret_cast<const float*>(gsrc);
+#endif
+}
+// at most N vector-memory operations of this wave still outstanding (N <= 3 here)
+__device__ __forceinline__ void vm_wait(int n) {
+#if defined(__clang__)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    }
+#else
+    (void)n;
+#endif
+}
+
+template <int M, int K, bool IS_A>
+__device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, K>& sh) {
+    using Gm = RoomGeom<M, K>;
+    constexpr int KR = Gm::KR, P = Gm::P, NP = Gm::NP, NB = Gm::NB, NA = Gm::NA, WA = Gm::WA, NT = Gm::NT, MH = Gm::MH;
+    constexpr int NITEMS = Gm::NITEMS, NL = Gm::NL, D = DISCO_ROOM_DEPTH;
+    constexpr int BPR = 16 / MH;                       // bins per 256-byte bank row of granules
+    static_assert(D >= 4 && NL + 1 <= 3, "three frames ahead; vm_wait knows 0..3");
+    const int T = a.T, F = a.F;
+    long long item = blockIdx.x;
+    const int c = (int)(item % a.chunks);
+    item /= a.chunks;
+    const int tile = (int)(item % a.tiles);
+    const long long room = item / a.tiles;
+    const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
+    const int f0 = tile * NB;
+    const int tid = threadIdx.x, wid = wave_id(), lane = tid & 63;
+    const int bin = lane & (NB - 1), half = lane >> 5;
+    const bool live = f0 + bin < F;
+
+    const c32* Xr = a.X + (room * K * T) * (long long)F * M;
+    c32* Zr = a.z + (room * K * T) * (long long)F;
+    const float* Mr = a.mask + (room * K * T) * (long long)F;
+    // loader lane: LDS position it = tid + r * NT  <->  node lk, bin lbin, granule lp = lp' ^ swz(lbin); bins beyond F - 1 fetch (and
+    // later re-write) bin F - 1: every load and store is issued by every lane, the counts the waits rely on are exact
+    unsigned lxo[NL];
+    bool lact[NL];
+    int nload = 0;
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const int it = tid + r * NT;
+        lact[r] = wid * 64 + r * NT < NITEMS;          // whole waves: a scalar condition
+        nload += lact[r] ? 1 : 0;
+        const int it_ = lact[r] ? it : 0;
+        const int lk = it_ / (NB * MH), rem = it_ % (NB * MH), lbin = rem / MH, lp = (rem % MH) ^ ((lbin / BPR) % MH);
+        const int lf = min(f0 + lbin, F - 1);
+        lxo[r] = (unsigned)((((lk * T) * F + lf) * M + 2 * lp) * 8);           // bytes; + t * F * M * 8
+        if (lact[r]) {
+            const float4 wq = *reinterpret_cast<const float4*>(a.w + ((room * K + lk) * F + lf) * (long long)M + 2 * lp);
+            *reinterpret_cast<float4*>(&sh.wt[0][0][0] + (lk * NB + lbin) * M + 2 * lp) = wq;
+        }
+    }
+    const bool mact = wid * 64 < K * NB;               // whole waves
+    nload += mact ? 1 : 0;
+    const unsigned mo = (unsigned)((((mact ? tid / NB : 0) * T) * F + min(f0 + tid % NB, F - 1)) * 4);
+
+    auto issue = [&](int t, int slot_) {
+        t = t < t1 ? t : t1 - 1;
+#pragma unroll
+        for (int r = 0; r < NL; ++r)
+            if (lact[r])
+                lds_dma16(reinterpret_cast<const char*>(Xr) + (lxo[r] + (unsigned)t * (unsigned)(F * M * 8)), &sh.xs[slot_][wid * 64 + r * NT], lane);
+        if (mact) lds_dma4(reinterpret_cast<const char*>(Mr) + (mo + (unsigned)t * (unsigned)(F * 4)), &sh.ms[slot_][wid * 64], lane);
+    };
+    // z(t) = w^H x of every (node, bin) of the tile from ring slot `slot_`: a lane's own granule and taps, then the MH lanes of the bin
+    c32 zreg[NL];                                       // z of the frame just formed, on its way to HBM (stored after the counted wait)
+    auto form_z = [&](int t, int slot_) {
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            if (lact[r]) {
+                int it = tid + r * NT;
+                DISCO_CONSUME(it);                      // re-derived every frame: hoisted, the addresses below would cost six registers
+                const float4 q = sh.xs[slot_][it];
+                const int nb_ = it / MH, lbin = nb_ & (NB - 1), lp = (it % MH) ^ ((lbin / BPR) % MH);
+                const float4 wq = *reinterpret_cast<const float4*>(&sh.wt[0][0][0] + nb_ * M + 2 * lp);
+                c32 p = cfma_conj(make_float2(wq.x, wq.y), make_float2(q.x, q.y), make_float2(0.f, 0.f));
+                p = cfma_conj(make_float2(wq.z, wq.w), make_float2(q.z, q.w), p);
+                static_assert(MH == 2 || MH == 4, "the lanes of a bin are (part of) a quad");
+                p.x = quad_xor_add<1>(p.x);
+                p.y = quad_xor_add<1>(p.y);
+                if constexpr (MH == 4) {
+                    p.x = quad_xor_add<2>(p.x);
+                    p.y = quad_xor_add<2>(p.y);
+                }
+                if (it % MH == 0) (&sh.zs[t & 1][0][0])[nb_] = p;
+                zreg[r] = p;
+            }
+        }
+    };
+    auto store_z = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            if (lact[r]) {
+                int it = tid + r * NT;
+                DISCO_CONSUME(it);
+                const int nb_ = it / MH, lbin = nb_ & (NB - 1);
+                if (it % MH == 0) Zr[((nb_ / NB) * T + t) * F + min(f0 + lbin, F - 1)] = zreg[r];      // bins beyond F - 1 repeat bin F - 1's value
+            }
+        }
+    };
+
+    // ---- the lane's slot
+    constexpr bool is_a = IS_A;
+    const int slot = (is_a ? wid : wid - WA) * 2 + half;
+    const int k = is_a ? slot / NA : slot;
+    const int h = is_a ? slot % NA : 0;
+    const int swz = (bin / BPR) % MH;
+    constexpr int NACC = IS_A ? 4 * KR : KR * (KR + 1) / 2;
+    c32 acc_s[NACC], acc_n[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
+
+    auto fold = [&](int t, int slot_) {
+        const float mkv = sh.ms[slot_][k * NB + bin];
+        const float m = live ? mkv : 0.f, mc = live ? 1.f - mkv : 0.f;
+        const float wa = m * m, wb = mc * mc;
+        const c32(*zs)[NB] = sh.zs[t & 1];
+        if constexpr (is_a) {
+            c32 x[4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float4 q = sh.xs[slot_][(k * NB + bin) * MH + ((2 * h + p) ^ swz)];
+                x[2 * p] = make_float2(q.x, q.y);
+                x[2 * p + 1] = make_float2(q.z, q.w);
+            }
+            c32 z[KR];                                                    // all remote rows requested up front: one LDS latency per frame, not K - 1
+#pragma unroll
+            for (int jj = 0; jj < KR; ++jj) z[jj] = zs[jj < k ? jj : jj + 1][bin];        // concatenate_signals order
+#pragma unroll
+            for (int jj = 0; jj < KR; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cov_pair_acc(x[i], z[jj], wa, wb, acc_s[i * KR + jj], acc_n[i * KR + jj]);
+        } else {
+            c32 z[KR];
+#pragma unroll
+            for (int jj = 0; jj < KR; ++jj) z[jj] = zs[jj < k ? jj : jj + 1][bin];
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < KR; ++i)
+#pragma unroll
+                for (int j = i; j < KR; ++j, ++q) {
+                    if (j == i) cov_diag_acc(z[i], wa, wb, acc_s[q], acc_n[q]);
+                    else cov_pair_acc(z[i], z[j], wa, wb, acc_s[q], acc_n[q]);
+                }
+        }
+    };
+
+    issue(t0, 0);
+    issue(t0 + 1, 1);
+    issue(t0 + 2, 2);
+    vm_wait(nload);                                     // frames t0 and t0 + 1 have landed (this wave's part)
+    __syncthreads();                                    // ... and everybody else's; the taps are in place
+    form_z(t0, 0);
+    store_z(t0);
+    __syncthreads();
+    int s0 = 0;                                         // ring slot of frame t
+    for (int t = t0; t < t1; ++t) {
+        issue(t + 3, (s0 + 3) % D);                     // the slot frame t - 1 was folded from (D = 4)
+        if (t + 1 < t1) form_z(t + 1, (s0 + 1) % D);    // frame t + 1 landed (and was published) an iteration ago; into the OTHER z buffer
+        fold(t, s0);
+        vm_wait(nload);                                 // only the issue above may still be in flight: frame t + 2 is in LDS
+        if (t + 1 < t1) store_z(t + 1);                 // after the counted wait: the stores never stand between an issue and its wait
+        __syncthreads();
+        s0 = (s0 + 1) % D;
+    }
+    vm_wait(0);                                         // no LDS-DMA may outlive the workgroup's LDS allocation
+    if (live) {
+        float4* o = a.part + ((((room * K + k) * a.chunks + c) * F) + f0 + bin) * (long long)NP;
+        if constexpr (is_a) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < KR; ++jj) {
+                    const int q = i * KR + jj;
+                    o[tri_index<P>(4 * h + i, M + jj)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+                }
+        } else {
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < KR; ++i)
+#pragma unroll
+                for (int j = i; j < KR; ++j, ++q)
+                    o[tri_index<P>(M + i, M + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+        }
+    }
+}
+
+template <int M, int K>
+__global__ __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM_WPE) void k_room_cov_dma(RoomArgs a) {
+    __shared__ RoomRing<M, K> sh;
+    if (wave_id() < RoomGeom<M, K>::WA) room_cov_dma_run<M, K, true>(a, sh);
+    else room_cov_dma_run<M, K, false>(a, sh);
+}
+
 }  // namespace disco

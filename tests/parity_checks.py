@@ -876,26 +876,30 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
     if tuning is not None:
         eng.set_tuning(*tuning)
     m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F)
-    saved = os.environ.get('DISCO_ROOM_COV')
+    saved = {v: os.environ.get(v) for v in ('DISCO_ROOM_COV', 'DISCO_ROOM_DMA')}
     res = {}
     try:
-        for mode in ('1', '0'):
-            os.environ['DISCO_ROOM_COV'] = mode
+        # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route
+        for mode, cov, dma in (('1', '1', '1'), ('reg', '1', '0'), ('0', '0', '1')):
+            os.environ['DISCO_ROOM_COV'] = cov
+            os.environ['DISCO_ROOM_DMA'] = dma
             eng.stage_timing(True)
             out_i, yf_i = eng.tango_enhance_iterated(y, m, iters=iters)
             stages = set(eng.stage_report())
             eng.stage_timing(False)
-            assert ('room_cov2' in stages) == (mode == '1'), (mode, stages)
+            assert ('room_cov2' in stages) == (cov == '1'), (mode, stages)
             out_e, z_e, yf_e = eng.tango_enhance(y, m)
             res[mode] = (out_i.numpy(), yf_i.numpy(), out_e.numpy(), z_e.numpy(), yf_e.numpy())
     finally:
-        if saved is None:
-            del os.environ['DISCO_ROOM_COV']
-        else:
-            os.environ['DISCO_ROOM_COV'] = saved
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
     errs = {}
-    for name, a, b in zip(('out_iter', 'yf_iter', 'out', 'z_y', 'yf'), res['1'], res['0']):
+    for name, a, b, c_ in zip(('out_iter', 'yf_iter', 'out', 'z_y', 'yf'), res['1'], res['0'], res['reg']):
         errs[name + '_vs_staged'] = max(relerr(a[r, k], b[r, k]) for r in range(R) for k in range(K))
+        errs[name + '_reg_vs_staged'] = max(relerr(c_[r, k], b[r, k]) for r in range(R) for k in range(K))
     assert max(errs.values()) < 2e-5, errs
     for r in range(R):
         for it_, (o_idx, yf_idx) in ((iters, (0, 1)), (1, (2, 4))):
