@@ -273,33 +273,35 @@ struct alignas(16) RoomRing {
     c32 wt[K][Gm::NB][M];
 };
 
-// 64 lanes x 16 (4) bytes, each lane from its own address gsrc, to the LDS bytes [lds_wave, lds_wave + 1024 (256)) in lane order;
-// lds_wave is wave-uniform.  M0 (the LDS-DMA destination base) is compiler-reserved: saved, written and restored inside the one
-// statement that reads it.  hipcc neither counts these loads nor waits for them (vm_wait below does).
-__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave, int lane) {
+// 64 lanes x 16 (4) bytes, lane i from gbase + off[i] (gbase wave-uniform: an SGPR pair, off a 32-bit byte offset: no per-lane
+// 64-bit address arithmetic), to the LDS bytes [lds_wave, lds_wave + 1024 (256)) in lane order; lds_wave is wave-uniform.
+// M0 (the LDS-DMA destination base) is compiler-reserved: saved, written and restored inside the one statement that reads it;
+// the nops cover "SALU writes an SGPR -> VMEM reads it as base" (5 wait states) for a base the compiler has just formed.
+// hipcc neither counts these loads nor waits for them (vm_wait below does).
+__device__ __forceinline__ void lds_dma16(const void* gbase, unsigned off, void* lds_wave, int lane) {
 #if defined(__clang__)
     (void)lane;
     const unsigned l = (unsigned)(unsigned long long)lds_wave;            // low half of a flat LDS address = the LDS byte address
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(l)
+                 : "v"(off), "s"(gbase), "s"(l)
                  : "memory");
 #else
-    reinterpret_cast<float4*>(lds_wave)[lane] = *reinterpret_cast<const float4*>(gsrc);
+    reinterpret_cast<float4*>(lds_wave)[lane] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gbase) + off);
 #endif
 }
-__device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_wave, int lane) {
+__device__ __forceinline__ void lds_dma4(const void* gbase, unsigned off, void* lds_wave, int lane) {
 #if defined(__clang__)
     (void)lane;
     const unsigned l = (unsigned)(unsigned long long)lds_wave;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(l)
+                 : "v"(off), "s"(gbase), "s"(l)
                  : "memory");
 #else
-    reinterpret_cast<float*>(lds_wave)[lane] = *reinterpret_cast<const float*>(gsrc);
+    reinterpret_cast<float*>(lds_wave)[lane] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gbase) + off);
 #endif
 }
 // at most N vector-memory operations of this wave still outstanding (N <= 3 here)
@@ -341,6 +343,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
     // loader lane: LDS position it = tid + r * NT  <->  node lk, bin lbin, granule lp = lp' ^ swz(lbin); bins beyond F - 1 fetch (and
     // later re-write) bin F - 1: every load and store is issued by every lane, the counts the waits rely on are exact
     unsigned lxo[NL];
+    int lwt[NL], lzs[NL], lzo[NL];                      // taps in wt (c32 units), z slot in zs (-1: not this lane's), z offset in the room's z block
     bool lact[NL];
     int nload = 0;
 #pragma unroll
@@ -352,6 +355,9 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         const int lk = it_ / (NB * MH), rem = it_ % (NB * MH), lbin = rem / MH, lp = (rem % MH) ^ ((lbin / BPR) % MH);
         const int lf = min(f0 + lbin, F - 1);
         lxo[r] = (unsigned)((((lk * T) * F + lf) * M + 2 * lp) * 8);           // bytes; + t * F * M * 8
+        lwt[r] = (lk * NB + lbin) * M + 2 * lp;
+        lzs[r] = (rem % MH == 0) ? lk * NB + lbin : -1;
+        lzo[r] = (lk * T) * F + lf;                                              // + t * F; bins beyond F - 1 repeat bin F - 1's value
         if (lact[r]) {
             const float4 wq = *reinterpret_cast<const float4*>(a.w + ((room * K + lk) * F + lf) * (long long)M + 2 * lp);
             *reinterpret_cast<float4*>(&sh.wt[0][0][0] + (lk * NB + lbin) * M + 2 * lp) = wq;
@@ -365,9 +371,8 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         t = t < t1 ? t : t1 - 1;
 #pragma unroll
         for (int r = 0; r < NL; ++r)
-            if (lact[r])
-                lds_dma16(reinterpret_cast<const char*>(Xr) + (lxo[r] + (unsigned)t * (unsigned)(F * M * 8)), &sh.xs[slot_][wid * 64 + r * NT], lane);
-        if (mact) lds_dma4(reinterpret_cast<const char*>(Mr) + (mo + (unsigned)t * (unsigned)(F * 4)), &sh.ms[slot_][wid * 64], lane);
+            if (lact[r]) lds_dma16(Xr + (long long)t * F * M, lxo[r], &sh.xs[slot_][wid * 64 + r * NT], lane);       // the frame's base is scalar
+        if (mact) lds_dma4(Mr + (long long)t * F, mo, &sh.ms[slot_][wid * 64], lane);
     };
     // z(t) = w^H x of every (node, bin) of the tile from ring slot `slot_`: a lane's own granule and taps, then the MH lanes of the bin
     c32 zreg[NL];                                       // z of the frame just formed, on its way to HBM (stored after the counted wait)
@@ -375,11 +380,8 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
 #pragma unroll
         for (int r = 0; r < NL; ++r) {
             if (lact[r]) {
-                int it = tid + r * NT;
-                DISCO_CONSUME(it);                      // re-derived every frame: hoisted, the addresses below would cost six registers
-                const float4 q = sh.xs[slot_][it];
-                const int nb_ = it / MH, lbin = nb_ & (NB - 1), lp = (it % MH) ^ ((lbin / BPR) % MH);
-                const float4 wq = *reinterpret_cast<const float4*>(&sh.wt[0][0][0] + nb_ * M + 2 * lp);
+                const float4 q = sh.xs[slot_][tid + r * NT];
+                const float4 wq = *reinterpret_cast<const float4*>(&sh.wt[0][0][0] + lwt[r]);
                 c32 p = cfma_conj(make_float2(wq.x, wq.y), make_float2(q.x, q.y), make_float2(0.f, 0.f));
                 p = cfma_conj(make_float2(wq.z, wq.w), make_float2(q.z, q.w), p);
                 static_assert(MH == 2 || MH == 4, "the lanes of a bin are (part of) a quad");
@@ -389,28 +391,34 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
                     p.x = quad_xor_add<2>(p.x);
                     p.y = quad_xor_add<2>(p.y);
                 }
-                if (it % MH == 0) (&sh.zs[t & 1][0][0])[nb_] = p;
+                if (lzs[r] >= 0) (&sh.zs[t & 1][0][0])[lzs[r]] = p;
                 zreg[r] = p;
             }
         }
     };
     auto store_z = [&](int t) {
 #pragma unroll
-        for (int r = 0; r < NL; ++r) {
-            if (lact[r]) {
-                int it = tid + r * NT;
-                DISCO_CONSUME(it);
-                const int nb_ = it / MH, lbin = nb_ & (NB - 1);
-                if (it % MH == 0) Zr[((nb_ / NB) * T + t) * F + min(f0 + lbin, F - 1)] = zreg[r];      // bins beyond F - 1 repeat bin F - 1's value
-            }
-        }
+        for (int r = 0; r < NL; ++r)
+            if (lact[r] && lzs[r] >= 0) Zr[lzo[r] + t * F] = zreg[r];
     };
 
     // ---- the lane's slot
+    // slot = 2 * (wave within its role) + half.  A: k = slot / NA, h = slot % NA; B: k = slot.  kw = the wave's first node (a
+    // SCALAR), dk = k - kw in {0, 1} (always 0 when the two halves of a wave share a node, NA even): the remote row jj of a lane
+    // is node jj + (jj >= kw + dk), which differs between the halves only for jj == kw -- every other LDS offset of a remote
+    // row is a scalar instead of a per-lane select.
     constexpr bool is_a = IS_A;
-    const int slot = (is_a ? wid : wid - WA) * 2 + half;
-    const int k = is_a ? slot / NA : slot;
-    const int h = is_a ? slot % NA : 0;
+    constexpr bool two_nodes = !IS_A || (NA % 2 != 0);
+    const int wr = is_a ? wid : wid - WA;
+    const int kw = is_a ? (2 * wr) / NA : 2 * wr;
+    const int dk = two_nodes ? half : 0;
+    const int k = kw + dk;
+    const int h = is_a ? ((2 * wr) % NA + (two_nodes ? 0 : half)) : 0;
+    auto remote = [&](int jj) {                          // concatenate_signals order: jj -> node jj (jj < k), jj + 1 (jj >= k)
+        int j = jj + (jj > kw ? 1 : 0);
+        if (jj == kw) j += two_nodes ? (dk == 0 ? 1 : 0) : 1;
+        return j;
+    };
     const int swz = (bin / BPR) % MH;
     constexpr int NACC = IS_A ? 4 * KR : KR * (KR + 1) / 2;
     c32 acc_s[NACC], acc_n[NACC];
@@ -432,7 +440,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
             }
             c32 z[KR];                                                    // all remote rows requested up front: one LDS latency per frame, not K - 1
 #pragma unroll
-            for (int jj = 0; jj < KR; ++jj) z[jj] = zs[jj < k ? jj : jj + 1][bin];        // concatenate_signals order
+            for (int jj = 0; jj < KR; ++jj) z[jj] = zs[remote(jj)][bin];
 #pragma unroll
             for (int jj = 0; jj < KR; ++jj)
 #pragma unroll
@@ -440,7 +448,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         } else {
             c32 z[KR];
 #pragma unroll
-            for (int jj = 0; jj < KR; ++jj) z[jj] = zs[jj < k ? jj : jj + 1][bin];
+            for (int jj = 0; jj < KR; ++jj) z[jj] = zs[remote(jj)][bin];
             int q = 0;
 #pragma unroll
             for (int i = 0; i < KR; ++i)
