@@ -68,6 +68,16 @@ __device__ __forceinline__ c64 zscale(c64 a, double s) { return make_double2(a.x
 #define DISCO_SCHED_FENCE() asm volatile("" ::: "memory")
 #endif
 
+// Placement of the streaming kernels' code.  hipcc aligns a kernel to 256 bytes, so where it falls inside a 4-KiB page depends on
+// every kernel defined before it.  Measured (round 2, pass l): adding the k_room.h kernels moved k_step2_apply_istft<512, 4, 4>
+// from 512 to 3584 bytes into its page and cost it 9-11 % (4.39 -> 4.79 / 4.88 ms per C3 launch on two boxes, sources of the kernel
+// unchanged).  The hot kernels are therefore pinned to page boundaries: their speed no longer depends on unrelated code.
+#if defined(__clang__)
+#define DISCO_KERNEL_ALIGN __attribute__((aligned(4096)))
+#else
+#define DISCO_KERNEL_ALIGN
+#endif
+
 // The wave index as a PROVABLY wave-uniform value: anything derived from threadIdx is divergent to hipcc, which
 // then wraps every access guarded by a per-wave condition in exec-mask branches (one per load).
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

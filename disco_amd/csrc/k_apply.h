@@ -7,7 +7,7 @@
 namespace disco {
 
 template <int M, int KR>
-__global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const c32* __restrict__ Z,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const c32* __restrict__ Z,
                                                 const c32* __restrict__ w, c32* __restrict__ out,
                                                 int K, int T, int F, int conj_w, int blocks_per_node, int Kl, int k0, int zblk,
                                                 long long R) {
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_apply(const c32* __restrict__ X, const 
 #define DISCO_APPLY_XCD 8             // XCDs the workgroup ids of k_apply_m are dealt over
 #endif
 template <int M>
-__global__ __launch_bounds__(64) void k_apply_m(const c32* __restrict__ X, const c32* __restrict__ Z,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64) void k_apply_m(const c32* __restrict__ X, const c32* __restrict__ Z,
                                                  const c32* __restrict__ w, c32* __restrict__ out, int KR,
                                                  int K, int T, int F, int conj_w, int tiles, int t_chunks, int Kl, int k0, int zblk,
                                                  long long R) {

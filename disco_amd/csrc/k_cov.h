@@ -526,7 +526,7 @@ __device__ __forceinline__ void cov_split_roles(const int role, Fn&& fn) {
 
 // grid = R*Kl * (tiles + 1) * chunks blocks of 64 * cov_split_waves() threads; Zs == Zn and mask_remote != 0 are the caller's contract
 template <int M, int KR, bool SKIPLOC>
-__global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_split(CovArgs a) {
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_split(CovArgs a) {
     static_assert(KR > 0 || !SKIPLOC, "nothing to compute");
     const int nbin = a.F - 1, tiles = (nbin + 63) / 64;
     int bid = blockIdx.x;
@@ -679,7 +679,7 @@ __device__ __forceinline__ void cov_split_wave_lds(const CovArgs& a, const long 
 }
 
 template <int M, int KR, bool SKIPLOC>
-__global__ __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>()), DISCO_COV_LDS_WPE) void k_cov_split_lds(CovArgs a) {
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>()), DISCO_COV_LDS_WPE) void k_cov_split_lds(CovArgs a) {
     static_assert(KR > 0 && M % 2 == 0, "remote rows and 16-byte granules of X");
     constexpr int NW = cov_split_waves<KR, SKIPLOC>();
     __shared__ CovStage<M, KR, DISCO_COV_STAGE_FRAMES> sh[2];

@@ -72,7 +72,7 @@ constexpr int S2_U_APPLY = DISCO_S2_U_APPLY;    // frames per barrier in the app
 // M x M block of both step-2 covariances equals the step-1 covariances already sitting in the context as partial sums:
 // those 10 of 28 entry pairs (M = 4, K = 4) are neither accumulated nor written, the solver takes them from step 1.
 template <int M, int K, bool SKIPLOC>
-__global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
     constexpr int P = M + K - 1, NP = P * (P + 1) / 2, U = S2_U_COV;
     __shared__ c32 zbuf[2][U][K][64];
     const int k = wave_id(), lane = threadIdx.x & 63;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * K) void k_step2_cov_fused(Step2Args a) {
 }
 
 template <int M, int K>
-__global__ __launch_bounds__(64 * K) void k_step2_apply_fused(Step2Args a) {
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * K) void k_step2_apply_fused(Step2Args a) {
     constexpr int P = M + K - 1, U = S2_U_APPLY;
     __shared__ c32 zbuf[2][U][K][64];
     const int k = wave_id(), lane = threadIdx.x & 63;
@@ -314,7 +314,7 @@ struct alignas(16) ApplyIstftShared {
 
 // 2 waves per SIMD is what the 68 kB of LDS allow; stated so that the allocator keeps the prefetch within 256 registers
 template <int N, int M, int K>
-__global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_apply_istft(Step2Args a, float* __restrict__ out,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_apply_istft(Step2Args a, float* __restrict__ out,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
                                                                int L, int blocks_per_room, int pairs) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2, EH = E / 2, NJ = EH + 1, P = M + K - 1;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_ap
 // transform of the frame pair and the overlap-add are k_step2_apply_istft's.  SURVEY 8d prices the path this way
 // ("16 M H": every pass over the signals re-transforms the samples); it pays once a transform costs ~140 instructions.
 template <int N, int M, int K>
-__global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_stft_apply_istft(
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_stft_apply_istft(
     const float* __restrict__ y, const c32* __restrict__ w_loc_g, const c32* __restrict__ w_glo_g, float* __restrict__ out,
     const float* __restrict__ win, const c32* __restrict__ tw, int L, int T, int pad_mode, int blocks_per_room, int pairs) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, NJ = EH + 1, P = M + K - 1, CHP = (M + 1) / 2;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_st
 // A wave owns `pairs` frame pairs of one node (2 pairs - 1 hop segments; consecutive waves overlap by one frame, as in
 // k_step2_apply_istft); the half-window shared by consecutive frames is recycled in registers as in k_stft.
 template <int N, int M>
-__global__ __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_istft(const float* __restrict__ x, const c32* __restrict__ wf,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_istft(const float* __restrict__ x, const c32* __restrict__ wf,
                                                                                     float* __restrict__ out, const float* __restrict__ win,
                                                                                     const c32* __restrict__ tw, int L, int T, int pad_mode,
                                                                                     int runs_per_node, int pairs, long long n_witems) {

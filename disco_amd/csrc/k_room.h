@@ -227,7 +227,7 @@ __device__ __forceinline__ void room_cov_run(const RoomArgs& a, RoomStage<M, K>*
 }
 
 template <int M, int K>
-__global__ __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM_WPE) void k_room_cov(RoomArgs a) {
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM_WPE) void k_room_cov(RoomArgs a) {
     __shared__ RoomStage<M, K> sh[2];
     if (wave_id() < RoomGeom<M, K>::WA) room_cov_run<M, K, true>(a, sh);
     else room_cov_run<M, K, false>(a, sh);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
 }
 
 template <int M, int K>
-__global__ __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM_WPE) void k_room_cov_dma(RoomArgs a) {
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM_WPE) void k_room_cov_dma(RoomArgs a) {
     __shared__ RoomRing<M, K> sh;
     if (wave_id() < RoomGeom<M, K>::WA) room_cov_dma_run<M, K, true>(a, sh);
     else room_cov_dma_run<M, K, false>(a, sh);

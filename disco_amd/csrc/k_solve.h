@@ -439,7 +439,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
 }
 
 template <int P, bool FROM_PART>
-__global__ __launch_bounds__(SolveGeom<P>::THREADS, SolveGeom<P>::WPE) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(SolveGeom<P>::THREADS, SolveGeom<P>::WPE) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
                                                                         c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
     __shared__ c64 s_L[PROBS][SolveGeom<P>::LSZ];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]

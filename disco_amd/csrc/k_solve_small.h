@@ -261,7 +261,7 @@ __device__ __forceinline__ void solve_load_tri(const SolveSrc& src, long long pi
 constexpr int SOLVE_SMALL_THREADS = 128;
 
 template <int P, bool FROM_PART>
-__global__ __launch_bounds__(SOLVE_SMALL_THREADS) void k_gevd_mwf_r1_thread(SolveSrc src, long long n_prob, double mu,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(SOLVE_SMALL_THREADS) void k_gevd_mwf_r1_thread(SolveSrc src, long long n_prob, double mu,
                                                                               c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
     const long long pid = (long long)blockIdx.x * SOLVE_SMALL_THREADS + threadIdx.x;

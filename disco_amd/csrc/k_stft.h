@@ -88,7 +88,7 @@ __device__ __forceinline__ void load_frame_slots(c32* v, const float* __restrict
 // requested before the current frame is transformed (the loads fly under the butterflies), the shared
 // half-window is recycled in registers.
 template <int N, int CHP>
-__global__ __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restrict__ x, c32* __restrict__ X,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_stft(const float* __restrict__ x, c32* __restrict__ X,
                                                            const float* __restrict__ win, const c32* __restrict__ tw,
                                                            int chans, int L, int T, int pad_mode, int runs_per_sig,
                                                            long long n_witems) {
@@ -181,7 +181,7 @@ struct alignas(16) StftPairsShared {
 };
 
 template <int N>
-__global__ __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* __restrict__ x, c32* __restrict__ X,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* __restrict__ x, c32* __restrict__ X,
                                                                     const float* __restrict__ win, const c32* __restrict__ tw,
                                                                     int chans, int L, int T, int pad_mode, int runs_per_sig) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, NJ = E / 2 + 1, EH = E / 2;
@@ -257,7 +257,7 @@ __device__ __forceinline__ float tf_mask_value(c32 S, c32 Nn, int mask_type, int
 
 // s_ref, n_ref: [n_sig][L] -> mask [n_sig][T][F]; the pair (s, n) shares one complex FFT.  Streams like k_stft.
 template <int N>
-__global__ __launch_bounds__(64 * STFT_WAVES) void k_mask_oracle(const float* __restrict__ s_ref, const float* __restrict__ n_ref,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_mask_oracle(const float* __restrict__ s_ref, const float* __restrict__ n_ref,
                                                                   float* __restrict__ mask, const float* __restrict__ win,
                                                                   const c32* __restrict__ tw, int L, int T, int pad_mode,
                                                                   int mask_type, int mask_pow, float thr_lin, int runs_per_sig,
@@ -332,7 +332,7 @@ __device__ __forceinline__ float* istft_frame(IstftShared<N>& sh, int j) {
 }
 
 template <int N>
-__global__ __launch_bounds__(64 * STFT_WAVES) void k_istft(const c32* __restrict__ Z, float* __restrict__ out,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_istft(const c32* __restrict__ Z, float* __restrict__ out,
                                                             const float* __restrict__ win, const c32* __restrict__ tw,
                                                             int L, int T, int blocks_per_sig) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2;
@@ -424,7 +424,7 @@ struct alignas(16) StftCovShared {
 // STORE = false: the spectra are reduced into the covariances and dropped (single-node path: the filter pass recomputes them
 // from the samples, k_stft_apply_istft, instead of reading 8 M F bytes per node-frame back)
 template <int N, int M, bool STORE = true>
-__global__ __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WPE : 1) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M <= 4) ? DISCO_SC_WPE : 1) void k_stft_cov(const float* __restrict__ x, const float* __restrict__ mask,
                                                                c32* __restrict__ X, float4* __restrict__ part,
                                                                const float* __restrict__ win, const c32* __restrict__ tw,
                                                                int L, int T, int pad_mode, int chunks, int runw) {
