@@ -69,9 +69,11 @@ __device__ __forceinline__ c64 zscale(c64 a, double s) { return make_double2(a.x
 #endif
 
 // Placement of the streaming kernels' code.  hipcc aligns a kernel to 256 bytes, so where it falls inside a 4-KiB page depends on
-// every kernel defined before it.  Measured (round 2, pass l): adding the k_room.h kernels moved k_step2_apply_istft<512, 4, 4>
-// from 512 to 3584 bytes into its page and cost it 9-11 % (4.39 -> 4.79 / 4.88 ms per C3 launch on two boxes, sources of the kernel
-// unchanged).  The hot kernels are therefore pinned to page boundaries: their speed no longer depends on unrelated code.
+// every kernel defined before it.  Round 2, pass l: after the k_room.h kernels were added, k_step2_apply_istft<512, 4, 4> (sources
+// unchanged, now 3584 instead of 512 bytes into its page) measured 4.79 / 4.88 ms per C3 launch on two boxes against 4.37-4.39 before;
+// pinned to a page boundary it measured 4.45 ms on a third box -- and 4.85 ms on a fourth.  The box-to-box spread of that kernel is
+// therefore as large as the suspected placement effect and the effect itself is NOT established; the hot kernels stay pinned to page
+// boundaries because it costs nothing but padding and takes one variable out of every later comparison.
 #if defined(__clang__)
 #define DISCO_KERNEL_ALIGN __attribute__((aligned(4096)))
 #else

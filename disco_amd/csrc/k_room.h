@@ -235,8 +235,8 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 
 // ---- the same pass with the frames fetched by LDS-DMA ---------------------------------------------------------------------------
 // k_room_cov keeps ONE frame of the tile in flight per workgroup (registers: 112 of a lane's 168 are accumulators, a second
-// frame does not fit) and there is one workgroup per CU: 4.4 MB in flight over the chip, the pass is latency-bound (8.6 ms per C5
-// launch, an iteration lasts as long as a fetch).  Here the spectra and masks go from HBM straight into an LDS ring of
+// frame does not fit) and there is one workgroup per CU: 4.4 MB in flight over the chip (8.6 ms per C5 launch; this variant: 7.1 ms,
+// the two passes it replaces: 11.0 ms).  Here the spectra and masks go from HBM straight into an LDS ring of
 // DISCO_ROOM_DEPTH frames (global_load_lds_dwordx4 / _dword: no registers), issued THREE frames ahead:
 //   iteration t:  issue frame t + 3  ->  fold frame t  ->  wait until only that issue is outstanding (frame t + 2 has landed)
 //                 ->  form z(t + 1) from the ring (own granule + taps, cross-lane sum), publish it  ->  barrier.
