@@ -156,9 +156,9 @@ struct StageScope {
 
 // (tests/hipemu compiles these sources with g++ for logic tests and defines HIPEMU: the string must not claim a GPU there)
 #ifdef HIPEMU
-extern "C" const char* disco_version(void) { return "disco_hip 0.2.0 (hipemu host TEST build, not a product)"; }
+extern "C" const char* disco_version(void) { return "disco_hip 0.3.0 (hipemu host TEST build, not a product)"; }
 #else
-extern "C" const char* disco_version(void) { return "disco_hip 0.2.0 (gfx950)"; }
+extern "C" const char* disco_version(void) { return "disco_hip 0.3.0 (gfx950)"; }
 #endif
 
 extern "C" const char* disco_last_error(const disco_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
@@ -665,7 +665,7 @@ static bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* m
     const bool want = env ? atoi(env) != 0 : DISCO_ROOM_COV != 0;
     if (!want || !shape || M + K - 1 <= 8 || sharded(ctx) || !X || !mask) return false;
     if (!(ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask)) return false;       // the leading M x M block must be step 1's
-    return (long long)K * ctx->T * ctx->F * M <= 0x7fffffffLL;                               // 32-bit offsets inside a room
+    return (long long)K * ctx->T * ctx->F * M <= 0x0fffffffLL;                               // 32-bit BYTE offsets inside a room (8 B per element)
 }
 
 static int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
