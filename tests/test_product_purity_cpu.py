@@ -48,3 +48,20 @@ def test_kernel_sources_have_no_cuda_or_portability_shims():
         txt = open(os.path.join(csrc, f)).read()
         for token in ('__HIP_PLATFORM_AMD__', '__CUDACC__', 'cuda_runtime', 'hipify', '#include <cuda'):
             assert token not in txt, (f, token)
+
+
+def test_build_refuses_spilling_lds_dma_kernels():
+    """disco_amd/build.py: k_room_cov_dma counts its vector-memory queue by hand, so a build in which it uses scratch is refused;
+    the parser of hipcc's resource-usage remarks is what decides."""
+    from disco_amd import build
+    remarks = '''
+k_room.h:504:1: remark: Function Name: _ZN5disco14k_room_cov_dmaILi8ELi8EEEvNS_8RoomArgsE [-Rpass-analysis=kernel-resource-usage]
+k_room.h:504:1: remark:     VGPRs: 164 [-Rpass-analysis=kernel-resource-usage]
+k_room.h:504:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+k_room.h:504:1: remark: Function Name: _ZN5disco14k_room_cov_dmaILi4ELi8EEEvNS_8RoomArgsE [-Rpass-analysis=kernel-resource-usage]
+k_room.h:504:1: remark:     ScratchSize [bytes/lane]: 36 [-Rpass-analysis=kernel-resource-usage]
+k_stft.h:427:1: remark: Function Name: _ZN5disco10k_stft_covILi512ELi4ELb1EEEvPKf [-Rpass-analysis=kernel-resource-usage]
+k_stft.h:427:1: remark:     ScratchSize [bytes/lane]: 20 [-Rpass-analysis=kernel-resource-usage]
+'''
+    assert build.scratch_users(remarks, 'k_room_cov_dma') == ['_ZN5disco14k_room_cov_dmaILi4ELi8EEEvNS_8RoomArgsE']
+    assert build.scratch_users(remarks.replace(' 36 ', ' 0 '), 'k_room_cov_dma') == []
