@@ -232,7 +232,8 @@ def test_no_allocation_in_compute_calls(make_engine):
 
 
 @pytest.mark.parametrize('K,M,n_fft,L,tuning', [(2, 8, 512, 20000, None), (6, 4, 512, 20000, (0, 3, 0, 0)), (4, 8, 1024, 40000, None),
-                                                (8, 8, 512, 30000, (0, 2, 0, 0)), (8, 4, 512, 20000, None), (8, 8, 1024, 40000, None)])
+                                                (8, 8, 512, 30000, (0, 2, 0, 0)), (8, 4, 512, 20000, None), (8, 8, 1024, 40000, None),
+                                                (2, 8, 512, 5120, (0, 20, 0, 0))])
 def test_room_cov(make_engine, K, M, n_fft, L, tuning):
     """k_room_cov (csrc/k_room.h) against the staged route it replaces (DISCO_ROOM_COV=0) and against the float64 oracle."""
     print(pc.check_room_cov(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M > 32 else 2, tuning=tuning))
