@@ -188,8 +188,8 @@ def parity_sample(samples, n_fft, iters, tol=1e-4):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='C3', choices=sorted(CONFIGS), help='BASELINE.json configuration (shape defaults)')
     ap.add_argument('--rooms', type=int, default=None, help='rooms per GPU')
     ap.add_argument('--nodes', type=int, default=None)
