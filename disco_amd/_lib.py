@@ -47,6 +47,8 @@ PROTOTYPES = {
     'disco_set_node_shard': (_int, [_vp, _int, _int]),
     'disco_set_z_blocks': (_int, [_vp, _int]),
     'disco_set_tuning': (_int, [_vp, _int, _int, _int, _int]),
+    'disco_set_option': (_int, [_vp, C.c_char_p, _int]),
+    'disco_get_option': (_int, [_vp, C.c_char_p, C.POINTER(_int)]),
     'disco_stage_timing': (_int, [_vp, _int]),
     'disco_stage_report': (_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int), _int]),
     'disco_dev_alloc': (_int, [_vp, _sz, C.POINTER(_vp)]),

@@ -1,38 +1,93 @@
-"""Build libdisco_hip.so for gfx950 with hipcc (in-tree, so the .so travels with the repository snapshot)."""
+"""Build libdisco_hip.so for gfx950 with hipcc (in-tree, so the .so travels with the repository snapshot).
+
+The host side of the C ABI is a handful of translation units (csrc/api_*.hip, one per kernel family); they are compiled in
+parallel and linked into the one shared library.  A unit is recompiled only when it or a header changed."""
+import hashlib
 import os
 import subprocess
 import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, 'csrc', 'disco_hip.hip')
+CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'lib', 'libdisco_hip.so')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in os.listdir(os.path.join(HERE, 'csrc'))] + \
-       [os.path.join(os.path.dirname(HERE), 'include', 'disco_hip.h')]
+OBJ = os.path.join(HERE, 'lib', 'obj')
+# -fno-slp-vectorize: hipcc's SLP pass fuses adjacent f32 ops into v_pk_*_f32, which issue slower than the scalar
+# pair on gfx950 (guide: "packed f32 VALU ... an anti-lever"); measured -0.9 ms on k_stft_cov, -0.6 ms on k_step2_cov_fused
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-fPIC']
+# kernels that count their vector-memory queue by hand (csrc/k_room.h): a compiler spill inside their loops would shift that
+# count -- a build in which one of them uses scratch is refused
+NO_SPILL = ('k_room_cov_dma', 'k_stft_pairs_cov')
+
+
+def units():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith('api_') and f.endswith('.hip'))
+
+
+def headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
+        [os.path.join(os.path.dirname(HERE), 'include', 'disco_hip.h')]
+
+
+def _newer(target, deps):
+    return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
 
 
 def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+    return _newer(OUT, units() + headers())
 
 
-def build_hip(force=False, verbose=True):
-    if not force and up_to_date():
+def _extra_flags():
+    """-D switches for A/B builds (DISCO_CXXFLAGS='-DDISCO_X=1 ...'); part of an object's identity."""
+    return os.environ.get('DISCO_CXXFLAGS', '').split()
+
+
+def _compile(src, hipcc, extra, verbose):
+    tag = hashlib.sha1(' '.join(extra).encode()).hexdigest()[:8] if extra else 'default'
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.' + tag + '.o')
+    if _newer(obj, [src] + headers()):
+        return obj, '', 0
+    cmd = [hipcc] + FLAGS + extra + ['-c', '-o', obj, src, '-Rpass-analysis=kernel-resource-usage']
+    if verbose:
+        print(' '.join(cmd[:-1]), flush=True)
+    t0 = time.time()
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if p.returncode != 0 and os.path.exists(obj):
+        os.remove(obj)
+    if p.returncode == 0:
+        open(obj[:-2] + '.remarks', 'w').write(p.stderr)          # registers / scratch / LDS / occupancy of every kernel of the unit
+    if verbose:
+        print(f'  {os.path.basename(src)}: {time.time() - t0:.0f} s', flush=True)
+    return obj, p.stderr, p.returncode
+
+
+def build_hip(force=False, verbose=True, jobs=None):
+    extra = _extra_flags()
+    if not force and not extra and up_to_date():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    # -fno-slp-vectorize: hipcc's SLP pass fuses adjacent f32 ops into v_pk_*_f32, which issue slower than the scalar
-    # pair on gfx950 (guide: "packed f32 VALU ... an anti-lever"); measured -0.9 ms on k_stft_cov, -0.6 ms on k_step2_cov_fused
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-shared', '-fPIC', '-o', OUT, SRC]
+    jobs = jobs or int(os.environ.get('DISCO_BUILD_JOBS', os.cpu_count() or 4))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        results = list(ex.map(lambda s: _compile(s, hipcc, extra, verbose), units()))
+    objs = []
+    for obj, remarks, rc in results:
+        if rc != 0:
+            sys.stderr.write(remarks[-8000:])
+            raise RuntimeError(f'hipcc failed ({rc}) on {obj}')
+        spilled = [k for part in NO_SPILL for k in scratch_users(remarks, part)]
+        if spilled:
+            os.remove(obj)
+            raise RuntimeError(f'kernels that must not spill use scratch: {spilled}')
+        objs.append(obj)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
-    # the resource-usage remarks go to stderr: k_room_cov_dma counts its vector-memory queue by hand (csrc/k_room.h) and a
-    # compiler spill inside its loop would shift that count -- a build whose LDS-DMA kernels use scratch is refused
-    p = subprocess.run(cmd + ['-Rpass-analysis=kernel-resource-usage'], stderr=subprocess.PIPE, text=True)
-    spilled = scratch_users(p.stderr, 'k_room_cov_dma')
-    if p.returncode != 0 or spilled:
-        sys.stderr.write(p.stderr[-8000:] if p.returncode != 0 else '')
-        if os.path.exists(OUT) and spilled:
-            os.remove(OUT)
-        raise RuntimeError(f'hipcc failed ({p.returncode})' if p.returncode != 0 else f'kernels that must not spill use scratch: {spilled}')
+    subprocess.check_call(cmd)
     return OUT
 
 

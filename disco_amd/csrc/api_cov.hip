@@ -1,0 +1,149 @@
+// libdisco_hip.so -- host side of the C ABI declared in include/disco_hip.h (gfx950 only): masked covariances (staged form)
+#include "host.h"
+#include "k_cov.h"
+
+using namespace disco;
+using namespace disco_host;
+
+namespace disco_host {
+int cov_chunks(const disco_ctx* ctx) {
+    const long long g = (long long)ctx->cfg.rooms * ctx->cfg.nodes;
+    long long c = (2048 + g - 1) / g;
+    if (c > 8) c = 8;
+    if (ctx->tune_cov_chunks > 0) c = ctx->tune_cov_chunks;
+    if (c > ctx->T) c = ctx->T;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+int ensure_scratch(disco_ctx* ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return 0;
+    if (ctx->scratch) {
+        HIPCHK(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return 0;
+}
+
+int ensure_scratch2(disco_ctx* ctx, size_t bytes) {
+    if (ctx->scratch2_bytes >= bytes) return 0;
+    if (ctx->scratch2) {
+        HIPCHK(ctx, hipFree(ctx->scratch2));
+        ctx->scratch2 = nullptr;
+        ctx->scratch2_bytes = 0;
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->scratch2, bytes));
+    ctx->scratch2_bytes = bytes;
+    return 0;
+}
+
+int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco_c32* Rnn, disco_stream s) {
+    const long long n_gf = (long long)ctx->cfg.rooms * ctx->Kl * ctx->F;
+    hipLaunchKernelGGL(k_cov_finalize, dim3((unsigned)std::min<long long>((n_gf + 127) / 128, 65535)), dim3(128), 0,
+                       (hipStream_t)s, (const float4*)ctx->scratch, (c32*)Rss, (c32*)Rnn, n_gf, ctx->F, chunks, P,
+                       1.0f / (float)ctx->T);
+    return check_launch(ctx, "k_cov_finalize");
+}
+// (M, KR) shapes of the block-partitioned kernels k_cov_split / k_cov_split_lds (api_cov_split.hip)
+bool cov_split_shape(int M, int KR);
+bool launch_cov_split_shape(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const disco::CovArgs& a);
+
+// skiploc (step 2 only, internal): the caller guarantees that `scratch` holds the step-1 partial sums of THIS X with THIS
+// mask (ctx->loc_M == M): the leading M x M block is then neither accumulated nor written, the partial sums go to `scratch2`
+// and the solver assembles the pencil from both.  Honoured only by k_cov_split; the return value of *skiploc_used says so.
+int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs, const disco_c32* Zn,
+                 int mask_remote, int P, int* chunks_out, disco_stream s, bool skiploc) {
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, KR = P - M;
+    if (!X || !mask) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: null argument");
+    if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: P must be M or M + K - 1");
+    if (KR > 0 && (!Zs || !Zn)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Zs/Zn required when P > M");
+    if (P > CB_PMAX || M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: P > 16 or M > 8");
+    const int chunks = cov_chunks(ctx);
+    const long long G = (long long)c.rooms * ctx->Kl;
+    const int NP = P * (P + 1) / 2;
+    const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
+    const bool same = (Zs == Zn);
+    const bool split = (KR == 0 || (P > 8 && same && mask_remote && (ctx->F - 1) % 64 == 0)) && cov_split_shape(M, KR);
+    skiploc = skiploc && split && KR > 0 && ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask;
+    int rc = 0;
+    rc = skiploc ? ensure_scratch2(ctx, need) : ensure_scratch(ctx, need);
+    if (rc) return rc;
+    CovArgs a;
+    a.X = (const c32*)X;
+    a.mask = mask;
+    a.Zs = (const c32*)Zs;
+    a.Zn = (const c32*)Zn;
+    a.part = (float4*)(skiploc ? ctx->scratch2 : ctx->scratch);
+    a.K = c.nodes;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    a.chunks = chunks;
+    a.mask_remote = mask_remote;
+    a.Kl = ctx->Kl;
+    a.k0 = ctx->k0;
+    a.zblk = ctx->zblk;
+    a.R = c.rooms;
+    const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
+    bool launched = false;
+    if (split) {                // 9 <= P <= 16, one vector for both statistics: one block of pairs per wave
+        const int tiles = (ctx->F - 1 + 63) / 64;
+        const long long nblk = G * (tiles + 1) * chunks;
+        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
+        launched = launch_cov_split_shape(M, KR, skiploc, (unsigned)nblk, (hipStream_t)s, a);
+    }
+#define X_(M_, KR_)                                                                                                  \
+    if (!launched && M == M_ && KR == KR_) {                                                                         \
+        if (c.n_fft == 512) {                                                                                        \
+            if (KR_ == 0 || same)                                                                                    \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, true, 320>), grid, block, 0, (hipStream_t)s, a);   \
+            else                                                                                                     \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, false, 320>), grid, block, 0, (hipStream_t)s, a);  \
+        } else {                                                                                                     \
+            if (KR_ == 0 || same)                                                                                    \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, true, 576>), grid, block, 0, (hipStream_t)s, a);   \
+            else                                                                                                     \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov<M_, KR_, false, 576>), grid, block, 0, (hipStream_t)s, a);  \
+        }                                                                                                            \
+        launched = true;                                                                                             \
+    }
+    DISCO_FOR_MKR(X_)
+#undef X_
+    if (!launched) {            // 9 <= P <= 16: pairs split over the waves of a workgroup
+        const int tiles = (ctx->F - 1 + 63) / 64;
+        const long long nblk = G * (tiles + 1) * chunks;
+        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
+        if (KR == 0 || same)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_big<true>), dim3((unsigned)nblk), dim3(64 * CB_S), 0, (hipStream_t)s, a, M, KR);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_big<false>), dim3((unsigned)nblk), dim3(64 * CB_S), 0, (hipStream_t)s, a, M, KR);
+    }
+    *chunks_out = chunks;
+    ctx->pending_chunks = chunks;
+    ctx->pending_P = P;
+    ctx->pending_skiploc = skiploc ? 1 : 0;
+    if (!skiploc) {
+        // `scratch` now holds THIS call's partial sums: step-1 ones (P == M, all nodes here) can be re-used by a step 2
+        // on the same mask, anything else invalidates what k_stft_cov / an earlier step-1 call left
+        ctx->loc_M = (KR == 0 && !sharded(ctx)) ? M : 0;
+        ctx->loc_chunks = chunks;
+        ctx->loc_X = X;
+        ctx->loc_mask = mask;
+    }
+    return check_launch(ctx, "k_cov");
+}
+}  // namespace disco_host
+
+extern "C" int disco_cov_masked(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs,
+                                const disco_c32* Zn, int mask_remote, int P, disco_c32* Rss, disco_c32* Rnn,
+                                disco_stream s) {
+    DISCO_ENTER(ctx);
+    if ((Rss == nullptr) != (Rnn == nullptr)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Rss and Rnn must both be given or both be NULL");
+    int chunks = 1;
+    int rc = cov_partials(ctx, X, mask, Zs, Zn, mask_remote, P, &chunks, s);
+    if (rc || !Rss) return rc;
+    return cov_finalize(ctx, chunks, P, Rss, Rnn, s);
+}

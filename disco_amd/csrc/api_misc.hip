@@ -1,0 +1,167 @@
+// libdisco_hip.so -- host side of the C ABI declared in include/disco_hip.h (gfx950 only): DNN helpers, metrics, ivad mask, RIR convolution, image-source generator, packed-arithmetic self-test
+#include "host.h"
+#include "k_apply.h"
+#include "k_metrics.h"
+#include "k_vad.h"
+#include "k_conv.h"
+#include "k_ism.h"
+#include "pk.h"
+
+using namespace disco;
+using namespace disco_host;
+
+// ---- helper of the mask-estimation DNN (disco_amd/dnn/crnn.py): the pointwise half of a GRU step -----------------------------
+extern "C" int disco_gru_gates(disco_ctx* ctx, const float* gi, int64_t gi_stride, const float* gh, const float* gh_bias,
+                               const float* h_prev, float* h_out, int64_t n, int H, disco_stream s) {
+    // ctx may be NULL (the DNN owns no context): the launch then goes to the calling thread's current device
+    if (!gi || !h_out || (!gh && !gh_bias) || n < 1 || H < 1 || gi_stride < 3 * (int64_t)H) return ctx ? fail(ctx, DISCO_E_ARG, "disco_gru_gates: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    const long long total = (long long)n * H;
+    hipLaunchKernelGGL(k_gru_gates, dim3((unsigned)std::min<long long>((total + 255) / 256, 65536)), dim3(256), 0, (hipStream_t)s, gi,
+                       (long long)gi_stride, gh, gh_bias, h_prev, h_out, (long long)n, H);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return DISCO_E_HIP_BASE - (int)e;
+    return 0;
+}
+
+extern "C" int disco_maxpool_last4(disco_ctx* ctx, const float* x, const float* bias, int64_t n_rows, int row_len, int rows_per_channel,
+                                   int channels, float* out, disco_stream s) {
+    if (!x || !out || n_rows < 1 || row_len < 4 || (bias && (rows_per_channel < 1 || channels < 1))) return ctx ? fail(ctx, DISCO_E_ARG, "disco_maxpool_last4: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    const long long total = (long long)n_rows * (row_len / 4);
+    hipLaunchKernelGGL(k_maxpool_last4, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)s, x, bias, out,
+                       (long long)n_rows, row_len, rows_per_channel > 0 ? rows_per_channel : 1, channels > 0 ? channels : 1);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
+}
+
+extern "C" int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco_c32* b, const disco_c32* c, int64_t n,
+                                 disco_c32* out_hw, disco_c32* out_ref, disco_stream s) {
+    static_assert(PK_SELFTEST_OPS == DISCO_PK_SELFTEST_OPS, "header and kernel disagree");
+    if (!a || !b || !c || !out_hw || !out_ref || n < 1) return ctx ? fail(ctx, DISCO_E_ARG, "disco_selftest_pk: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    hipLaunchKernelGGL(k_pk_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, (const c32*)a, (const c32*)b, (const c32*)c,
+                       (long long)n, (c32*)out_hw, (c32*)out_ref);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
+}
+
+extern "C" int disco_crnn_windows(disco_ctx* ctx, const float* feat, int64_t B, int C, int Tp, int T, int W, int n_keep, float* out,
+                                  disco_stream s) {
+    if (!feat || !out || B < 1 || C < 1 || T < 1 || W < 1 || Tp < T + W - 1 || n_keep < 4 || n_keep % 4 || n_keep > C * W * 4 ||
+        ((uintptr_t)feat & 15) || ((uintptr_t)out & 15))
+        return ctx ? fail(ctx, DISCO_E_ARG, "disco_crnn_windows: bad argument") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    const long long total = (long long)B * T * (n_keep / 4);
+    hipLaunchKernelGGL(k_crnn_windows, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)s,
+                       (const float4*)feat, (float4*)out, (long long)B, C, Tp, T, W, n_keep / 4);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
+}
+// ---- evaluation metrics ----------------------------------------------------------------------------------
+
+extern "C" int disco_pair_stats(disco_ctx* ctx, const float* a, const float* b, int64_t n_sig, int64_t len, int start, int stop,
+                                double* stats, disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!a || !b || !stats || n_sig < 1 || len < 1) return fail(ctx, DISCO_E_ARG, "disco_pair_stats: bad argument");
+    if (start < 0 || stop > len || stop < start) return fail(ctx, DISCO_E_ARG, "disco_pair_stats: need 0 <= start <= stop <= len");
+    if (n_sig > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_pair_stats: batch too large");
+    hipLaunchKernelGGL(k_pair_stats, dim3((unsigned)n_sig), dim3(METRIC_THREADS), 0, (hipStream_t)s, a, b, (long long)len, start, stop, stats);
+    return check_launch(ctx, "k_pair_stats");
+}
+
+extern "C" int disco_band_stats(disco_ctx* ctx, const float* x, int64_t n_sig, int64_t len, int start, int stop,
+                                const double* b, const double* a, int n_bands, double* stats, disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!x || !b || !a || !stats || n_sig < 1 || len < 1) return fail(ctx, DISCO_E_ARG, "disco_band_stats: bad argument");
+    if (start < 0 || stop > len || stop < start) return fail(ctx, DISCO_E_ARG, "disco_band_stats: need 0 <= start <= stop <= len");
+    if (n_bands < 1 || n_bands > METRIC_THREADS) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_band_stats: 1 <= n_bands <= 256");
+    const int spb = std::min(IIR_MAX_SPB, METRIC_THREADS / n_bands);
+    const long long grid = (n_sig + spb - 1) / spb;
+    if (grid > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_band_stats: batch too large");
+    hipLaunchKernelGGL(k_band_stats, dim3((unsigned)grid), dim3(METRIC_THREADS), 0, (hipStream_t)s, x, (long long)n_sig, (long long)len,
+                       start, stop, b, a, n_bands, spb, stats);
+    return check_launch(ctx, "k_band_stats");
+}
+
+// ---- 'ivad' mask (tango.py:217-221 + sigproc_utils.py:12-55) ---------------------------------------------------------------
+
+extern "C" int disco_mask_ivad(disco_ctx* ctx, const float* s_ref, int64_t n_sig, float* mask, disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!s_ref || !mask || n_sig < 1) return fail(ctx, DISCO_E_ARG, "disco_mask_ivad: bad argument");
+    const disco_cfg& c = ctx->cfg;
+    if ((c.length + c.hop - 1) / c.hop > VAD_MAX_SEG) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mask_ivad: signal longer than 4096 hops");
+    if (n_sig > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_mask_ivad: batch too large");
+    hipLaunchKernelGGL(k_vad_mask, dim3((unsigned)n_sig), dim3(VAD_THREADS), 0, (hipStream_t)s, s_ref, mask, c.length, ctx->T, ctx->F,
+                       c.n_fft, c.hop, 0.001f, 0.99f, 2);
+    return check_launch(ctx, "k_vad_mask");
+}
+
+// ---- RIR convolution, the step before the path -----------------------------------------------------------
+
+extern "C" int disco_rir_convolve(disco_ctx* ctx, const float* dry, const float* rir, int64_t n_sig, int n_ch, int dry_len,
+                                  int rir_len, float* out, int out_len, disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!dry || !rir || !out || n_sig < 1 || n_ch < 1 || dry_len < 1 || rir_len < 1 || out_len < 1)
+        return fail(ctx, DISCO_E_ARG, "disco_rir_convolve: bad argument");
+    const int P = (rir_len + CV_B - 1) / CV_B;
+    if (P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_rir_convolve: impulse responses longer than 8192 taps");
+    const int nb = (out_len + CV_B - 1) / CV_B;
+    if (n_sig * n_ch > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_rir_convolve: batch too large");
+    hipStream_t st = (hipStream_t)s;
+    if (!ctx->d_tw_conv) {
+        if (ctx->cfg.n_fft == CV_N) {
+            ctx->d_tw_conv = ctx->d_tw;
+        } else {
+            std::vector<c32> tw(CV_N);
+            const double two_pi = 6.283185307179586476925286766559;
+            for (int i = 0; i < CV_N; ++i) {
+                tw[i].x = (float)std::cos(two_pi * i / CV_N);
+                tw[i].y = (float)(-std::sin(two_pi * i / CV_N));
+            }
+            HIPCHK(ctx, hipMalloc((void**)&ctx->d_tw_conv, CV_N * sizeof(c32)));
+            HIPCHK(ctx, hipMemcpy(ctx->d_tw_conv, tw.data(), CV_N * sizeof(c32), hipMemcpyHostToDevice));
+        }
+    }
+    const size_t x_bytes = (size_t)n_sig * nb * CV_F * sizeof(c32);
+    const size_t h_bytes = (size_t)n_sig * n_ch * P * CV_F * sizeof(c32);
+    const size_t need = align_up(x_bytes) + h_bytes;
+    if (ctx->conv_ws_bytes < need) {
+        if (ctx->conv_ws) HIPCHK(ctx, hipFree(ctx->conv_ws));
+        ctx->conv_ws = nullptr;
+        ctx->conv_ws_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->conv_ws, need));
+        ctx->conv_ws_bytes = need;
+    }
+    c32* X = (c32*)ctx->conv_ws;
+    c32* H = (c32*)((char*)ctx->conv_ws + align_up(x_bytes));
+    const long long nx = (long long)n_sig * nb, nh = (long long)n_sig * n_ch * P;
+    auto grid_of = [](long long items) { return dim3((unsigned)std::min<long long>((items + CV_WAVES - 1) / CV_WAVES, 1 << 20)); };
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_spectra<true>), grid_of(nx), dim3(64 * CV_WAVES), 0, st, dry, (long long)dry_len, nb, nx, X,
+                       ctx->d_tw_conv);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_spectra<false>), grid_of(nh), dim3(64 * CV_WAVES), 0, st, rir, (long long)rir_len, P, nh, H,
+                       ctx->d_tw_conv);
+    const dim3 grid((unsigned)(n_sig * n_ch));
+    if (P <= 8)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mac_ifft<8>), grid, dim3(64 * CV_WAVES), 0, st, X, H, out, ctx->d_tw_conv, n_ch, nb, P, out_len);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_mac_ifft<16>), grid, dim3(64 * CV_WAVES), 0, st, X, H, out, ctx->d_tw_conv, n_ch, nb, P, out_len);
+    return check_launch(ctx, "k_conv_mac_ifft");
+}
+// ---- image-source RIR generator --------------------------------------------------------------------------
+
+extern "C" int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorption, const float* src, const float* mic,
+                             int64_t n_room, int n_src, int n_mic, int max_order, float fs, float c_sound, float* rir, int rir_len,
+                             disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!room_dims || !absorption || !src || !mic || !rir || n_room < 1 || n_src < 1 || n_mic < 1 || max_order < 0 || !(fs > 0.f) ||
+        !(c_sound > 0.f) || rir_len < 1)
+        return fail(ctx, DISCO_E_ARG, "disco_ism_rir: bad argument");
+    if (rir_len > ISM_MAX_LEN) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_ism_rir: responses longer than 8192 taps");
+    if (max_order > 64) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_ism_rir: max_order > 64");
+    const long long n = (long long)n_room * n_src * n_mic;
+    if (n > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_ism_rir: batch too large");
+    hipLaunchKernelGGL(k_ism_rir, dim3((unsigned)n), dim3(ISM_THREADS), 0, (hipStream_t)s, room_dims, absorption, src, mic, n_src, n_mic,
+                       max_order, fs, c_sound, rir, rir_len);
+    return check_launch(ctx, "k_ism_rir");
+}

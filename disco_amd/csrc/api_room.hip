@@ -1,0 +1,66 @@
+// libdisco_hip.so -- host side of the C ABI declared in include/disco_hip.h (gfx950 only): one-pass room covariance for the wide shapes
+#include "host.h"
+#include "k_room.h"
+
+using namespace disco;
+using namespace disco_host;
+
+// Wide shapes (P = M + K - 1 > 8), all nodes of a room on this GPU, mask_for_z = 'local', step-1 partial sums of THIS X with
+// THIS mask still in `scratch`: z of every node AND the step-2 partial sums of every node from ONE pass over X (k_room.h),
+// instead of disco_apply + cov_partials; room_cov_ok says whether the shape and the context's state qualify.
+#define DISCO_FOR_ROOM(X_) X_(8, 8) X_(8, 6) X_(8, 4) X_(8, 2) X_(4, 8) X_(4, 6)
+namespace disco_host {
+bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes;
+    bool shape = false;
+#define X_(M_, K_) if (M == M_ && K == K_) shape = true;
+    DISCO_FOR_ROOM(X_)
+#undef X_
+    const bool want = ctx->opt[DISCO_OPT_ROOM_COV] != 0;
+    if (!want || !shape || M + K - 1 <= 8 || sharded(ctx) || !X || !mask) return false;
+    if (!(ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask)) return false;       // the leading M x M block must be step 1's
+    return (long long)K * ctx->T * ctx->F * M <= 0x0fffffffLL;                               // 32-bit BYTE offsets inside a room (8 B per element)
+}
+
+int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
+                             int* chunks_out, disco_stream s) {
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes, P = M + K - 1;
+    if (!w_loc || !z || !room_cov_ok(ctx, X, mask)) return fail(ctx, DISCO_E_ARG, "room covariance: shape / state does not qualify");
+    const int chunks = cov_chunks(ctx);
+    const long long G = (long long)c.rooms * K;
+    const int NP = P * (P + 1) / 2;
+    int rc = ensure_scratch2(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
+    if (rc) return rc;
+    RoomArgs a;
+    a.X = (const c32*)X;
+    a.mask = mask;
+    a.w = (const c32*)w_loc;
+    a.z = (c32*)z;
+    a.part = (float4*)ctx->scratch2;
+    a.T = ctx->T;
+    a.F = ctx->F;
+    a.chunks = chunks;
+    a.tiles = (ctx->F + 31) / 32;
+    a.R = c.rooms;
+    const long long nblk = (long long)c.rooms * a.tiles * chunks;
+    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
+    // frames through an LDS-DMA ring three ahead (default), or staged through registers one ahead (DISCO_ROOM_DMA=0; k_room.h)
+    const bool dma = ctx->opt[DISCO_OPT_ROOM_DMA] != 0;
+#define X_(M_, K_)                                                                                                       \
+    if (M == M_ && K == K_) {                                                                                            \
+        if (dma)                                                                                                         \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a); \
+        else                                                                                                             \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);     \
+    }
+    DISCO_FOR_ROOM(X_)
+#undef X_
+    *chunks_out = chunks;
+    ctx->pending_chunks = chunks;
+    ctx->pending_P = P;
+    ctx->pending_skiploc = 1;
+    return check_launch(ctx, "k_room_cov");
+}
+}  // namespace disco_host

@@ -1,0 +1,47 @@
+// Launches of the block-partitioned covariance kernels k_cov_split / k_cov_split_lds (k_cov.h), shared by api_cov_split_m*.hip:
+// each of those units instantiates the shapes of ONE mic count (the kernels are large; three units build in parallel).
+#pragma once
+#include "host.h"
+#include "k_cov.h"
+
+namespace disco_host {
+using namespace disco;
+
+template <int M, int KR>
+static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {
+    if constexpr (KR > 0) {
+        // shapes with remote rows (all have an even M, and F - 1 is a multiple of 64 for both FFT sizes): frames staged through
+        // LDS once per workgroup (k_cov.h; 7.3 ms per C5 launch, the per-wave fetches of k_cov_split: 9.6 ms)
+        static_assert(M % 2 == 0, "k_cov_split_lds fetches X in 16-byte granules");
+        const unsigned nb = DISCO_COV_XCD ? (nblk + DISCO_COV_XCD - 1) / DISCO_COV_XCD * DISCO_COV_XCD : nblk;      // see the kernel's id -> item map
+        if (skiploc)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nb), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, false>), dim3(nb), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+    }
+}
+
+
+// (M, KR) shapes for which the block-partitioned kernels are instantiated: 9 <= M + KR <= 16, and the step-1 shapes (KR = 0)
+// whose 2 * M(M+1)/2 complex accumulators no longer fit one thread without spilling (M >= 7)
+#define DISCO_FOR_SPLIT_M8(X_) X_(7, 0) X_(8, 0) X_(8, 1) X_(8, 2) X_(8, 3) X_(8, 4) X_(8, 5) X_(8, 6) X_(8, 7) X_(8, 8)
+#define DISCO_FOR_SPLIT_M4(X_) X_(4, 5) X_(4, 6) X_(4, 7) X_(4, 8) X_(4, 9) X_(4, 10) X_(4, 11) X_(4, 12)
+#define DISCO_FOR_SPLIT_M2(X_) X_(2, 7) X_(2, 8) X_(2, 9) X_(2, 10) X_(2, 11) X_(2, 12) X_(2, 13) X_(2, 14)
+
+bool launch_cov_split_m8(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a);
+bool launch_cov_split_m4(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a);
+bool launch_cov_split_m2(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a);
+
+#define DISCO_DEFINE_SPLIT_LAUNCHER(NAME_, TABLE_)                                                          \
+    bool NAME_(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {              \
+        TABLE_(DISCO_SPLIT_CASE_)                                                                           \
+        return false;                                                                                       \
+    }
+#define DISCO_SPLIT_CASE_(M_, KR_)                        \
+    if (M == M_ && KR == KR_) {                           \
+        launch_cov_split<M_, KR_>(skiploc, nblk, st, a);  \
+        return true;                                      \
+    }
+}  // namespace disco_host

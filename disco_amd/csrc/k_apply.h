@@ -112,7 +112,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64) void k_apply_m(const c32* __
 }
 
 // w_loc[g][f][0:M] <- w_glo[g][f][0:M]  (the local part of a P-entry filter; iterated scheme)
-__global__ void k_filter_head(const c32* __restrict__ w_glo, c32* __restrict__ w_loc, long long n_bins, int M, int P) {
+static __global__ void k_filter_head(const c32* __restrict__ w_glo, c32* __restrict__ w_loc, long long n_bins, int M, int P) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_bins * M; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / M;
         w_loc[i] = w_glo[b * P + (int)(i % M)];
@@ -120,7 +120,7 @@ __global__ void k_filter_head(const c32* __restrict__ w_glo, c32* __restrict__ w
 }
 
 // zn = Y[ref] - z  (tango.py:376)
-__global__ void k_noise_residual(const c32* __restrict__ X, const c32* __restrict__ z, c32* __restrict__ zn,
+static __global__ void k_noise_residual(const c32* __restrict__ X, const c32* __restrict__ z, c32* __restrict__ zn,
                                  long long n, int M, int ref) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const c32 x = X[i * M + ref];
@@ -129,11 +129,8 @@ __global__ void k_noise_residual(const c32* __restrict__ X, const c32* __restric
 }
 
 // ---- small elementwise helpers of the reference-output path (disco_tango_reference) ---------------------------------
-// tf_mask on ONE channel of two interleaved STFTs: mask[i] = tf_mask(S[i*M + ch], N[i*M + ch])   (tango.py:338-342, 391)
-__global__ void k_tf_mask_channel(const c32* __restrict__ S, const c32* __restrict__ Nn, float* __restrict__ mask, long long n, int M,
-                                  int ch, int mask_type, int mask_pow, float thr_lin);
 // the sender-side variants of mask_for_z (tango.py:396-405): zs = m z, zn = (1 - m) z
-__global__ void k_mask_rows(const c32* __restrict__ z, const float* __restrict__ m, c32* __restrict__ zs, c32* __restrict__ zn,
+static __global__ void k_mask_rows(const c32* __restrict__ z, const float* __restrict__ m, c32* __restrict__ zs, c32* __restrict__ zn,
                             long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const c32 v = z[i];
@@ -143,11 +140,11 @@ __global__ void k_mask_rows(const c32* __restrict__ z, const float* __restrict__
     }
 }
 // plane[i] = X[i*M + ch]   ('use_oracle_refs': the remote rows are the oracle images at the reference microphone, tango.py:406-407)
-__global__ void k_pick_channel(const c32* __restrict__ X, c32* __restrict__ plane, long long n, int M, int ch) {
+static __global__ void k_pick_channel(const c32* __restrict__ X, c32* __restrict__ plane, long long n, int M, int ch) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         plane[i] = X[i * M + ch];
 }
-__global__ void k_fill_f32(float* __restrict__ p, float v, long long n) {
+static __global__ void k_fill_f32(float* __restrict__ p, float v, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
 
@@ -155,7 +152,7 @@ __global__ void k_fill_f32(float* __restrict__ p, float v, long long n) {
 //   r = sigm(gi_r + gh_r), z = sigm(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h
 // gi: rows of 3H floats at stride gi_stride (a time slice of the all-steps input projection); gh [n][3H] or NULL with gh_bias
 // [3H] (first step: h = 0, the recurrent product is its bias); h_prev [n][H] or NULL (= 0); h_out [n][H].
-__global__ void k_gru_gates(const float* __restrict__ gi, long long gi_stride, const float* __restrict__ gh, const float* __restrict__ gh_bias,
+static __global__ void k_gru_gates(const float* __restrict__ gi, long long gi_stride, const float* __restrict__ gh, const float* __restrict__ gh_bias,
                             const float* __restrict__ h_prev, float* __restrict__ h_out, long long n, int H) {
     const long long total = n * H;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -184,7 +181,7 @@ __global__ void k_gru_gates(const float* __restrict__ gi, long long gi_stride, c
 // MaxPool2d((1, 4)) over the last axis (floor mode) of x [B][C][rows_per_ch][row_len], plus the convolution's per-channel bias
 // (a constant commutes with the maximum, and adding it here saves a read-modify-write pass over the 4x larger input):
 // out[r][q] = max x[r][4q .. 4q+3] + bias[channel of row r],  q < row_len / 4
-__global__ void k_maxpool_last4(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, long long n_rows,
+static __global__ void k_maxpool_last4(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, long long n_rows,
                                 int row_len, int rows_per_ch, int C) {
     const int nq = row_len / 4;
     const long long total = n_rows * nq;
@@ -193,14 +190,17 @@ __global__ void k_maxpool_last4(const float* __restrict__ x, const float* __rest
         const int q = (int)(i - r * nq);
         const float* p = x + r * row_len + 4 * q;
         const float b = bias ? bias[(r / rows_per_ch) % C] : 0.f;
-        out[i] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])) + b;
+        // torch.nn.MaxPool2d propagates NaN, fmaxf drops it: the sum is NaN iff one of the four is
+        const float mx = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+        const float any = (p[0] + p[1]) + (p[2] + p[3]);
+        out[i] = (any != any ? any : mx) + b;
     }
 }
 
 // The recurrent layer's input windows (crnn.py:59 `.view`): out[(b T + t) * n_keep + e] = feat[b][c][t + w][fy] with
 // e = (c W + w) 4 + fy < n_keep -- the leading n_keep floats of window t's (C, W, 4) block, moved 16 bytes at a time.
 // feat [B][C][Tp][4] (Tp >= T + W - 1), n_keep a multiple of 4.
-__global__ void k_crnn_windows(const float4* __restrict__ feat, float4* __restrict__ out, long long B, int C, int Tp, int T, int W,
+static __global__ void k_crnn_windows(const float4* __restrict__ feat, float4* __restrict__ out, long long B, int C, int Tp, int T, int W,
                                int n_keep4) {
     const long long total = B * T * n_keep4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

@@ -720,7 +720,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLO
 }
 
 // part [n_gf/F][chunks][F][NP] -> Rss, Rnn [n_gf][P][P], mean over T, Hermitian mirror.
-__global__ void k_cov_finalize(const float4* __restrict__ part, c32* __restrict__ Rss, c32* __restrict__ Rnn,
+static __global__ void k_cov_finalize(const float4* __restrict__ part, c32* __restrict__ Rss, c32* __restrict__ Rnn,
                                long long n_gf, int F, int chunks, int P, float inv_T) {
     const int NP = P * (P + 1) / 2;
     for (long long gf = (long long)blockIdx.x * blockDim.x + threadIdx.x; gf < n_gf; gf += (long long)gridDim.x * blockDim.x) {

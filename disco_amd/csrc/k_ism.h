@@ -17,7 +17,7 @@ constexpr int ISM_THREADS = 256;
 constexpr int ISM_MAX_LEN = 8192;           // taps held in LDS
 constexpr int ISM_FDL = 81, ISM_FDL2 = 40;
 
-__global__ __launch_bounds__(ISM_THREADS) void k_ism_rir(const float* __restrict__ dims, const float* __restrict__ absorption,
+static __global__ __launch_bounds__(ISM_THREADS) void k_ism_rir(const float* __restrict__ dims, const float* __restrict__ absorption,
                                                           const float* __restrict__ src, const float* __restrict__ mic,
                                                           int S, int Q, int max_order, float fs, float c_sound,
                                                           float* __restrict__ rir, int Lh) {

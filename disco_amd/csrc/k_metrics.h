@@ -23,7 +23,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // one workgroup per signal pair: a[sig][start:stop], b[sig][start:stop]  (b may alias a)
-__global__ __launch_bounds__(METRIC_THREADS) void k_pair_stats(const float* __restrict__ a, const float* __restrict__ b,
+static __global__ __launch_bounds__(METRIC_THREADS) void k_pair_stats(const float* __restrict__ a, const float* __restrict__ b,
                                                                 long long len, int start, int stop,
                                                                 double* __restrict__ stats) {
     __shared__ double red[METRIC_THREADS / 64][PAIR_STATS];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(METRIC_THREADS) void k_pair_stats(const float* __re
 // zero initial state at `start` -- the reference slices BEFORE filtering, tango.py:577-590) on its band.
 constexpr int IIR_TILE = 256;
 constexpr int IIR_MAX_SPB = 32;      // signals per workgroup (static LDS: 32 x 257 floats)
-__global__ __launch_bounds__(METRIC_THREADS) void k_band_stats(const float* __restrict__ x, long long n_sig, long long len,
+static __global__ __launch_bounds__(METRIC_THREADS) void k_band_stats(const float* __restrict__ x, long long n_sig, long long len,
                                                                 int start, int stop, const double* __restrict__ bc,
                                                                 const double* __restrict__ ac, int n_bands, int spb,
                                                                 double* __restrict__ stats) {

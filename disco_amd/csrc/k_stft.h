@@ -21,6 +21,9 @@ namespace disco {
 #endif
 constexpr int STFT_WAVES = DISCO_STFT_WAVES;     // waves per block; each streams its own run of frames
 constexpr int STFT_RUN = DISCO_STFT_RUN;         // consecutive frames per wave
+// host side: launch geometry of the per-wave-run kernels
+inline int stft_runs(int T) { return (T + STFT_RUN - 1) / STFT_RUN; }
+inline long long stft_blocks(long long n_witems) { return (n_witems + STFT_WAVES - 1) / STFT_WAVES; }
 
 template <int N>
 struct StftShared {
@@ -302,13 +305,13 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_mask_ora
     }
 }
 
-__global__ void k_tf_mask(const c32* __restrict__ S, const c32* __restrict__ Nn, float* __restrict__ mask,
+static __global__ void k_tf_mask(const c32* __restrict__ S, const c32* __restrict__ Nn, float* __restrict__ mask,
                           long long n, int mask_type, int mask_pow, float thr_lin) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         mask[i] = tf_mask_value(S[i], Nn[i], mask_type, mask_pow, thr_lin);
 }
 
-__global__ void k_tf_mask_channel(const c32* __restrict__ S, const c32* __restrict__ Nn, float* __restrict__ mask, long long n, int M,
+static __global__ void k_tf_mask_channel(const c32* __restrict__ S, const c32* __restrict__ Nn, float* __restrict__ mask, long long n, int M,
                                   int ch, int mask_type, int mask_pow, float thr_lin) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         mask[i] = tf_mask_value(S[i * M + ch], Nn[i * M + ch], mask_type, mask_pow, thr_lin);

@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned vad_select(VadShared& sh, const float* __res
     return sh.prefix;
 }
 
-__global__ __launch_bounds__(VAD_THREADS) void k_vad_mask(const float* __restrict__ ts, float* __restrict__ mask, int L, int T,
+static __global__ __launch_bounds__(VAD_THREADS) void k_vad_mask(const float* __restrict__ ts, float* __restrict__ mask, int L, int T,
                                                           int F, int win, int hop, float thr_rel, float quant, int rat) {
     __shared__ VadShared sh;
     const int tid = threadIdx.x, lane = tid & 63, w = wave_id();

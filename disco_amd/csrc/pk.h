@@ -182,7 +182,7 @@ __device__ __forceinline__ void pk_selftest_ops(c32 a, c32 b, c32 c, c32* o) {
     o[14] = Pk<HW>::template scale_by_half<1>(a, b);
     o[15] = Pk<HW>::template fma_by_half<1>(a, b, c);
 }
-__global__ void k_pk_selftest(const c32* __restrict__ a, const c32* __restrict__ b, const c32* __restrict__ c, long long n,
+static __global__ void k_pk_selftest(const c32* __restrict__ a, const c32* __restrict__ b, const c32* __restrict__ c, long long n,
                               c32* __restrict__ out_hw, c32* __restrict__ out_ref) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

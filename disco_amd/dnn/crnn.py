@@ -174,6 +174,8 @@ class CRNN(nn.Module):
         frame_to_pred: 'mid' (tango.py:35, what offline_tango uses) or 'last' (prepare_data's own default);
         norm_type: None | 'scale_to_unit_norm' | 'scale_to_1' | 'center_and_scale' (per frequency over the whole sequence,
         utils.py:36-66; 'pcen' is librosa's and not offered)."""
+        if self.training:
+            raise RuntimeError('predict_masks is the inference path (BatchNorm folded on its running statistics): call model.eval() first')
         B, C, T, F = mag.shape
         W = self.x_out                                              # 15 output frames per 21-frame window
         if frame_to_pred == 'mid':                                  # get_frames_to_pad (utils.py:13-33), reshape_mask (tango.py:228-240)

@@ -232,6 +232,15 @@ class Engine:
         """Pin the launch geometry (0 = batch-size heuristic): lets a small batch run the code path of a large one."""
         self._chk(self.lib.disco_set_tuning(self.ctx, stft_frames_per_wave, cov_chunks, step2_chunks, istft_pairs))
 
+    def set_option(self, key, value):
+        """Per-context switch between equivalent kernel routes (include/disco_hip.h: disco_set_option)."""
+        self._chk(self.lib.disco_set_option(self.ctx, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        self._chk(self.lib.disco_get_option(self.ctx, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def stage_timing(self, enable=True):
         """Start (clearing) / stop the per-stage hipEvent timers of the whole-path calls."""
         self._chk(self.lib.disco_stage_timing(self.ctx, int(bool(enable))))

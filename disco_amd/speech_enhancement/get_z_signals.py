@@ -13,7 +13,7 @@ def offline_tango(y, s, n, vads='irm1', mods=None, mask_for_z='local'):
         vads = vads[0]                                        # only the step-1 mask type is used (get_z_signals.py:277-281)
     yb, sb, nb = _as_batch(y), _as_batch(s), _as_batch(n)
     if yb is None or sb is None or nb is None:                # ragged channel counts: the staged per-node path
-        d = _offline_tango_ragged(y, s, n, vads, mask_for_z)
+        d = _offline_tango_ragged(y, s, n, vads, mask_for_z, steps=1)
         return tuple([np.ascontiguousarray(v.T) for v in d[nm]] for nm in names)
     mods = None if mods is None else [mods[0] if isinstance(mods, (list, tuple)) else mods, None]
     d = offline_tango_batched(yb, sb, nb, vads=[vads, vads], mods=mods, mask_for_z=mask_for_z, steps=1)

@@ -137,12 +137,15 @@ def offline_tango_batched(y, s, n, vads='irm1', mods=None, mask_for_z=MASK_Z, z_
     return {k: v.numpy() for k, v in eng.tango_reference(yd, sd, nd, mask_z=mz, mask_w=mw, mask_for_z=mask_for_z, steps=3).items()}
 
 
-def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='reflect', ref_mic=0, mu=1.0):
+def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='reflect', ref_mic=0, mu=1.0, steps=3):
     """Nodes with DIFFERENT channel counts (the reference allows them: nb_ch is per node, tango.py:259-261, 286).  The
     batched layout is uniform, so every node runs as a one-node shard (`disco_set_node_shard(k, 1)`) of a K-node context
     with ITS OWN mic count; the remote rows of step 2 are the z of all K nodes, exactly the node-sharded data flow.
-    Returns per-node lists of (T, F) arrays."""
+    steps = 1: stop after step 1 (get_z_signals.py:213-317) -- no step-2 mask, statistics, solves or filter passes, and none of
+    step 2's restrictions.  Returns per-node lists of (T, F) arrays."""
     vads = _mask_names(vads, [1, 1])
+    if steps == 1:
+        vads = [vads[0], vads[0]]
     if 'crnn' in vads:
         raise NotImplementedError('DNN masks with ragged channel counts: run the nodes through disco_amd.dnn.inloop')
     MODES = ('local', None, 'distant', 'compressed', 'use_oracle_refs', 'use_oracle_zs', 'previous')
@@ -170,7 +173,7 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
             Sh, Nh = S.numpy(), N.numpy()
             mz = _get_mask(eng, Sh[..., ref_mic], Nh[..., ref_mic], s[k][ref_mic][None], vads[0])
             same = (vads[1] == vads[0]) and ref_mic == 0
-            mw = mz if same else _get_mask(eng, Sh[..., 0], Nh[..., 0], s[k][0][None], vads[1])
+            mw = mz if (same or steps == 1) else _get_mask(eng, Sh[..., 0], Nh[..., 0], s[k][0][None], vads[1])
             if oracle_sigs:
                 Rss, _ = eng.cov_masked(S, np.ones_like(mz))
                 _, Rnn = eng.cov_masked(N, np.zeros_like(mz))
@@ -183,6 +186,8 @@ def _offline_tango_ragged(y, s, n, vads, mask_for_z, n_fft=N_FFT, pad_mode='refl
             for nm, v in (('z_y', z_y), ('z_s', z_s), ('z_n', z_n), ('zn', zn), ('masks_z', mz), ('mask_w', mw)):
                 out[nm][k] = v[0, 0]
             st.append((eng, M, Y.numpy(), Sh, Nh, mw))
+        if steps == 1:
+            return out
         Zy, Zs, Zn, ZN = (np.ascontiguousarray(np.stack(out[nm])[None]) for nm in ('z_y', 'z_s', 'z_n', 'zn'))
         MW = np.stack(out['mask_w'])[None]
         if mask_for_z == 'compressed':                                         # sender-side mask from (z_s, z_n), tango.py:402-405

@@ -127,6 +127,22 @@ int  disco_set_z_blocks(disco_ctx* ctx, int nodes_per_block);
  * 0 keeps the heuristic for that kernel.  Results do not depend on the geometry beyond float32 summation order. */
 int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, int step2_chunks, int istft_pairs);
 
+/* Per-context options: integer switches that choose between equivalent kernel routes (A/B measurements, tests of both routes).
+ * Two contexts of one process may differ; nothing is read from the environment inside a compute call -- an environment variable
+ * (named below) only PRESETS the option when disco_create runs.  The route a whole-path call took shows in the stage names of
+ * disco_stage_report.  Keys:
+ *   "step2_from_samples" (DISCO_STEP2_FROM_SAMPLES, default 0)  fused filter + iSTFT pass re-transforms the samples (stage
+ *                         "step2_stft_apply_istft") instead of reading the stored spectra ("step2_apply_istft")
+ *   "room_cov"           (DISCO_ROOM_COV, 1)   wide shapes: z + step-2 statistics of a whole room in one pass ("room_cov2") instead of
+ *                         disco_apply + disco_cov_masked ("apply1" + "cov2")
+ *   "room_dma"           (DISCO_ROOM_DMA, 1)   that pass on its LDS-DMA ring ("room_cov2"); 0: register-staged ("room_cov2_reg")
+ *   "overlap_solves"     (DISCO_OVERLAP_SOLVES, 1)  whole-path calls on large batches run as two half-batches on two streams so that one
+ *                         half's solves overlap the other half's streaming kernels (stages then appear twice per step)
+ *   "solve_f32"          (DISCO_SOLVE_F32, 1)  group solver (P >= 5): float32 squarings + float64 polish; 0: float64 throughout
+ * Unknown key: DISCO_E_ARG. */
+int  disco_set_option(disco_ctx* ctx, const char* key, int value);
+int  disco_get_option(const disco_ctx* ctx, const char* key, int* value);
+
 /* Per-stage timers of the whole-path entry points (disco_tango_enhance, _iterated, _online) and of disco_mask_oracle:
  * while enabled, every stage they launch (STFT+covariance, solves, filter passes, iSTFT ...) is bracketed by two hipEvents on
  * the call's stream.  disco_stage_timing(ctx, 1) clears and starts, (ctx, 0) clears and stops.  disco_stage_report waits for
@@ -227,7 +243,8 @@ int disco_step2_cov_fused(disco_ctx* ctx, const disco_c32* X, const float* mask_
  * disco_stft_cov_fused call left in this context; that block is neither accumulated nor written, and
  * disco_gevd_mwf_r1_pending assembles the pencil from both sets of partial sums.
  * Contract: the LAST covariance call of this context was disco_stft_cov_fused(y, mask_w, X, ...) producing THIS X with
- * THIS mask_w (only disco_gevd_mwf_r1_pending may have run in between); anything else returns DISCO_E_ARG.
+ * THIS mask_w (only disco_gevd_mwf_r1_pending may have run in between); anything else returns DISCO_E_ARG.  The check is on
+ * the POINTERS: the caller must not have rewritten X or mask_w in place since (the library cannot see that).
  * The matrices themselves are not available from this entry point (use disco_step2_cov_fused for Rss / Rnn). */
 int disco_step2_cov_fused_reuse(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc,
                                 disco_c32* z_out, disco_stream s);
@@ -268,7 +285,9 @@ int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, con
  *                ('ivad' / DNN masks are computed by the caller -- disco_mask_ivad, the CRNN -- and passed in)
  *   mask_for_z   DISCO_MZ_*: what the remote rows of the step-2 statistics are (tango.py:343-348, 396-429)
  *   steps        1: step 1 only (get_z_signals.py:213-317); 3: both; 2: step 2 only, on the state a previous `steps = 1` call
- *                with the same y, s, n left in the SAME workspace (a DNN step-2 mask needs z before it can be computed)
+ *                with the same y, s, n left in the SAME workspace (a DNN step-2 mask needs z before it can be computed); the
+ *                context remembers that state and returns DISCO_E_ARG for steps = 2 when it is not there -- no steps = 1 call,
+ *                other y / s / n / workspace pointers, or another whole-path call that used the workspace in between
  *   out          device pointers, each [R][K][T][F]; any of them may be NULL (not wanted)
  * workspace: at least disco_reference_workspace_bytes(ctx) (three STFTs, the exchanged rows, filters), or NULL to let the
  * context allocate and keep it. */

@@ -4,22 +4,33 @@ logic at toy sizes without a GPU; never loaded by the disco_amd package (which h
 import ctypes
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRC = os.path.join(REPO, 'disco_amd', 'csrc', 'disco_hip.hip')
+CSRC = os.path.join(REPO, 'disco_amd', 'csrc')
 OUT = os.path.join(HERE, '_emu', 'libdisco_hipemu_TESTONLY.so')
+OBJ = os.path.join(HERE, '_emu', 'obj')
 
 
 def build_emu():
-    deps = [os.path.join(REPO, 'disco_amd', 'csrc', f) for f in os.listdir(os.path.join(REPO, 'disco_amd', 'csrc'))]
-    deps += [os.path.join(HERE, 'hipemu', 'include', 'hip', 'hip_runtime.h'), os.path.join(REPO, 'include', 'disco_hip.h')]
-    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    units = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith('api_') and f.endswith('.hip'))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs += [os.path.join(HERE, 'hipemu', 'include', 'hip', 'hip_runtime.h'), os.path.join(REPO, 'include', 'disco_hip.h')]
+    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in units + hdrs):
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ['g++', '-O2', '-std=c++17', '-x', 'c++', '-fPIC', '-shared', '-pthread', '-ffp-contract=off',
-           '-I', os.path.join(HERE, 'hipemu', 'include'), '-o', OUT, SRC]
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    flags = ['g++', '-O2', '-std=c++17', '-x', 'c++', '-fPIC', '-pthread', '-ffp-contract=off', '-I', os.path.join(HERE, 'hipemu', 'include')]
+
+    def compile_unit(src):
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+        if not (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
+            subprocess.check_call(flags + ['-c', '-o', obj, src])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        objs = list(ex.map(compile_unit, units))
+    subprocess.check_call(['g++', '-shared', '-pthread', '-o', OUT] + objs)
     return OUT
 
 

@@ -542,22 +542,13 @@ def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-
     the one a large batch takes, and additionally check the `outputs=enhanced` call (no z / yf requested: the fused
     filter+iSTFT kernel, which is what bench.py times) against the same oracle.
     from_samples = 0 | 1: which step-2 filter + iSTFT kernel the `outputs=enhanced` call takes -- the one reading the stored
-    spectra back or the one re-transforming the samples (the library reads DISCO_STEP2_FROM_SAMPLES when a context is
-    created); None: the library's default.
+    spectra back or the one re-transforming the samples (disco_set_option "step2_from_samples"); None: the library's default.
     Returns the per-output worst relative errors."""
-    import os
     R, K, M, L = y.shape
-    saved = os.environ.get('DISCO_STEP2_FROM_SAMPLES')
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask, staged_step2=staged_step2)
     if from_samples is not None:
-        os.environ['DISCO_STEP2_FROM_SAMPLES'] = str(int(from_samples))
-    try:
-        eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, mask=mask, staged_step2=staged_step2)
-    finally:
-        if from_samples is not None:
-            if saved is None:
-                del os.environ['DISCO_STEP2_FROM_SAMPLES']
-            else:
-                os.environ['DISCO_STEP2_FROM_SAMPLES'] = saved
+        eng.set_option('step2_from_samples', int(from_samples))
+        assert eng.get_option('step2_from_samples') == int(from_samples)
     if tuning is not None:
         eng.set_tuning(*tuning)
     T, F = eng.T, eng.F
@@ -868,34 +859,35 @@ def check_no_allocation_in_compute_calls(make_engine, K=3, M=2, L=6000, n_fft=51
 def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tuning=None, tol=1e-4):
     """k_room_cov (csrc/k_room.h: z of every node + the step-2 statistics of every node of a room from ONE pass over X, wide
     shapes P = M + K - 1 > 8) against (a) the route it replaces -- disco_apply + the split covariance kernels, selected with
-    DISCO_ROOM_COV=0 -- on the same context, and (b) the float64 oracle; both whole-path entry points."""
-    import os
+    disco_set_option("room_cov", 0) -- and (b) the float64 oracle; both whole-path entry points.  The three routes run on THREE
+    contexts alive at the same time (options are per context, not process-global), and the stage names say which route ran."""
     from disco_amd import synth
     y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
     eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
     if tuning is not None:
         eng.set_tuning(*tuning)
     m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F)
-    saved = {v: os.environ.get(v) for v in ('DISCO_ROOM_COV', 'DISCO_ROOM_DMA')}
     res = {}
-    try:
-        # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route
-        for mode, cov, dma in (('1', '1', '1'), ('reg', '1', '0'), ('0', '0', '1')):
-            os.environ['DISCO_ROOM_COV'] = cov
-            os.environ['DISCO_ROOM_DMA'] = dma
-            eng.stage_timing(True)
-            out_i, yf_i = eng.tango_enhance_iterated(y, m, iters=iters)
-            stages = set(eng.stage_report())
-            eng.stage_timing(False)
-            assert ('room_cov2' in stages) == (cov == '1'), (mode, stages)
-            out_e, z_e, yf_e = eng.tango_enhance(y, m)
-            res[mode] = (out_i.numpy(), yf_i.numpy(), out_e.numpy(), z_e.numpy(), yf_e.numpy())
-    finally:
-        for v, old in saved.items():
-            if old is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = old
+    # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route
+    engines = {}
+    for mode, cov, dma in (('1', 1, 1), ('reg', 1, 0), ('0', 0, 1)):
+        e = eng if mode == '1' else make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+        if mode != '1' and tuning is not None:
+            e.set_tuning(*tuning)
+        e.set_option('room_cov', cov)
+        e.set_option('room_dma', dma)
+        engines[mode] = e
+    m_np = m.numpy()
+    want_stage = {'1': 'room_cov2', 'reg': 'room_cov2_reg', '0': 'cov2'}
+    for mode, e in engines.items():
+        mm = m if e is eng else m_np
+        e.stage_timing(True)
+        out_i, yf_i = e.tango_enhance_iterated(y, mm, iters=iters)
+        stages = set(e.stage_report())
+        e.stage_timing(False)
+        assert want_stage[mode] in stages and not (set(want_stage.values()) - {want_stage[mode]}) & stages, (mode, stages)
+        out_e, z_e, yf_e = e.tango_enhance(y, mm)
+        res[mode] = (out_i.numpy(), yf_i.numpy(), out_e.numpy(), z_e.numpy(), yf_e.numpy())
     errs = {}
     for name, a, b, c_ in zip(('out_iter', 'yf_iter', 'out', 'z_y', 'yf'), res['1'], res['0'], res['reg']):
         errs[name + '_vs_staged'] = max(relerr(a[r, k], b[r, k]) for r in range(R) for k in range(K))

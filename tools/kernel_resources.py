@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """Per-kernel register / scratch / LDS / occupancy table from hipcc's -Rpass-analysis=kernel-resource-usage.
-Usage: tools/kernel_resources.py [substring ...]"""
+Usage: tools/kernel_resources.py [-DFOO=1 ...] [substring ...]"""
 import os
 import re
 import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(REPO, 'disco_amd', 'csrc', 'disco_hip.hip')
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-c', '-fPIC', '-Rpass-analysis=kernel-resource-usage',
-       '-o', '/tmp/_res.o', src] + [a for a in sys.argv[1:] if a.startswith('-D')]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+sys.path.insert(0, REPO)
+from disco_amd import build as _b
+
+# the remarks hipcc printed for every translation unit (disco_amd/build.py keeps them next to the objects);
+# -D switches go through DISCO_CXXFLAGS, as for the build itself
+extra = [a for a in sys.argv[1:] if a.startswith('-D')]
+if extra:
+    os.environ['DISCO_CXXFLAGS'] = ' '.join(extra)
+_b.build_hip(verbose=False)
+import hashlib
+tag = hashlib.sha1(' '.join(extra).encode()).hexdigest()[:8] if extra else 'default'
+out = ''.join(open(os.path.join(_b.OBJ, f)).read() for f in sorted(os.listdir(_b.OBJ)) if f.endswith('.' + tag + '.remarks'))
 rows, cur = [], None
 for line in out.splitlines():
     m = re.search(r'remark: (?:.*?:\d+:\d+: )?\s*(Function Name|Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|SGPRs): (\S+)', line)
