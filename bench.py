@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""Benchmark of the MI355X MWF hot path (driver contract: one JSON line on rank 0).
+"""Benchmark of the MI355X MWF hot path (driver contract: ONE JSON line on rank 0).
 
-Workload: `--config` picks one of BASELINE.json's configurations (default C3, the one the headline metric is quoted on):
-  C2  256 rooms x 1 node  x 4 mics, 512-pt STFT, oracle mask            (single node: step 1 + iSTFT)
-  C3  1000 rooms x 4 nodes x 4 mics, 512-pt STFT, oracle mask, z exchange on the GPU
-  C4  C3's shape with CRNN masks (PyTorch-ROCm) in the loop, 125 rooms per GPU (1000 rooms over 8 GPUs)
-  C5  200 rooms x 8 nodes x 8 mics, 1024-pt STFT, 2 step-2 iterations (DANSE-style stress shape)
+Headline workload: `--config` picks one of BASELINE.json's configurations (default C3, the one the metric is quoted on):
+  C2       256 rooms x 1 node  x 4 mics, 512-pt STFT, oracle mask            (single node: step 1 + iSTFT)
+  C3       1000 rooms x 4 nodes x 4 mics, 512-pt STFT, oracle mask, z exchange on the GPU
+  C4       C3's shape with CRNN masks (PyTorch-ROCm) in the loop, 125 rooms per GPU (1000 rooms over 8 GPUs)
+  C5       200 rooms x 8 nodes x 8 mics, 1024-pt STFT, 2 step-2 iterations (DANSE-style stress shape)
 all at 16 kHz, 10 s clips (L = 160000); --rooms/--nodes/--mics/--n-fft/--iters/--mask override single fields.
 One "step" = the whole path over the whole batch: oracle mask (2 STFTs/node) -> STFT -> covariance -> GEVD-MWF solve -> z ->
 exchange -> covariance -> solve -> filter -> iSTFT, inputs and outputs resident in HBM.  metric = node-frames/s (1 node-frame =
 one hop of all M mics of one node); x real-time = audio seconds per room / seconds per step.
+
+The plain command (`python bench.py [--gpus N]`, headline C3) ALSO runs the other BASELINE configurations for a few steps each
+-- C5, C2 (256 and 4000 rooms), C4 and the online mode -- and attaches them as `"configs": {name: {ms_per_step, value, roofline,
+parity_sample, stages, ...}}` inside the same JSON line (`--extras none` skips them, `--extras C5,C2` picks).  The headline
+fields are untouched by them: they run after the headline's timed region.
 
 Multi-GPU (`--gpus N`): one process per GPU.  Under torch.distributed.run (RANK/WORLD_SIZE in the environment) the ranks are
 taken as given; started plainly with --gpus N > 1 the script launches its own N ranks (disco_amd/dist.py:launch_ranks).
@@ -18,8 +23,10 @@ taken as given; started plainly with --gpus N > 1 the script launches its own N 
   --shard nodes          : the nodes of every room are split over the ranks and z is exchanged with one RCCL all-gather per
                            step-2 iteration -- the exchange DISCO's algorithm performs (tango.py:378-386); the line then carries
                            the all-gather's bytes per rank and link rate.
-After the timed region rank 0 checks sampled rooms of the LAST timed step against the float64 CPU oracle ("parity_sample";
-a failure exits non-zero after printing the line).
+EVERY rank checks sampled rooms of ITS OWN batch -- the output of the last timed step -- against the float64 CPU oracle
+("parity_sample": rank 0's rooms in `per_room`, every rank's rooms / device / worst error in `ranks`, the worst over all
+ranks in `worst_rel_all_ranks`); a failure on any rank exits non-zero after the line is printed.  The oracle runs in worker
+processes while the GPU goes on with the next workload.
 """
 import argparse
 import hashlib
@@ -32,12 +39,21 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
+F32_MATRIX_PEAK = 157.3e12  # same guide: f32-input MFMA = the f32 vector rate (what a float32 library GEMM / convolution can reach)
 
 CONFIGS = {
-    'C2': dict(rooms=256, nodes=1, mics=4, n_fft=512, iters=1, mask='oracle'),
-    'C3': dict(rooms=1000, nodes=4, mics=4, n_fft=512, iters=1, mask='oracle'),
-    'C4': dict(rooms=125, nodes=4, mics=4, n_fft=512, iters=1, mask='crnn'),
-    'C5': dict(rooms=200, nodes=8, mics=8, n_fft=1024, iters=2, mask='oracle'),
+    'C2': dict(rooms=256, nodes=1, mics=4, n_fft=512, iters=1, mask='oracle', online_every=0),
+    'C3': dict(rooms=1000, nodes=4, mics=4, n_fft=512, iters=1, mask='oracle', online_every=0),
+    'C4': dict(rooms=125, nodes=4, mics=4, n_fft=512, iters=1, mask='crnn', online_every=0),
+    'C5': dict(rooms=200, nodes=8, mics=8, n_fft=1024, iters=2, mask='oracle', online_every=0),
+}
+# what the plain command runs after the headline (name -> workload, steps, warmup, rooms rank 0 checks against the oracle)
+EXTRAS = {
+    'C5': (dict(CONFIGS['C5']), 5, 2, 3),
+    'C2': (dict(CONFIGS['C2']), 10, 3, 3),
+    'C2x4000': (dict(CONFIGS['C2'], rooms=4000), 5, 2, 2),
+    'C4': (dict(CONFIGS['C4']), 3, 1, 2),
+    'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 1),
 }
 
 
@@ -61,6 +77,7 @@ def kernel_alg_bytes(M, K, F, H):
         'apply1': M * F * 8 + F * 8,                          # X in, z out
         'cov2': M * F * 8 + F * 4 + (K - 1) * F * 8,          # X + mask + remote z in
         'room_cov2': M * F * 8 + F * 4 + F * 8,               # X + mask in, z out (all nodes of a room in one workgroup: remote z's stay on chip)
+        'room_cov2_reg': M * F * 8 + F * 4 + F * 8,
         'apply2': M * F * 8 + (K - 1) * F * 8 + F * 8,        # X + remote z in, yf out
         'step2_cov': M * F * 8 + F * 4,                       # X + mask in (z stays on chip)
         'step2_apply': M * F * 8 + F * 8,                     # X in, yf out
@@ -68,6 +85,9 @@ def kernel_alg_bytes(M, K, F, H):
         'stft_apply_istft': M * H * 4 + H * 4,                # samples in, hop samples out (single node, nothing materialised)
         'step2_stft_apply_istft': M * H * 4 + H * 4,          # samples in, hop samples out (spectra re-transformed, z / yf on chip)
         'istft': F * 8 + H * 4,                               # yf in, hop samples out
+        'apply_istft': M * F * 8 + H * 4,
+        'online1': M * F * 8 + F * 4 + F * 8,                 # X + mask in, z out (the smoothed matrices live in registers)
+        'online2': M * F * 8 + (K - 1) * F * 8 + F * 4 + F * 8,   # X + remote z + mask in, yf out
     }
 
 
@@ -137,7 +157,6 @@ def cpu_baseline(K, M, L, n_fft=512):
     from disco_amd import synth
     from oracle import tango_oracle as to
     hop = n_fft // 2
-    T = 1 + L // hop
     Ls = L if K * M <= 16 else L // 8                     # C5-shaped rooms: an eighth of the clip keeps the sample bounded
     y, s, n, _ = synth.make_room_numpy(0, K=K, M=M, L=Ls)
     Ts = 1 + Ls // hop
@@ -157,32 +176,69 @@ def cpu_baseline(K, M, L, n_fft=512):
             'x_realtime': (Ls / 16000.0) / dt}
 
 
-def parity_sample(samples, n_fft, iters, tol=1e-4):
-    """Sampled rooms of the batch the timed region just processed, against the float64 CPU oracle (test infrastructure used
-    as the checker, never as the thing measured).  samples: [(room id, y (K,M,L), s_ref (K,L), n_ref (K,L), got (Kl,L), k0)]
-    as host arrays; `got` are this rank's nodes [k0, k0+Kl) of the room's output."""
+# ---- the checker: sampled rooms against the float64 CPU oracle (runs in worker processes) ------------------------------------------
+def parity_job(kind, room, yr, sr, nr, got, k0, n_fft, iters, masks=None):
+    """One sampled room of the batch the timed region just processed, against the float64 CPU oracle (test infrastructure used as
+    the checker, never as the thing measured).  yr (K,M,L); sr, nr (K,L) target / noise image at the reference mic; got (Kl,L):
+    this rank's nodes [k0, k0+Kl) of the room's output.  kind: 'batch' (offline_tango_vec, oracle masks), 'masks' (the same
+    around GIVEN masks: the DNN's predictions go to both sides), 'online' (online_oracle.online_tango).  -> (room, worst rel err)."""
     import numpy as np
     from oracle import stft_oracle as so
-    from oracle import tango_oracle as to
-    worst, per_room = 0.0, {}
-    for r, yr, sr, nr, got, k0 in samples:
-        L = yr.shape[-1]
-        s = np.zeros_like(yr)
-        n = np.zeros_like(yr)
-        s[:, 0] = sr                                      # the masks only look at the reference microphone (tango.py:338-342)
-        n[:, 0] = nr
-        o = to.offline_tango_vec(yr, s, n, vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh',
-                                 extra_iters=iters - 1)
-        e = 0.0
-        for kl in range(got.shape[0]):
-            ref = so.istft(o['yf'][k0 + kl], L, n_fft, n_fft // 2, work_dtype=np.float64)
-            e = max(e, float(np.linalg.norm(got[kl] - ref) / np.linalg.norm(ref)))
-        per_room[int(r)] = e
-        worst = max(worst, e)
-    return {'rooms': [int(x[0]) for x in samples], 'worst_rel': worst, 'tol': tol, 'ok': bool(worst < tol),
-            'per_room': per_room,
-            'oracle': 'oracle/tango_oracle.py:offline_tango_vec(float64) + oracle/stft_oracle.py:istft, per (room, node) '
-                      '||out - ref||_2 / ||ref||_2 on the output of the last timed step'}
+    L = yr.shape[-1]
+    s = np.zeros_like(yr)
+    n = np.zeros_like(yr)
+    s[:, 0] = sr                                          # the masks only look at the reference microphone (tango.py:338-342)
+    n[:, 0] = nr
+    if kind == 'online':
+        from oracle import online_oracle as oo
+        ref_out = oo.online_tango(yr, s, n, n_fft=n_fft, hop=n_fft // 2, update_every=iters)['out']
+        refs = [ref_out[k0 + kl] for kl in range(got.shape[0])]
+    else:
+        from oracle import tango_oracle as to
+        kw = dict(masks=masks) if kind == 'masks' else dict(vads=['irm1', 'irm1'], extra_iters=iters - 1)
+        o = to.offline_tango_vec(yr, s, n, n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh', **kw)
+        refs = [so.istft(o['yf'][k0 + kl], L, n_fft, n_fft // 2, work_dtype=np.float64) for kl in range(got.shape[0])]
+    e = 0.0
+    for kl in range(got.shape[0]):
+        e = max(e, float(np.linalg.norm(got[kl] - refs[kl]) / np.linalg.norm(refs[kl])))
+    return int(room), e
+
+
+def rank_sample_rooms(rank, R, n_rank0):
+    """Local room indices a rank checks: rank 0 spreads `n_rank0` over its batch (first ... last); every other rank takes ONE room of
+    its own, at a rank-dependent position (so that a wrong room range or device on rank r shows up)."""
+    if rank == 0:
+        n_s = max(1, min(n_rank0, R))
+        return sorted({int(round(i * (R - 1) / max(n_s - 1, 1))) for i in range(n_s)})
+    return [(37 * rank + R // 2) % R]
+
+
+def merge_parity(local, per_rank_rows, tol):
+    """local: rank 0's {'rooms', 'per_room', 'worst_rel'}; per_rank_rows: [(rank, device, first_room, [global room ids], worst)] of
+    EVERY rank -> the parity_sample object of the line."""
+    worst_all = max(r[4] for r in per_rank_rows)
+    return {'rooms': local['rooms'], 'worst_rel': local['worst_rel'], 'tol': tol, 'ok': bool(worst_all < tol),
+            'per_room': local['per_room'], 'worst_rel_all_ranks': worst_all,
+            'ranks': [{'rank': int(r[0]), 'device': int(r[1]), 'first_room': int(r[2]), 'rooms_checked': [int(x) for x in r[3]],
+                       'worst_rel': r[4]} for r in per_rank_rows],
+            'oracle': 'float64 CPU oracle (oracle/tango_oracle.py:offline_tango_vec + oracle/stft_oracle.py:istft; online: '
+                      'oracle/online_oracle.py:online_tango), per (room, node) ||out - ref||_2 / ||ref||_2 on the output of the last '
+                      'timed step; every rank checks rooms of its own batch'}
+
+
+def gather_rank_rows(rank, world, device_index, first_room, rooms_global, worst, dist, dev, gloo=False):
+    """All-gather of every rank's (device, first room, checked rooms, worst error) as one fixed-size float64 row."""
+    import torch
+    row = [float(rank), float(device_index), float(first_room), float(len(rooms_global))] + [float(x) for x in rooms_global[:4]]
+    row += [-1.0] * (8 - len(row)) + [float(worst)]
+    if world == 1:
+        rows = [row]
+    else:
+        t = torch.tensor(row, dtype=torch.float64, device='cpu' if gloo else dev)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        rows = [o.cpu().tolist() for o in outs]
+    return [(int(r[0]), int(r[1]), int(r[2]), [int(x) for x in r[4:4 + int(r[3])]], float(r[8])) for r in rows]
 
 
 def parse_args(argv=None):
@@ -198,9 +254,9 @@ def parse_args(argv=None):
     ap.add_argument('--n-fft', type=int, default=None)
     ap.add_argument('--mask', default=None, choices=['oracle', 'crnn'],
                     help="'crnn': BASELINE configs[3] -- randomly initialised CRNN mask estimators (PyTorch-ROCm) in the loop")
-    ap.add_argument('--online-every', type=int, default=0,
+    ap.add_argument('--online-every', type=int, default=None,
                     help='> 0: time the ONLINE pipeline (SURVEY 8f-2) with a filter update every this many frames instead of '
-                         'the batch path (not the headline metric; roofline is skipped)')
+                         'the batch path (not the headline metric)')
     ap.add_argument('--iters', type=int, default=None,
                     help='> 1: the DANSE-style iterated scheme (BASELINE configs[4]; disco_tango_enhance_iterated)')
     ap.add_argument('--shard', default='rooms', choices=['rooms', 'nodes'],
@@ -208,19 +264,353 @@ def parse_args(argv=None):
     ap.add_argument('--graph', action='store_true',
                     help='capture one step (mask + whole path) into a hipGraph on a side stream and time its replays: one launch per '
                          'step instead of 6-20 (matters for small batches; oracle masks, room-sharded batch path only)')
+    ap.add_argument('--extras', default='auto',
+                    help="the other BASELINE configurations run after the headline and attached as `configs`: 'auto' (all of "
+                         f"{', '.join(EXTRAS)} when the command is the plain C3 headline, none otherwise), 'all', 'none', or a comma list")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the sampled-room oracle check after the timed region')
     ap.add_argument('--parity-rooms', type=int, default=3)
     ap.add_argument('--pmc-calibrate', action='store_true', help='also run a 4 GiB device copy (known bytes) for PMC calibration')
     ap.add_argument('--selftest-launch', action='store_true',
-                    help='no GPU work: every rank joins a gloo group and rank 0 prints n_gpus (covers the self-launch path on CPU)')
+                    help='no GPU work: every rank joins a gloo group, rank 0 prints n_gpus and the all-rank parity merge of fake per-rank '
+                         'errors (covers the self-launch path and the all-rank bookkeeping on CPU)')
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config]
-    for k in ('rooms', 'nodes', 'mics', 'n_fft', 'iters', 'mask'):
+    plain = all(getattr(args, k) is None for k in ('rooms', 'nodes', 'mics', 'n_fft', 'iters', 'mask', 'online_every'))
+    for k in ('rooms', 'nodes', 'mics', 'n_fft', 'iters', 'mask', 'online_every'):
         if getattr(args, k) is None:
             setattr(args, k, cfg[k])
+    if args.extras == 'auto':
+        args.extras = 'all' if (plain and args.config == 'C3' and args.shard == 'rooms' and not args.graph and args.length == 160000) else 'none'
+    if args.extras == 'all':
+        args.extra_names = list(EXTRAS)
+    elif args.extras == 'none':
+        args.extra_names = []
+    else:
+        args.extra_names = [x for x in args.extras.split(',') if x]
+        bad = [x for x in args.extra_names if x not in EXTRAS]
+        if bad:
+            ap.error(f'--extras: unknown workload(s) {bad}; known: {list(EXTRAS)}')
     return args
+
+
+class TorchStageMarks:
+    """Phase timer of the PyTorch-driven path (C4): an event on the launch stream after every phase."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.ev = []
+        self('start')
+
+    def __call__(self, name):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev.append((name, e))
+
+    def report(self):
+        self.torch.cuda.synchronize()
+        out = {}
+        for (_, a), (name, b) in zip(self.ev[:-1], self.ev[1:]):
+            ms, n = out.get(name, (0.0, 0))
+            out[name] = (ms + a.elapsed_time(b), n + 1)
+        return out
+
+
+def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
+    """Generate the synthetic batch of workload `w` on this rank's GPU, time `steps` steps, time the stages, hand sampled rooms of
+    the last timed step to the oracle workers.  Collectives (barrier / max / sum) only for the headline; the extras time every
+    rank on its own clock and are merged at the end (no collective inside something that may fail on one rank only).
+    -> (result dict, parity ticket)"""
+    import numpy as np
+    import torch
+    from disco_amd import dist as dd
+    from disco_amd import synth
+    from disco_amd.engine import Engine
+
+    rank, world, local_rank, dev, dist, lib = env['rank'], env['world'], env['local_rank'], env['dev'], env['dist'], env['lib']
+    R, K, M, Ls, N = w['rooms'], w['nodes'], w['mics'], args.length, w['n_fft']
+    iters, mask_kind, online_every = w['iters'], w['mask'], w['online_every']
+    H, F = N // 2, N // 2 + 1
+    node_sharded = headline and args.shard == 'nodes'
+    if node_sharded and (mask_kind != 'oracle' or online_every):
+        raise SystemExit('--shard nodes runs the batch path with oracle masks')
+    eng = Engine(rooms=R, nodes=K, mics=M, length=Ls, n_fft=N, device=local_rank, lib=lib)
+    T = eng.T
+    assert torch.cuda.current_stream().cuda_stream == 0, 'bench times the null stream the library launches on'
+
+    want_parity = not args.no_parity
+    sample_rooms = rank_sample_rooms(rank, R, n_parity_rank0) if want_parity else []
+    sample_in = {}
+
+    # synthetic rooms, generated on the GPU (SURVEY 8d recipe)
+    if node_sharded:
+        from disco_amd import node_sharded as ns
+        k0, Kl = ns.node_range(rank, world, K)
+        eng.set_node_shard(k0, Kl)
+        first_room = 0
+        # every rank draws the same R rooms and keeps its own nodes (the generator is per room; slicing keeps it simple)
+        y_all, s_all, n_all = synth.make_rooms_torch(R, K, M, Ls, first_room=0, device=dev, ref_only_sn=True)
+        y = y_all[:, k0:k0 + Kl].contiguous()
+        s_ref = s_all[:, k0:k0 + Kl].contiguous()
+        n_ref = n_all[:, k0:k0 + Kl].contiguous()
+        # the oracle needs ALL nodes of a sampled room
+        sample_in = {r: (y_all[r].cpu().numpy(), s_all[r].cpu().numpy(), n_all[r].cpu().numpy()) for r in sample_rooms}
+        del y_all, s_all, n_all
+        units_per_step = R * Kl * T
+    else:
+        k0, Kl = 0, K
+        first_room, _ = dd.room_range(rank, world, R)     # rank r owns rooms [r*R, (r+1)*R)
+        y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, Ls, first_room=first_room, device=dev, ref_only_sn=True)
+        sample_in = {r: (y[r].cpu().numpy(), s_ref[r].cpu().numpy(), n_ref[r].cpu().numpy()) for r in sample_rooms}
+        units_per_step = R * K * T
+    mask = torch.empty((R, Kl, T, F), dtype=torch.float32, device=dev)
+    out = torch.empty((R, Kl, Ls), dtype=torch.float32, device=dev)
+    ws = None if node_sharded else torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
+    G = R * Kl
+
+    dnn = {}
+    if mask_kind == 'crnn':
+        from disco_amd.dnn.crnn import build_crnn
+        from disco_amd.dnn.inloop import tango_enhance_dnn
+        torch.manual_seed(0)
+        model_z = build_crnn(1, device=dev)
+        model_w = build_crnn(K, device=dev) if K > 1 else None
+
+    gather_events = []                     # (start, stop) torch events around every all-gather of z (--shard nodes)
+
+    def step(mark=None):
+        if mask_kind == 'crnn':
+            o, mz, mw = tango_enhance_dnn(eng, y, model_z, model_w, want_masks=True, mark=mark)
+            out.copy_(o)
+            dnn['mz'], dnn['mw'] = mz, mw
+            return
+        eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), None))
+        if node_sharded:
+            ns.tango_enhance_node_sharded_torch(eng, y, mask, mask, iters=iters, out=out, gather_events=gather_events)
+            return
+        if online_every > 0:
+            eng._chk(lib.disco_tango_online(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), 0.95, online_every,
+                                            1e-3, out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
+            return
+        if iters > 1:
+            eng._chk(lib.disco_tango_enhance_iterated(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), iters,
+                                                      out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
+            return
+        eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                         None, None, ws.data_ptr(), ws.numel(), None))
+
+    def barrier():
+        if world > 1 and headline:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eager_step = step
+    if args.graph and headline:
+        if mask_kind != 'oracle' or node_sharded or online_every:
+            raise SystemExit('--graph captures the room-sharded batch path with oracle masks')
+        eng.reserve(0)
+        step()                              # nothing is left to allocate inside the captured calls
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        hip_graph = torch.cuda.CUDAGraph()
+        h = side.cuda_stream
+        with torch.cuda.graph(hip_graph, stream=side):
+            eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), h))
+            if iters > 1:
+                eng._chk(lib.disco_tango_enhance_iterated(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), iters,
+                                                          out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), h))
+            else:
+                eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                                 None, None, ws.data_ptr(), ws.numel(), h))
+        torch.cuda.synchronize()
+        step = hip_graph.replay             # replays on the current (null) stream, the one the barriers drain
+
+    if args.pmc_calibrate and headline:
+        src = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        torch.neg(src, out=dst)             # 4 GiB read + 4 GiB written by ONE elementwise kernel (a plain copy_ goes to the DMA engines)
+        torch.cuda.synchronize()
+        del src, dst
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt_local = time.perf_counter() - t0
+    if headline:
+        value, dt = dd.whole_job_throughput(units_per_step * steps, dt_local, world, device=dev)
+    else:
+        value, dt = units_per_step * steps / dt_local, dt_local       # merged over the ranks at the end (merge_extras)
+    finite = bool(torch.isfinite(out).all())
+    gather_ms = [a_.elapsed_time(b_) for a_, b_ in gather_events[-steps * iters:]] if gather_events else []
+    ms_per_step = 1e3 * dt / steps
+    x_rt = (Ls / 16000.0) / (dt / steps)
+
+    # ---- sampled rooms of the last timed step -> the oracle workers (every rank, its own rooms)
+    ticket = {'name': name, 'jobs': [], 'rooms_global': [first_room + r for r in sample_rooms], 'first_room': first_room,
+              'tol': 1e-4, 'finite': finite}
+    if want_parity:
+        pool = env['pool']
+        for r in sample_rooms:
+            yr, sr, nr = sample_in[r]
+            got = out[r].cpu().numpy()
+            if mask_kind == 'crnn':
+                masks = ([dnn['mz'][r, k].T.double().cpu().numpy() for k in range(K)], [dnn['mw'][r, k].T.double().cpu().numpy() for k in range(K)])
+                job = ('masks', first_room + r, yr, sr, nr, got, k0, N, 1, masks)
+            elif online_every > 0:
+                job = ('online', first_room + r, yr, sr, nr, got, k0, N, online_every)
+            else:
+                job = ('batch', first_room + r, yr, sr, nr, got, k0, N, iters)
+            ticket['jobs'].append(pool.submit(parity_job, *job))
+
+    # ---- per-stage timing on the launch stream, for the roofline object (rank 0)
+    roofline, stages = None, None
+    if rank == 0 and not args.no_stage_timing and not node_sharded:
+        reps = max(2, min(steps, 5 if headline else 3))
+        eager_step()                            # the event objects are created inside the library: warm that path once
+        torch.cuda.synchronize()
+        # one report per step, and the MEDIAN over the steps: an event pair also spans whatever the host does between the two
+        # records, and a single descheduled launch call (seen once: 85 ms inside one 7 ms stage) would otherwise own the mean
+        per_rep = []
+        for _ in range(reps):
+            if mask_kind == 'crnn':
+                marks = TorchStageMarks(torch)
+                eager_step(marks)
+                per_rep.append(marks.report())
+            else:
+                eng.stage_timing(True)
+                eager_step()                    # (a captured graph carries no events: the stage pass always launches eagerly)
+                per_rep.append(eng.stage_report())
+        if mask_kind != 'crnn':
+            eng.stage_timing(False)
+        kab = kernel_alg_bytes(M, K, F, H)
+        stages = {}
+        for nm in per_rep[0]:
+            ms_list = sorted(r_[nm][0] for r_ in per_rep if nm in r_)
+            per_step = ms_list[len(ms_list) // 2] if len(ms_list) % 2 else 0.5 * (ms_list[len(ms_list) // 2 - 1] + ms_list[len(ms_list) // 2])
+            launches = per_rep[0][nm][1]
+            ent = {'ms': round(per_step, 4), 'launches_per_step': float(launches), 'ms_min': round(ms_list[0], 4), 'ms_max': round(ms_list[-1], 4)}
+            if nm in kab:
+                ent['alg_bytes'] = kab[nm] * R * K * T * launches     # per step (all launches of the stage)
+                ent['GBps'] = round(ent['alg_bytes'] / (per_step * 1e-3) / 1e9, 1)
+            if nm in ('crnn_z', 'crnn_w'):
+                from disco_amd.dnn.crnn import flops_per_frame
+                ent['flops'] = flops_per_frame(1 if nm == 'crnn_z' else K) * R * K * T
+                ent['TFLOPs'] = round(ent['flops'] / (per_step * 1e-3) / 1e12, 2)
+            stages[nm] = ent
+        pipeline_b = b_alg(M, K, F, H, iters)
+        pipeline = {'B_alg_per_node_frame': pipeline_b, 'achieved_GBps': round(units_per_step * steps / dt_local * pipeline_b / 1e9, 1),
+                    'frac': round(units_per_step * steps / dt_local * pipeline_b / HBM_PEAK, 4)}
+        dom = max(stages, key=lambda n_: stages[n_]['ms'])
+        lps = stages[dom]['launches_per_step']
+        launch_ms = stages[dom]['ms'] / lps
+        if 'flops' in stages[dom]:
+            # the dominant stage is the mask-estimation DNN: float32 library GEMMs (rocBLAS / hipBLASLt) and MIOpen convolutions driven
+            # by PyTorch -- not a HIP kernel of this library; priced against the float32 matrix peak
+            achieved = stages[dom]['flops'] / lps / (launch_ms * 1e-3)
+            roofline = {'bound': 'mfma', 'kernel': f'{dom}: PyTorch-ROCm CRNN forward (float32 rocBLAS GEMMs + MIOpen convolutions, not a kernel of this library)',
+                        'achieved': round(achieved / 1e12, 2), 'peak': F32_MATRIX_PEAK / 1e12, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / F32_MATRIX_PEAK, 4), 'traffic': None, 'avg_launch_ms': round(launch_ms, 4),
+                        'flops_per_launch': stages[dom]['flops'] / lps, 'pipeline': pipeline}
+        else:
+            cand = [n_ for n_ in stages if 'alg_bytes' in stages[n_]]
+            dom = max(cand, key=lambda n_: stages[n_]['ms'])
+            lps = stages[dom]['launches_per_step']
+            launch_ms = stages[dom]['ms'] / lps
+            launch_bytes = stages[dom]['alg_bytes'] / lps
+            achieved = launch_bytes / (launch_ms * 1e-3)
+            traffic, traffic_note = None, None
+            tfile = os.path.join(REPO, 'profiles', f'pmc_traffic_{name}.json')
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    traffic = tj.get(dom, {}).get('hbm_bytes_per_launch')
+                    if tj.get('_csrc_digest') != csrc_digest():
+                        traffic_note = (f'{os.path.basename(tfile)} was measured on other kernel sources (digest '
+                                        f'{tj.get("_csrc_digest")} vs {csrc_digest()}): stale, shown for orientation only')
+                except Exception:
+                    traffic = None
+            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved / 1e9, 1), 'peak': HBM_PEAK / 1e9,
+                        'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': traffic,
+                        'alg_bytes_per_launch': launch_bytes, 'avg_launch_ms': round(launch_ms, 4), 'pipeline': pipeline}
+            if online_every > 0:
+                roofline['note'] = ('the online kernels re-solve a P x P GEVD per (bin, frame): float64-issue-bound, not HBM-bound; the '
+                                    'fraction says how far they are from the streaming bound of their inputs')
+            if traffic_note:
+                roofline['traffic_note'] = traffic_note
+
+    exchange = None
+    if node_sharded:
+        # one all-gather per step-2 iteration: every rank receives the other ranks' z (R * (K - Kl) * T * F complex64)
+        per_gather = R * (K - Kl) * T * F * 8
+        exchange = {'collective': 'all_gather_into_tensor (RCCL)', 'gathers_per_step': iters,
+                    'bytes_received_per_rank_per_gather': per_gather,
+                    'bytes_per_peer_link_per_gather': R * Kl * T * F * 8,
+                    'ms_per_gather': (sum(gather_ms) / len(gather_ms)) if gather_ms else None,
+                    'link_GBps': (R * Kl * T * F * 8 / (sum(gather_ms) / len(gather_ms) * 1e-3) / 1e9) if (gather_ms and world > 1) else None,
+                    'note': 'xGMI is point-to-point: each of the W-1 peers sends its R*Kl*T*F*8-byte block over its own link'}
+
+    mask_desc = 'oracle irm1 mask' if mask_kind == 'oracle' else 'CRNN masks in the loop (random weights, PyTorch-ROCm)'
+    par = (f'nodes of every room split over {world} GPU(s) ({Kl} per rank), one RCCL all-gather of z per step-2 iteration'
+           if node_sharded else f'rooms sharded over {world} GPU(s), no data-path collective')
+    res = {
+        'value': value, 'unit': 'node-frames/s', 'ms_per_step': ms_per_step, 'x_realtime': x_rt, 'steps': steps, 'warmup': warmup,
+        'seconds_local': dt_local, 'units_local': units_per_step * steps,
+        'config': {'workload': f'{name}: {R} rooms{"" if node_sharded else "/GPU"} x {K} nodes x {M} mics, 16 kHz, L={Ls}, '
+                               f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced'
+                               + (f', ONLINE mode lambda=0.95 update_every={online_every}' if online_every else '')
+                               + (f', {iters} step-2 iterations (DANSE-style)' if iters > 1 else ''),
+                   'launch': 'one hipGraph replay per step' if (args.graph and headline) else 'eager kernel launches',
+                   'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
+                   'iters': iters, 'parallelism': par},
+        'roofline': roofline, 'stages': stages,
+    }
+    if exchange:
+        res['exchange'] = exchange
+    del y, s_ref, n_ref, mask, out, ws, eng
+    torch.cuda.empty_cache()
+    return res, ticket
+
+
+def finish_parity(ticket, env, timeout=900.0):
+    """Wait for this rank's oracle jobs of one workload, then merge over the ranks -> parity_sample object (same on every rank)."""
+    rank, world = env['rank'], env['world']
+    per_room, worst, err = {}, 0.0, None
+    for fut in ticket['jobs']:
+        try:
+            room, e = fut.result(timeout=timeout)
+        except Exception as ex:                            # a checker that cannot run is a failed check, not a silent pass
+            room, e, err = -1, float('inf'), repr(ex)
+        per_room[int(room)] = e
+        worst = max(worst, e)
+    if not ticket['finite']:
+        worst = float('inf')
+    rows = gather_rank_rows(rank, world, env['local_rank'], ticket['first_room'], ticket['rooms_global'], worst, env['dist'], env['dev'])
+    ps = merge_parity({'rooms': ticket['rooms_global'], 'per_room': per_room, 'worst_rel': worst}, rows, ticket['tol'])
+    if err:
+        ps['error'] = err
+    return ps
+
+
+def merge_extras(res, env):
+    """value of an extra workload over the whole job: units of all ranks / the slowest rank's time (every rank on its own clock)."""
+    import torch
+    world = env['world']
+    if world == 1:
+        return res
+    t = torch.tensor([res['seconds_local'], res['units_local']], dtype=torch.float64, device=env['dev'])
+    outs = [torch.empty_like(t) for _ in range(world)]
+    env['dist'].all_gather(outs, t)
+    secs = [float(o[0]) for o in outs]
+    units = sum(float(o[1]) for o in outs)
+    res['value'] = units / max(secs)
+    res['ms_per_step'] = 1e3 * max(secs) / res['steps']
+    res['x_realtime'] = (res['config']['length'] / 16000.0) / (max(secs) / res['steps'])
+    res['seconds_per_rank'] = secs
+    return res
 
 
 def main(argv=None):
@@ -241,16 +631,21 @@ def main(argv=None):
     if args.selftest_launch:
         dist = dd.init('gloo', rank, world)
         value, dt = dd.whole_job_throughput(1000.0 * (rank + 1), 0.5 + 0.1 * rank, world)
+        # the all-rank parity bookkeeping on fake numbers: rank r "checked" its rooms with worst error 1e-6 * (r + 1)
+        rooms = [10 * rank + x for x in rank_sample_rooms(rank, 10, 3)]
+        rows = gather_rank_rows(rank, world, local_rank, 10 * rank, rooms, 1e-6 * (rank + 1), dist, 'cpu', gloo=True)
+        ps = merge_parity({'rooms': rooms, 'per_room': {r: 1e-6 * (rank + 1) for r in rooms}, 'worst_rel': 1e-6 * (rank + 1)}, rows, 1e-4)
         if rank == 0:
-            print(json.dumps({'selftest': 'launch', 'n_gpus': world, 'value': value, 'seconds': dt}), flush=True)
+            print(json.dumps({'selftest': 'launch', 'n_gpus': world, 'value': value, 'seconds': dt, 'parity_sample': ps}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return 0
 
-    import numpy as np
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+
     import torch
-    from disco_amd import _lib, synth
-    from disco_amd.engine import Engine
+    from disco_amd import _lib
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
@@ -260,229 +655,84 @@ def main(argv=None):
     if world == 1 and node_sharded:
         os.environ.setdefault('MASTER_PORT', str(dd.free_port()))
     dist = dd.init('nccl', rank, world, device=dev) if (world > 1 or node_sharded) else None    # RCCL (one-rank group for --shard nodes)
-
-    R, K, M, Ls, N = args.rooms, args.nodes, args.mics, args.length, args.n_fft
-    H, F = N // 2, N // 2 + 1
     lib = _lib.load()
-    if node_sharded and (args.mask != 'oracle' or args.online_every):
-        raise SystemExit('--shard nodes runs the batch path with oracle masks')
-    eng = Engine(rooms=R, nodes=K, mics=M, length=Ls, n_fft=N, device=local_rank, lib=lib)
-    T = eng.T
-    assert torch.cuda.current_stream().cuda_stream == 0, 'bench times the null stream the library launches on'
+    # oracle workers: fresh interpreters (spawn: a forked HIP context is not usable), single-threaded numpy each
+    for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ.setdefault(v, '1')
+    pool = None if args.no_parity else ProcessPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 8) // max(world, 1))),
+                                                           mp_context=mp.get_context('spawn'))
+    env = dict(rank=rank, world=world, local_rank=local_rank, dev=dev, dist=dist, lib=lib, pool=pool)
 
-    want_parity = rank == 0 and not args.no_parity and args.mask == 'oracle' and args.online_every == 0
-    n_s = max(1, min(args.parity_rooms, R))
-    sample_rooms = sorted({int(round(i * (R - 1) / max(n_s - 1, 1))) for i in range(n_s)})
-    if K * M > 16:
-        sample_rooms = sample_rooms[:1]                   # a P = 15 room costs the float64 oracle ~1 min
-    sample_in = {}
+    head_w = {k: getattr(args, k) for k in ('rooms', 'nodes', 'mics', 'n_fft', 'iters', 'mask', 'online_every')}
+    cfg_shape = CONFIGS[args.config]
+    is_cfg = all(head_w[k] == cfg_shape[k] for k in ('nodes', 'mics', 'n_fft', 'iters', 'mask', 'online_every'))
+    head_name = args.config if is_cfg else 'custom'
+    n_par = args.parity_rooms if head_w['nodes'] * head_w['mics'] <= 16 else min(args.parity_rooms, 3)
+    head, head_ticket = run_workload(head_name, head_w, args.steps, args.warmup, env, True, n_par, args)
 
-    # synthetic rooms, generated on the GPU (SURVEY 8d recipe)
-    if node_sharded:
-        from disco_amd import node_sharded as ns
-        k0, Kl = ns.node_range(rank, world, K)
-        eng.set_node_shard(k0, Kl)
-        # every rank draws the same R rooms and keeps its own nodes (the generator is per room; slicing keeps it simple)
-        y_all, s_all, n_all = synth.make_rooms_torch(R, K, M, Ls, first_room=0, device=dev, ref_only_sn=True)
-        y = y_all[:, k0:k0 + Kl].contiguous()
-        s_ref = s_all[:, k0:k0 + Kl].contiguous()
-        n_ref = n_all[:, k0:k0 + Kl].contiguous()
-        if want_parity:                                   # the oracle needs ALL nodes of a sampled room
-            sample_in = {r: (y_all[r].cpu().numpy(), s_all[r].cpu().numpy(), n_all[r].cpu().numpy()) for r in sample_rooms}
-        del y_all, s_all, n_all
-        units_per_step = R * Kl * T
-    else:
-        k0, Kl = 0, K
-        first_room, _ = dd.room_range(rank, world, R)     # rank r owns rooms [r*R, (r+1)*R)
-        y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, Ls, first_room=first_room, device=dev, ref_only_sn=True)
-        if want_parity:
-            sample_in = {r: (y[r].cpu().numpy(), s_ref[r].cpu().numpy(), n_ref[r].cpu().numpy()) for r in sample_rooms}
-        units_per_step = R * K * T
-    mask = torch.empty((R, Kl, T, F), dtype=torch.float32, device=dev)
-    out = torch.empty((R, Kl, Ls), dtype=torch.float32, device=dev)
-    ws = None if node_sharded else torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
-    G = R * Kl
+    extras, tickets = {}, {}
+    for nm in args.extra_names:
+        w, st, wu, npar = EXTRAS[nm]
+        try:
+            extras[nm], tickets[nm] = run_workload(nm, w, min(st, max(args.steps, 1)), min(wu, args.warmup), env, False, npar, args)
+        except Exception as e:                              # an extra must never take the headline down
+            import traceback
+            extras[nm] = {'error': repr(e), 'trace': traceback.format_exc()[-1500:]}
+            torch.cuda.empty_cache()
 
-    if args.mask == 'crnn':
-        from disco_amd.dnn.crnn import build_crnn
-        from disco_amd.dnn.inloop import tango_enhance_dnn
-        torch.manual_seed(0)
-        model_z = build_crnn(1, device=dev)
-        model_w = build_crnn(K, device=dev) if K > 1 else None
-
-    gather_events = []                     # (start, stop) torch events around every all-gather of z (--shard nodes)
-
-    def step():
-        if args.mask == 'crnn':
-            out.copy_(tango_enhance_dnn(eng, y, model_z, model_w))
-            return
-        eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), None))
-        if node_sharded:
-            ns.tango_enhance_node_sharded_torch(eng, y, mask, mask, iters=args.iters, out=out, gather_events=gather_events)
-            return
-        if args.online_every > 0:
-            eng._chk(lib.disco_tango_online(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), 0.95, args.online_every,
-                                            1e-3, out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
-            return
-        if args.iters > 1:
-            eng._chk(lib.disco_tango_enhance_iterated(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), args.iters,
-                                                      out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
-            return
-        eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
-                                         None, None, ws.data_ptr(), ws.numel(), None))
-
-    def barrier():
+    # ---- collect: parity of every workload (all ranks), whole-job value of the extras
+    parity = None if args.no_parity else finish_parity(head_ticket, env)
+    failures = []
+    if parity is not None and not parity['ok']:
+        failures.append((head_name, parity['worst_rel_all_ranks']))
+    for nm in args.extra_names:
+        # every rank takes part in the same gathers in the same order, whether its own run of the extra succeeded or not
+        ok_local = 'error' not in extras[nm]
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    eager_step = step
-    if args.graph:
-        if args.mask != 'oracle' or node_sharded or args.online_every:
-            raise SystemExit('--graph captures the room-sharded batch path with oracle masks')
-        eng.reserve(0)
-        step()                              # nothing is left to allocate inside the captured calls
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream(device=dev)
-        hip_graph = torch.cuda.CUDAGraph()
-        h = side.cuda_stream
-        with torch.cuda.graph(hip_graph, stream=side):
-            eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), h))
-            if args.iters > 1:
-                eng._chk(lib.disco_tango_enhance_iterated(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), args.iters,
-                                                          out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), h))
-            else:
-                eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
-                                                 None, None, ws.data_ptr(), ws.numel(), h))
-        torch.cuda.synchronize()
-        step = hip_graph.replay             # replays on the current (null) stream, the one the barriers drain
-
-    if args.pmc_calibrate:
-        src = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
-        dst = torch.empty_like(src)
-        torch.neg(src, out=dst)             # 4 GiB read + 4 GiB written by ONE elementwise kernel (a plain copy_ goes to the DMA engines)
-        torch.cuda.synchronize()
-        del src, dst
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    value, dt = dd.whole_job_throughput(units_per_step * args.steps, dt, world, device=dev)
-    assert bool(torch.isfinite(out).all())
-    gather_ms = [a_.elapsed_time(b_) for a_, b_ in gather_events[-args.steps * args.iters:]] if gather_events else []
-    ms_per_step = 1e3 * dt / args.steps
-    x_rt = (Ls / 16000.0) / (dt / args.steps)
-
-    # ---- sampled rooms of the last timed step against the CPU oracle (rank 0)
-    parity = None
-    if want_parity:
-        parity = parity_sample([(r,) + sample_in[r] + (out[r].cpu().numpy(), k0) for r in sample_rooms], N, args.iters)
-
-    # ---- per-stage timing with the library's own HIP events on the launch stream (rank 0), for the roofline object
-    roofline, stages = None, None
-    if rank == 0 and not args.no_stage_timing and args.mask == 'oracle' and not node_sharded:
-        reps = max(2, min(args.steps, 5))
-        eager_step()                            # the event objects are created inside the library: warm that path once
-        torch.cuda.synchronize()
-        # one report per step, and the MEDIAN over the steps: an event pair also spans whatever the host does between the two
-        # records, and a single descheduled launch call (seen once: 85 ms inside one 7 ms stage) would otherwise own the mean
-        per_rep = []
-        for _ in range(reps):
-            eng.stage_timing(True)
-            eager_step()                        # (a captured graph carries no events: the stage pass always launches eagerly)
-            per_rep.append(eng.stage_report())
-        eng.stage_timing(False)
-        kab = kernel_alg_bytes(M, K, F, H)
-        stages = {}
-        for name in per_rep[0]:
-            ms_list = sorted(r_[name][0] for r_ in per_rep if name in r_)
-            per_step = ms_list[len(ms_list) // 2] if len(ms_list) % 2 else 0.5 * (ms_list[len(ms_list) // 2 - 1] + ms_list[len(ms_list) // 2])
-            launches = per_rep[0][name][1]
-            ent = {'ms': round(per_step, 4), 'launches_per_step': float(launches), 'ms_min': round(ms_list[0], 4), 'ms_max': round(ms_list[-1], 4)}
-            if name in kab:
-                ent['alg_bytes'] = kab[name] * R * K * T * launches     # per step (all launches of the stage)
-                ent['GBps'] = round(ent['alg_bytes'] / (per_step * 1e-3) / 1e9, 1)
-            stages[name] = ent
-        if args.online_every == 0:
-            cand = [n_ for n_ in stages if 'alg_bytes' in stages[n_]]
-            dom = max(cand, key=lambda n_: stages[n_]['ms'])
-            lps = stages[dom]['launches_per_step']
-            launch_ms = stages[dom]['ms'] / lps
-            launch_bytes = stages[dom]['alg_bytes'] / lps
-            achieved = launch_bytes / (launch_ms * 1e-3)
-            traffic, traffic_note = None, None
-            tfile = os.path.join(REPO, 'profiles', f'pmc_traffic_{args.config}.json')
-            if os.path.exists(tfile):
-                try:
-                    tj = json.load(open(tfile))
-                    traffic = tj.get(dom, {}).get('hbm_bytes_per_launch')
-                    if tj.get('_csrc_digest') != csrc_digest():
-                        traffic_note = (f'{os.path.basename(tfile)} was measured on other kernel sources (digest '
-                                        f'{tj.get("_csrc_digest")} vs {csrc_digest()}): stale, shown for orientation only')
-                except Exception:
-                    traffic = None
-            pipeline_b = b_alg(M, K, F, H, args.iters)
-            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved / 1e9, 1), 'peak': HBM_PEAK / 1e9,
-                        'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': traffic,
-                        'alg_bytes_per_launch': launch_bytes, 'avg_launch_ms': round(launch_ms, 4),
-                        'pipeline': {'B_alg_per_node_frame': pipeline_b,
-                                     'achieved_GBps': round(value / world * pipeline_b / 1e9, 1),
-                                     'frac': round(value / world * pipeline_b / HBM_PEAK, 4)}}
-            if traffic_note:
-                roofline['traffic_note'] = traffic_note
+            flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            all_ok = bool(flag.item() > 0.5)
+        else:
+            all_ok = ok_local
+        if not all_ok:
+            if ok_local:
+                extras[nm] = {'error': 'another rank failed this workload'}
+            continue
+        extras[nm] = merge_extras(extras[nm], env)
+        if not args.no_parity:
+            extras[nm]['parity_sample'] = finish_parity(tickets[nm], env)
+            if not extras[nm]['parity_sample']['ok']:
+                failures.append((nm, extras[nm]['parity_sample']['worst_rel_all_ranks']))
+        for k in ('seconds_local', 'units_local'):
+            extras[nm].pop(k, None)
+    if pool is not None:
+        pool.shutdown(wait=True)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(K, M, Ls, N)
-
-    exchange = None
-    if node_sharded:
-        # one all-gather per step-2 iteration: every rank receives the other ranks' z (R * (K - Kl) * T * F complex64)
-        per_gather = R * (K - Kl) * T * F * 8
-        exchange = {'collective': 'all_gather_into_tensor (RCCL)', 'gathers_per_step': args.iters,
-                    'bytes_received_per_rank_per_gather': per_gather,
-                    'bytes_per_peer_link_per_gather': R * Kl * T * F * 8,
-                    'ms_per_gather': (sum(gather_ms) / len(gather_ms)) if gather_ms else None,
-                    'link_GBps': (R * Kl * T * F * 8 / (sum(gather_ms) / len(gather_ms) * 1e-3) / 1e9) if (gather_ms and world > 1) else None,
-                    'note': 'xGMI is point-to-point: each of the W-1 peers sends its R*Kl*T*F*8-byte block over its own link'}
+        cpu = cpu_baseline(head_w['nodes'], head_w['mics'], args.length, head_w['n_fft'])
 
     if rank == 0:
-        shape = (K, M, N, args.iters, args.mask)
-        cfg_shape = CONFIGS[args.config]
-        is_cfg = shape == (cfg_shape['nodes'], cfg_shape['mics'], cfg_shape['n_fft'], cfg_shape['iters'], cfg_shape['mask'])
-        cfg_name = args.config if is_cfg else 'custom'
-        mask_desc = 'oracle irm1 mask' if args.mask == 'oracle' else 'CRNN masks in the loop (random weights, PyTorch-ROCm)'
-        par = (f'nodes of every room split over {world} GPU(s) ({Kl} per rank), one RCCL all-gather of z per step-2 iteration'
-               if node_sharded else f'rooms sharded over {world} GPU(s), no data-path collective')
         line = {
             'metric': 'STFT node-frames/s, whole MWF path (STFT->mask->cov->GEVD-MWF->z exchange->MWF->iSTFT)',
-            'value': value, 'unit': 'node-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if node_sharded else 'weak',
+            'value': head['value'], 'unit': 'node-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong' if node_sharded else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'x_realtime': x_rt,
-            'config': {'workload': f'{cfg_name}: {R} rooms{"" if node_sharded else "/GPU"} x {K} nodes x {M} mics, 16 kHz, L={Ls}, '
-                                   f'{N}-pt STFT hop {H}, {mask_desc}, two-step Tango (mask_for_z=local), outputs=enhanced'
-                                   + (f', ONLINE mode lambda=0.95 update_every={args.online_every}' if args.online_every else '')
-                                   + (f', {args.iters} step-2 iterations (DANSE-style)' if args.iters > 1 else ''),
-                       'launch': 'one hipGraph replay per step' if args.graph else 'eager kernel launches',
-                       'rooms_per_gpu': R, 'nodes': K, 'mics': M, 'length': Ls, 'n_fft': N, 'frames': T,
-                       'iters': args.iters, 'parallelism': par},
-            'roofline': roofline, 'cpu_baseline': cpu, 'parity_sample': parity, 'stages': stages,
+            'x_realtime': head['x_realtime'],
+            'config': head['config'],
+            'roofline': head['roofline'], 'cpu_baseline': cpu, 'parity_sample': parity, 'stages': head['stages'],
         }
-        if exchange:
-            line['exchange'] = exchange
+        if 'exchange' in head:
+            line['exchange'] = head['exchange']
+        if args.extra_names:
+            line['configs'] = extras
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()                    # rank 0 may still be in its per-stage timing / parity check: leave together
+        dist.barrier()                    # leave together
         dist.destroy_process_group()
-    if parity is not None and not parity['ok']:
-        print(f'PARITY FAILURE: worst relative error {parity["worst_rel"]:.3e} >= {parity["tol"]}', file=sys.stderr)
-        return 3
-    return 0
+    for nm, worst in failures:
+        print(f'PARITY FAILURE ({nm}): worst relative error over all ranks {worst:.3e} >= 1e-4', file=sys.stderr)
+    return 3 if failures else 0
 
 
 if __name__ == '__main__':

@@ -15,6 +15,7 @@ MASK_TYPES = {'irm': 0, 'ibm': 1, 'iam': 2}
 PAD_MODES = {'reflect': 0, 'constant': 1}
 FLAG_STAGED_STEP2 = 1
 FLAG_LAZY_SCRATCH = 2
+FLAG_NO_CHILDREN = 4
 
 
 class DiscoCfg(C.Structure):
@@ -50,7 +51,7 @@ PROTOTYPES = {
     'disco_set_option': (_int, [_vp, C.c_char_p, _int]),
     'disco_get_option': (_int, [_vp, C.c_char_p, C.POINTER(_int)]),
     'disco_stage_timing': (_int, [_vp, _int]),
-    'disco_stage_report': (_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int), _int]),
+    'disco_stage_report': (_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int64), _int]),
     'disco_dev_alloc': (_int, [_vp, _sz, C.POINTER(_vp)]),
     'disco_dev_free': (_int, [_vp, _vp]),
     'disco_h2d': (_int, [_vp, _vp, _vp, _sz, _vp]),

@@ -32,7 +32,8 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
 #undef X_
     if (!launched) {
         const int tiles = (ctx->F + 63) / 64;
-        int t_chunks = (int)std::min<long long>(std::max<long long>(1, (8192 + G * tiles - 1) / (G * tiles)), std::max(1, ctx->T / 8));
+        const long long Gg = (long long)ctx->geom_rooms * ctx->Kl;
+        int t_chunks = (int)std::min<long long>(std::max<long long>(1, (8192 + Gg * tiles - 1) / (Gg * tiles)), std::max(1, ctx->T / 8));
         while (G * tiles * t_chunks > 0x7ffffff0LL && t_chunks > 1) t_chunks >>= 1;
         const long long items_m = G * tiles * t_chunks;
         const dim3 grid_m((unsigned)((items_m + DISCO_APPLY_XCD - 1) / DISCO_APPLY_XCD * DISCO_APPLY_XCD));      // ids are dealt over the XCDs

@@ -59,6 +59,11 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     ctx->k0 = 0;
     ctx->Kl = cfg->nodes;
     ctx->zblk = cfg->nodes;
+    ctx->geom_rooms = cfg->rooms;
+    ctx->half[0] = ctx->half[1] = nullptr;
+    ctx->parent = nullptr;
+    ctx->side_stream = nullptr;
+    ctx->ev_fork = ctx->ev_join = nullptr;
     ctx->tune_runw = ctx->tune_cov_chunks = ctx->tune_step2_chunks = ctx->tune_pairs = 0;
     // per-context options (disco_set_option); the environment may preset them, and is read HERE only -- never inside a compute call
     for (int i = 0; i < DISCO_N_OPTIONS; ++i) {
@@ -107,13 +112,69 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
             return rc;
         }
     }
+    // large batches: the two half-batch children of the overlapped whole-path calls (their partial-sum blocks are sized now, too)
+    if (!(cfg->flags & DISCO_FLAG_NO_CHILDREN) && ctx->opt[DISCO_OPT_OVERLAP_SOLVES]) {
+        const int rc = disco_host::ensure_halves(ctx);
+        if (rc) {
+            snprintf(g_create_err, sizeof(g_create_err), "disco_create: %.480s", ctx->err);
+            disco_destroy(ctx);
+            return rc;
+        }
+    }
     *out = ctx;
     return 0;
 }
 
+namespace disco_host {
+// The overlapped form applies to batches that still fill the chip when halved (rooms x nodes >= 2048; option value 2 forces it for
+// any batch of >= 2 rooms: tests), when every node of a room is here.
+bool overlap_applies(const disco_ctx* ctx) {
+    const int o = ctx->opt[DISCO_OPT_OVERLAP_SOLVES];
+    if (!o || ctx->parent || ctx->cfg.rooms < 2 || sharded(ctx)) return false;
+    return o >= 2 || (long long)ctx->cfg.rooms * ctx->cfg.nodes >= 2048;
+}
+
+int ensure_halves(disco_ctx* ctx) {
+    if (!overlap_applies(ctx) || ctx->half[0]) return 0;
+    const int ra = ctx->cfg.rooms / 2, rb = ctx->cfg.rooms - ra;
+    for (int h = 0; h < 2; ++h) {
+        disco_cfg c = ctx->cfg;
+        c.rooms = h ? rb : ra;
+        c.flags |= DISCO_FLAG_NO_CHILDREN | DISCO_FLAG_LAZY_SCRATCH;
+        disco_ctx* ch = nullptr;
+        const int rc = disco_create(&ch, &c);
+        if (rc) return fail(ctx, rc, disco_last_error(nullptr));
+        ch->parent = ctx;
+        ch->geom_rooms = ctx->cfg.rooms;                   // the launch geometry of the whole batch
+        ch->tune_runw = ctx->tune_runw;
+        ch->tune_cov_chunks = ctx->tune_cov_chunks;
+        ch->tune_step2_chunks = ctx->tune_step2_chunks;
+        ch->tune_pairs = ctx->tune_pairs;
+        for (int i = 0; i < DISCO_N_OPTIONS; ++i) ch->opt[i] = ctx->opt[i];
+        ch->opt[DISCO_OPT_OVERLAP_SOLVES] = 0;
+        ch->stage_on = ctx->stage_on;
+        ctx->half[h] = ch;
+        if (!(ctx->cfg.flags & DISCO_FLAG_LAZY_SCRATCH)) {
+            const int rs = reserve_scratch(ch);
+            if (rs) return fail(ctx, rs, ch->err);
+        }
+    }
+    if (!ctx->side_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    return 0;
+}
+}  // namespace disco_host
+
 extern "C" void disco_destroy(disco_ctx* ctx) {
     if (!ctx) return;
     DevGuard dev_guard_(ctx->cfg.device);
+    for (int h = 0; h < 2; ++h) disco_destroy(ctx->half[h]);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     stage_clear(ctx);
     if (ctx->d_win) (void)hipFree(ctx->d_win);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
@@ -139,27 +200,46 @@ extern "C" int disco_stage_timing(disco_ctx* ctx, int enable) {
     DISCO_ENTER(ctx);
     stage_clear(ctx);
     ctx->stage_on = enable != 0;
+    for (int h = 0; h < 2; ++h)
+        if (ctx->half[h]) {
+            stage_clear(ctx->half[h]);
+            ctx->half[h]->stage_on = ctx->stage_on;
+        }
     return 0;
 }
 
-extern "C" int disco_stage_report(disco_ctx* ctx, char* names, float* total_ms, int* launches, int max_stages) {
+extern "C" int disco_stage_report(disco_ctx* ctx, char* names, float* total_ms, int* launches, int64_t* rooms, int max_stages) {
     DISCO_ENTER(ctx);
     if (max_stages < 0 || (max_stages > 0 && (!names || !total_ms || !launches)))
         return fail(ctx, DISCO_E_ARG, "disco_stage_report: bad argument");
     int n = 0;
-    for (auto& st : ctx->stages) {
-        if (n >= max_stages) break;
-        float ms = 0.f;
-        for (auto& e : st.evs) {
-            float d = 0.f;
-            HIPCHK(ctx, hipEventSynchronize(e.second));
-            HIPCHK(ctx, hipEventElapsedTime(&d, e.first, e.second));
-            ms += d;
+    // the context's own records, then those of its half-batch children merged in by name
+    disco_ctx* src[3] = {ctx, ctx->half[0], ctx->half[1]};
+    for (disco_ctx* c : src) {
+        if (!c) continue;
+        for (auto& st : c->stages) {
+            float ms = 0.f;
+            for (auto& e : st.evs) {
+                float d = 0.f;
+                HIPCHK(ctx, hipEventSynchronize(e.second));
+                HIPCHK(ctx, hipEventElapsedTime(&d, e.first, e.second));
+                ms += d;
+            }
+            int at = -1;
+            for (int i = 0; i < n; ++i)
+                if (!strncmp(names + 32 * i, st.name, 32)) at = i;
+            if (at < 0) {
+                if (n >= max_stages) continue;
+                at = n++;
+                snprintf(names + 32 * at, 32, "%s", st.name);
+                total_ms[at] = 0.f;
+                launches[at] = 0;
+                if (rooms) rooms[at] = 0;
+            }
+            total_ms[at] += ms;
+            launches[at] += (int)st.evs.size();
+            if (rooms) rooms[at] += (int64_t)st.evs.size() * c->cfg.rooms;
         }
-        snprintf(names + 32 * n, 32, "%s", st.name);
-        total_ms[n] = ms;
-        launches[n] = (int)st.evs.size();
-        ++n;
     }
     return n;
 }
@@ -175,6 +255,15 @@ extern "C" int disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int co
     ctx->tune_pairs = istft_pairs;
     ctx->pending_chunks = 0;           // partial sums of another geometry must not be re-used
     ctx->loc_M = 0;
+    for (int h = 0; h < 2; ++h)
+        if (ctx->half[h]) {
+            const int rc = disco_set_tuning(ctx->half[h], stft_frames_per_wave, cov_chunks, step2_chunks, istft_pairs);
+            if (rc) return fail(ctx, rc, ctx->half[h]->err);
+            if (!(ctx->cfg.flags & DISCO_FLAG_LAZY_SCRATCH)) {
+                const int rs = reserve_scratch(ctx->half[h]);
+                if (rs) return fail(ctx, rs, ctx->half[h]->err);
+            }
+        }
     if (!(ctx->cfg.flags & DISCO_FLAG_LAZY_SCRATCH)) return reserve_scratch(ctx);     // the new geometry may need larger blocks
     return 0;
 }
@@ -204,6 +293,9 @@ extern "C" int disco_set_option(disco_ctx* ctx, const char* key, int value) {
     const int i = option_index(key);
     if (i < 0) return fail(ctx, DISCO_E_ARG, "disco_set_option: unknown key");
     ctx->opt[i] = value;
+    if (i == DISCO_OPT_OVERLAP_SOLVES) return disco_host::ensure_halves(ctx);     // (may allocate: this is not a compute call)
+    for (int h = 0; h < 2; ++h)
+        if (ctx->half[h]) ctx->half[h]->opt[i] = value;
     return 0;
 }
 

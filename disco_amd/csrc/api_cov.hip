@@ -7,7 +7,7 @@ using namespace disco_host;
 
 namespace disco_host {
 int cov_chunks(const disco_ctx* ctx) {
-    const long long g = (long long)ctx->cfg.rooms * ctx->cfg.nodes;
+    const long long g = (long long)ctx->geom_rooms * ctx->cfg.nodes;
     long long c = (2048 + g - 1) / g;
     if (c > 8) c = 8;
     if (ctx->tune_cov_chunks > 0) c = ctx->tune_cov_chunks;

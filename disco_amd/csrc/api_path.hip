@@ -25,9 +25,34 @@ WsLayout ws_layout(const disco_ctx* ctx) {
     l.w = o;   o = align_up(o + G * ctx->F * Pmax * sizeof(c32));
     l.w2 = o;  o = align_up(o + G * ctx->F * Pmax * sizeof(c32));
     l.total = o;
+    // an overlapped call hands each half-batch child its own slice: the two slices must fit
+    if (ctx->half[0] && ctx->half[1]) l.total = std::max(l.total, align_up(ws_layout(ctx->half[0]).total) + ws_layout(ctx->half[1]).total);
     return l;
 }
 }  // namespace disco_host
+
+// The two half-batch children of a whole-path call, the second on the context's side stream: fork from / join to the caller's
+// stream with events (no host synchronisation, capturable).  call(child, first room of the child, its workspace slice, its
+// size, its stream) launches the child's whole path.
+template <class Call>
+static int run_halves(disco_ctx* ctx, char* ws, disco_stream s, Call&& call) {
+    hipStream_t s0 = (hipStream_t)s, s1 = ctx->side_stream;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s0));
+    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_fork, 0));
+    size_t room0 = 0;
+    int rc = 0;
+    for (int h = 0; h < 2 && !rc; ++h) {
+        disco_ctx* c = ctx->half[h];
+        const size_t need = ws_layout(c).total;
+        rc = call(c, room0, ws, need, (disco_stream)(h ? s1 : s0));
+        if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", c->err);
+        room0 += (size_t)c->cfg.rooms;
+        ws += align_up(need);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, s1));             // joined even after a failure: the caller's stream must not be left forked
+    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_join, 0));
+    return rc;
+}
 
 extern "C" size_t disco_workspace_bytes(const disco_ctx* ctx) { return ctx ? ws_layout(ctx).total : 0; }
 
@@ -91,6 +116,15 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     char* ws = nullptr;
     int rcw = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance");
     if (rcw) return rcw;
+    if (overlap_applies(ctx) && ctx->half[0]) {
+        const size_t K = c.nodes, TF = (size_t)ctx->T * ctx->F, sy = K * c.mics * c.length, sm = K * TF, so = K * c.length;
+        const bool same_mask = mask_w == mask_z;
+        return run_halves(ctx, ws, s, [&](disco_ctx* ch, size_t r0, char* wsc, size_t wsn, disco_stream st) {
+            const float* mz = mask_z + r0 * sm;
+            return disco_tango_enhance(ch, y + r0 * sy, mz, same_mask ? mz : mask_w + r0 * sm, out + r0 * so, z_y ? z_y + r0 * sm : nullptr,
+                                       yf ? yf + r0 * sm : nullptr, wsc, wsn, st);
+        });
+    }
     if (c.nodes > 1 && c.mics + c.nodes - 1 <= 8 && !(c.flags & DISCO_FLAG_STAGED_STEP2))
         return tango_enhance_fused(ctx, y, mask_z, mask_w, out, z_y, yf, ws, l, s);
     disco_c32* X = (disco_c32*)(ws + l.X);
@@ -202,13 +236,17 @@ RefLayout ref_layout(const disco_ctx* ctx) {
 extern "C" size_t disco_reference_workspace_bytes(const disco_ctx* ctx) { return ctx ? ref_layout(ctx).total : 0; }
 
 extern "C" size_t disco_owned_bytes(const disco_ctx* ctx) {
-    return ctx ? ctx->scratch_bytes + ctx->scratch2_bytes + ctx->own_ws_bytes + ctx->conv_ws_bytes : 0;
+    if (!ctx) return 0;
+    return ctx->scratch_bytes + ctx->scratch2_bytes + ctx->own_ws_bytes + ctx->conv_ws_bytes + disco_owned_bytes(ctx->half[0]) +
+           disco_owned_bytes(ctx->half[1]);
 }
 
 extern "C" int disco_reserve(disco_ctx* ctx, int own_workspace) {
     DISCO_ENTER(ctx);
     if (own_workspace < 0 || own_workspace > 2) return fail(ctx, DISCO_E_ARG, "disco_reserve: own_workspace must be 0, 1 or 2");
     int rc = reserve_scratch(ctx);
+    for (int h = 0; h < 2 && !rc; ++h)
+        if (ctx->half[h] && (rc = reserve_scratch(ctx->half[h]))) return fail(ctx, rc, ctx->half[h]->err);
     if (rc || !own_workspace) return rc;
     size_t need = ws_layout(ctx).total;
     if (own_workspace == 2) need = std::max(need, ref_layout(ctx).total);
@@ -376,6 +414,15 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     char* ws = nullptr;
     int rc = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance_iterated");
     if (rc) return rc;
+    if (overlap_applies(ctx) && ctx->half[0]) {
+        const size_t K = c.nodes, TF = (size_t)ctx->T * ctx->F, sy = K * c.mics * c.length, sm = K * TF, so = K * c.length;
+        const bool same_mask = mask_w == mask_z;
+        return run_halves(ctx, ws, s, [&](disco_ctx* ch, size_t r0, char* wsc, size_t wsn, disco_stream st) {
+            const float* mz = mask_z + r0 * sm;
+            return disco_tango_enhance_iterated(ch, y + r0 * sy, mz, same_mask ? mz : mask_w + r0 * sm, iters, out + r0 * so,
+                                                z_y ? z_y + r0 * sm : nullptr, yf ? yf + r0 * sm : nullptr, wsc, wsn, st);
+        });
+    }
     disco_c32* X = (disco_c32*)(ws + l.X);
     disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
     disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);

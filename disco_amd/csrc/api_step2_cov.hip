@@ -10,7 +10,7 @@ using namespace disco_host;
 // ---------------------------------------------------------------------------------------------------------
 namespace disco_host {
 int step2_chunks(const disco_ctx* ctx, int tiles_plus_1) {
-    const long long base = (long long)ctx->cfg.rooms * tiles_plus_1;
+    const long long base = (long long)ctx->geom_rooms * tiles_plus_1;
     long long c = (4096 + base - 1) / base;
     if (c > 8) c = 8;
     if (ctx->tune_step2_chunks > 0) c = ctx->tune_step2_chunks;

@@ -38,7 +38,7 @@ extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X,
     a.chunks = 1;
     const int n_seg = (c.length + c.hop - 1) / c.hop;
     // frame pairs per workgroup: as many as possible (<= 64) while leaving >= ~8192 waves (a workgroup has K of them)
-    const long long units = (long long)c.rooms * K;
+    const long long units = (long long)ctx->geom_rooms * K;
     const long long bpr_wanted = std::max<long long>(1, (8192 + units - 1) / units);
     int pairs = (int)(((n_seg + bpr_wanted - 1) / bpr_wanted + 2) / 2);
     pairs = std::min(64, std::max(4, pairs));
@@ -69,7 +69,7 @@ int step2_stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w_lo
     const int M = c.mics, K = c.nodes;
     if (!from_samples_shape(c)) return DISCO_E_UNSUPPORTED;
     const int n_seg = (c.length + c.hop - 1) / c.hop;
-    const long long units = (long long)c.rooms * K;
+    const long long units = (long long)ctx->geom_rooms * K;
     const long long bpr_wanted = std::max<long long>(1, (8192 + units - 1) / units);
     int pairs = (int)(((n_seg + bpr_wanted - 1) / bpr_wanted + 2) / 2);
     pairs = std::min(64, std::max(4, pairs));
@@ -95,7 +95,8 @@ int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, float* 
     const disco_cfg& c = ctx->cfg;
     const long long G = (long long)c.rooms * c.nodes;
     const int n_seg = (c.length + c.hop - 1) / c.hop;
-    const long long runs_wanted = std::max<long long>(1, (8192 + G - 1) / G);          // >= ~8192 waves
+    const long long Gg = (long long)ctx->geom_rooms * c.nodes;
+    const long long runs_wanted = std::max<long long>(1, (8192 + Gg - 1) / Gg);          // >= ~8192 waves
     int pairs = (int)(((n_seg + runs_wanted - 1) / runs_wanted + 2) / 2);
     pairs = std::min(64, std::max(4, pairs));
     if (ctx->tune_pairs > 0) pairs = ctx->tune_pairs;

@@ -39,7 +39,7 @@ static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, co
 // as possible (<= 80 frames) while leaving >= ~2048 workgroups for the chip
 namespace disco_host {
 int stft_cov_chunks(const disco_ctx* ctx, int* runw_out) {
-    const long long G = (long long)ctx->cfg.rooms * ctx->cfg.nodes;
+    const long long G = (long long)ctx->geom_rooms * ctx->cfg.nodes;
     const long long chunks_wanted = std::max<long long>(1, (2048 + G - 1) / G);
     int runw = (int)((ctx->T + STFT_WAVES * chunks_wanted - 1) / (STFT_WAVES * chunks_wanted));
     runw = std::min(80, std::max(8, runw));

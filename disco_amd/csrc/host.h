@@ -68,6 +68,13 @@ struct disco_ctx {
     int zblk;                        // layout of the exchanged-signal arguments Zs / Zn / Z (disco_set_z_blocks; default K = plain)
     int tune_runw, tune_cov_chunks, tune_step2_chunks, tune_pairs;   // disco_set_tuning overrides (0 = batch-size heuristic)
     int opt[DISCO_N_OPTIONS];        // disco_set_option values (DISCO_OPT_*)
+    int geom_rooms;                  // batch size the launch-geometry heuristics look at (cfg.rooms; a half-batch child: its parent's)
+    // two half-batch children (rooms split [0, R/2) and [R/2, R)) + the second stream / events of the overlapped whole-path calls
+    // (DISCO_OPT_OVERLAP_SOLVES): one half's solves run beside the other half's streaming kernels.  NULL when not in use.
+    disco_ctx* half[2];
+    disco_ctx* parent;               // set in a child
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
     // per-stage hipEvent timers of the whole-path entry points (disco_stage_timing / disco_stage_report)
     struct StageRec {
         char name[32];
@@ -201,6 +208,9 @@ int stft_cov_chunks(const disco_ctx* ctx, int* runw_out);
 int ensure_scratch(disco_ctx* ctx, size_t bytes);
 int ensure_scratch2(disco_ctx* ctx, size_t bytes);
 int reserve_scratch(disco_ctx* ctx);
+// half-batch children of the overlapped whole-path calls: created when the batch is large enough (or the option forces it)
+int ensure_halves(disco_ctx* ctx);
+bool overlap_applies(const disco_ctx* ctx);
 int acquire_ws(disco_ctx* ctx, void* workspace, size_t workspace_bytes, const WsLayout& l, char** ws_out, const char* who);
 
 // stages (each leaves its partial sums pending in the context; see the definitions)

@@ -241,6 +241,21 @@ class CRNN(nn.Module):
         return out
 
 
+def flops_per_frame(n_ch=1, n_freq=257, cnn_filters=(32, 64, 64), rnn_units=256, frame_to_pred=PRED_FRAME):
+    """Multiply-add FLOPs (2 per MAC) `predict_masks` spends per output frame of one signal: the three 3x3 convolutions evaluated
+    once over the sequence (not once per 21-frame window), the GRU steps that reach the selected output frame (8 for 'mid', 15 for
+    'last') as an input-projection GEMM + one recurrent GEMM per step after the first, and the output layer."""
+    chans = [n_ch, *cnn_filters]
+    macs, f = 0, n_freq
+    for i in range(len(cnn_filters)):
+        macs += f * chans[i + 1] * chans[i] * 9
+        f //= 4
+    steps = (WIN_LEN - 2 * len(cnn_filters)) // 2 + 1 if frame_to_pred == 'mid' else WIN_LEN - 2 * len(cnn_filters)
+    n_in = chans[-1] * f
+    macs += steps * n_in * 3 * rnn_units + (steps - 1) * rnn_units * 3 * rnn_units + rnn_units * n_freq
+    return 2 * macs
+
+
 def build_crnn(n_ch=1, device=None, state_dict=None):
     """CRNN with the constructor arguments of tango.py:124-129; optionally loads a reference checkpoint's
     `model_state_dict` (train.py:151-156)."""

@@ -13,10 +13,13 @@ def _c64(t):
     return torch.view_as_complex(t)
 
 
-def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk=64):
+def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk=64, mark=None):
     """eng: disco_amd.engine.Engine (rooms R, nodes K, mics M); y: torch float32 (R, K, M, L) on the engine's device.
     model_z: CRNN(n_ch=1); model_w: CRNN(n_ch=K) or None (= reuse mask_z, tango.py:388-389).
+    mark: optional callable(name) invoked after every phase (stft, crnn_z, cov1, solve1, apply1, crnn_w, step2_cov, solve2,
+    step2_apply_istft) -- bench.py records an event on the launch stream in it to time the phases.
     Returns out (R, K, L) torch float32 [, mask_z, mask_w (R, K, T, F)]."""
+    mark = mark or (lambda name: None)
     lib, ctx = eng.lib, eng.ctx
     R, K, M, L, T, F = eng.R, eng.K, eng.M, eng.Lsamp, eng.T, eng.F
     dev = y.device
@@ -24,18 +27,23 @@ def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk
     p = lambda t: t.data_ptr()
     X = torch.empty((R, K, T, F, M, 2), dtype=torch.float32, device=dev)
     eng._chk(lib.disco_stft(ctx, p(y), G, M, p(X), None))
+    mark('stft')
     Xc = _c64(X)                                                       # (R, K, T, F, M) complex64 view
     ref = eng.cfg.ref_mic
     mag_ref = Xc[..., ref].abs().reshape(G, 1, T, F)                   # |Y| at the reference mic (tango.py:338)
     mask_z = model_z.predict_masks(mag_ref, chunk=dnn_chunk).reshape(R, K, T, F).contiguous()
+    mark('crnn_z')
     eng._chk(lib.disco_cov_masked(ctx, p(X), p(mask_z), None, None, 0, M, None, None, None))
+    mark('cov1')
     w_loc = torch.empty((R, K, F, M, 2), dtype=torch.float32, device=dev)
     eng._chk(lib.disco_gevd_mwf_r1_pending(ctx, eng.cfg.mu, p(w_loc), None, None))
+    mark('solve1')
     if model_w is None or K == 1:
         mask_w = mask_z
     else:
         z = torch.empty((R, K, T, F, 2), dtype=torch.float32, device=dev)
         eng._chk(lib.disco_apply(ctx, p(X), None, p(w_loc), M, 1, p(z), None))
+        mark('apply1')
         zmag = _c64(z).abs()                                           # (R, K, T, F)
         mag0 = Xc[..., 0].abs()                                        # step 2 always looks at channel 0 (tango.py:391)
         inp = torch.empty((R, K, K, T, F), dtype=torch.float32, device=dev)
@@ -43,19 +51,24 @@ def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk
             inp[:, k, 0] = mag0[:, k]
             inp[:, k, 1:] = get_z_for_mask(zmag.transpose(0, 1), None, k, K, 'zs_hat').transpose(0, 1)
         mask_w = model_w.predict_masks(inp.reshape(G, K, T, F), chunk=dnn_chunk).reshape(R, K, T, F).contiguous()
+        mark('crnn_w')
     out = torch.empty((R, K, L), dtype=torch.float32, device=dev)
     if K == 1:
         # single node: step 2 repeats step 1 on the same statistics (tango.py K = 1) -> iSTFT of z
         z = torch.empty((R, K, T, F, 2), dtype=torch.float32, device=dev)
         eng._chk(lib.disco_apply(ctx, p(X), None, p(w_loc), M, 1, p(z), None))
         eng._chk(lib.disco_istft(ctx, p(z), G, p(out), None))
+        mark('apply_istft')
     else:
         eng._chk(lib.disco_step2_cov_fused(ctx, p(X), p(mask_w), p(w_loc), None, None, None, None))
+        mark('step2_cov')
         w_glo = torch.empty((R, K, F, M + K - 1, 2), dtype=torch.float32, device=dev)
         eng._chk(lib.disco_gevd_mwf_r1_pending(ctx, eng.cfg.mu, p(w_glo), None, None))
+        mark('solve2')
         rc = lib.disco_step2_apply_istft_fused(ctx, p(X), p(w_loc), p(w_glo), p(out), None)
         if rc != 0:                                                    # shapes outside the fused kernel: two calls
             yf = torch.empty((R, K, T, F, 2), dtype=torch.float32, device=dev)
             eng._chk(lib.disco_step2_apply_fused(ctx, p(X), p(w_loc), p(w_glo), None, p(yf), None))
             eng._chk(lib.disco_istft(ctx, p(yf), G, p(out), None))
+        mark('step2_apply_istft')
     return (out, mask_z, mask_w) if want_masks else out

@@ -246,14 +246,16 @@ class Engine:
         self._chk(self.lib.disco_stage_timing(self.ctx, int(bool(enable))))
 
     def stage_report(self, max_stages=32):
-        """-> {stage: (total_ms, launches)} for everything recorded since stage_timing(True); waits for the events."""
+        """-> {stage: (total_ms, launches, rooms)} for everything recorded since stage_timing(True); waits for the events.
+        rooms = rooms processed summed over the launches (an overlapped call launches every stage once per half-batch)."""
         names = C.create_string_buffer(32 * max_stages)
         ms = (C.c_float * max_stages)()
         cnt = (C.c_int * max_stages)()
-        n = self.lib.disco_stage_report(self.ctx, names, ms, cnt, max_stages)
+        rooms = (C.c_int64 * max_stages)()
+        n = self.lib.disco_stage_report(self.ctx, names, ms, cnt, rooms, max_stages)
         if n < 0:
             self._chk(n)
-        return {names.raw[32 * i:32 * i + 32].split(b'\0', 1)[0].decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+        return {names.raw[32 * i:32 * i + 32].split(b'\0', 1)[0].decode(): (float(ms[i]), int(cnt[i]), int(rooms[i])) for i in range(n)}
 
     def sync(self):
         self._chk(self.lib.disco_sync(self.ctx, self.stream))

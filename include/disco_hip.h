@@ -52,6 +52,9 @@ extern "C" {
 /* disco_cfg.flags: do not size the covariance partial-sum blocks at disco_create; they are then allocated by the first call
  * that needs them (a hipMalloc inside that call).  For contexts that only ever run the transforms / masks / metrics. */
 #define DISCO_FLAG_LAZY_SCRATCH 2
+/* disco_cfg.flags: never create the half-batch children of the overlapped whole-path calls (option "overlap_solves"), whatever the
+ * batch size: the context then owns one set of partial-sum blocks only. */
+#define DISCO_FLAG_NO_CHILDREN 4
 
 #define DISCO_PAD_REFLECT  0   /* librosa < 0.10 (the reference's era)  */
 #define DISCO_PAD_CONSTANT 1   /* librosa >= 0.10                        */
@@ -136,8 +139,11 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *   "room_cov"           (DISCO_ROOM_COV, 1)   wide shapes: z + step-2 statistics of a whole room in one pass ("room_cov2") instead of
  *                         disco_apply + disco_cov_masked ("apply1" + "cov2")
  *   "room_dma"           (DISCO_ROOM_DMA, 1)   that pass on its LDS-DMA ring ("room_cov2"); 0: register-staged ("room_cov2_reg")
- *   "overlap_solves"     (DISCO_OVERLAP_SOLVES, 1)  whole-path calls on large batches run as two half-batches on two streams so that one
- *                         half's solves overlap the other half's streaming kernels (stages then appear twice per step)
+ *   "overlap_solves"     (DISCO_OVERLAP_SOLVES, 1)  disco_tango_enhance / _iterated on batches of rooms x nodes >= 2048 run as two
+ *                         half-batches, the second on an internal stream forked from / joined to the caller's with events (still one
+ *                         capturable launch sequence): one half's solves overlap the other half's streaming kernels.  Each stage
+ *                         then shows 2 launches of R/2 rooms.  2: force it for any batch of >= 2 rooms (tests); 0: off.  The
+ *                         half-batch contexts (own partial-sum blocks) are created by disco_create / disco_set_option
  *   "solve_f32"          (DISCO_SOLVE_F32, 1)  group solver (P >= 5): float32 squarings + float64 polish; 0: float64 throughout
  * Unknown key: DISCO_E_ARG. */
 int  disco_set_option(disco_ctx* ctx, const char* key, int value);
@@ -147,10 +153,11 @@ int  disco_get_option(const disco_ctx* ctx, const char* key, int* value);
  * while enabled, every stage they launch (STFT+covariance, solves, filter passes, iSTFT ...) is bracketed by two hipEvents on
  * the call's stream.  disco_stage_timing(ctx, 1) clears and starts, (ctx, 0) clears and stops.  disco_stage_report waits for
  * the recorded events and returns the number of distinct stages n <= max_stages, with names[i*32 .. i*32+31] (NUL-terminated),
- * total_ms[i] (sum over the recorded launches) and launches[i]; all three are HOST arrays.  Nothing is timed, recorded or
- * synchronised while disabled (the default). */
+ * total_ms[i] (sum over the recorded launches), launches[i] and rooms[i] (rooms processed, summed over the launches: a stage of the
+ * iterated scheme runs twice over the whole batch, a stage of an overlapped call once over each half; may be NULL); all HOST arrays.
+ * Nothing is timed, recorded or synchronised while disabled (the default). */
 int  disco_stage_timing(disco_ctx* ctx, int enable);
-int  disco_stage_report(disco_ctx* ctx, char* names, float* total_ms, int* launches, int max_stages);
+int  disco_stage_report(disco_ctx* ctx, char* names, float* total_ms, int* launches, int64_t* rooms, int max_stages);
 
 /* ---- plain device-memory helpers (so a numpy-only host can drive the library without torch) -------- */
 int  disco_dev_alloc(disco_ctx* ctx, size_t bytes, void** dptr);

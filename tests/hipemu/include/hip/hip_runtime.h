@@ -323,6 +323,12 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)std::malloc(1); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+// launches are synchronous here, so a second stream and cross-stream events order trivially
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { *st = (hipStream_t)std::malloc(1); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t st) { std::free(st); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)std::malloc(1); return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }

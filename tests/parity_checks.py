@@ -905,3 +905,40 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
                     errs['z_oracle'] = max(errs.get('z_oracle', 0.0), relerr(res['1'][3][r, k].T, o['z_y'][k]))
     assert errs['yf_oracle'] < tol and errs['out_oracle'] < tol and errs['z_oracle'] < tol, errs
     return errs
+
+
+def check_overlapped_halves(make_engine, K=2, M=2, L=6000, n_fft=512, R=3, iters=1):
+    """Option "overlap_solves" (include/disco_hip.h): the whole-path calls run the batch as two half-batch children, the second on the
+    context's side stream.  Rooms are independent and the children keep the launch geometry of the whole batch, so the outputs
+    must equal the plain call's BIT FOR BIT; the stage report shows two launches per stage covering R rooms together; nothing is
+    allocated by the calls (the children's partial-sum blocks are sized with the context); the option is per context."""
+    from disco_amd import synth
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    plain = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    plain.set_option('overlap_solves', 0)
+    over = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    over.set_option('overlap_solves', 2)                      # 2: also for batches far too small to be worth it
+    assert plain.get_option('overlap_solves') == 0 and over.get_option('overlap_solves') == 2
+    m = plain.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, plain.T, plain.F).numpy()
+    over.reserve(1)
+    own = over.owned_bytes()
+    res = {}
+    for name, e in (('plain', plain), ('over', over)):
+        e.stage_timing(True)
+        if iters > 1:
+            out, yf = e.tango_enhance_iterated(y, m, iters=iters)
+            z = None
+        else:
+            out, z, yf = e.tango_enhance(y, m)
+        rep = e.stage_report()
+        e.stage_timing(False)
+        out_enh = e.tango_enhance(y, m, want_z=False, want_yf=False)[0].numpy() if iters == 1 else None
+        res[name] = (out.numpy(), None if z is None else z.numpy(), yf.numpy(), out_enh, rep)
+    assert over.owned_bytes() == own, (over.owned_bytes(), own)
+    for a, b in zip(res['plain'][:4], res['over'][:4]):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    rp, ro = res['plain'][4], res['over'][4]
+    assert set(rp) == set(ro), (set(rp), set(ro))
+    for nm in rp:
+        assert ro[nm][1] == 2 * rp[nm][1] and ro[nm][2] == rp[nm][2] == rp[nm][1] * R, (nm, rp[nm], ro[nm])
+    return {nm: ro[nm][1:] for nm in ro}

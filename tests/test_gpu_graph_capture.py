@@ -29,14 +29,17 @@ def _oracle_time_outputs(y, s, n, n_fft, iters):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('K,M,n_fft,iters', [(4, 4, 512, 1), (1, 4, 512, 1), (3, 2, 1024, 2)])
-def test_whole_path_replayed_from_a_hip_graph(K, M, n_fft, iters):
+@pytest.mark.parametrize('K,M,n_fft,iters,overlap', [(4, 4, 512, 1, 0), (1, 4, 512, 1, 0), (3, 2, 1024, 2, 0), (4, 4, 512, 1, 2), (3, 2, 1024, 2, 2)])
+def test_whole_path_replayed_from_a_hip_graph(K, M, n_fft, iters, overlap):
+    """overlap = 2: the overlapped form (two half-batches, the second on the context's side stream forked from / joined to the
+    capturing stream with events) must capture and replay as well."""
     import torch
     lib = _lib.load()
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
     R, L = 3, 24000
     eng = Engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft, lib=lib)
+    eng.set_option('overlap_solves', overlap)
     eng.reserve(1)
     T, F, G = eng.T, eng.F, R * K
     y = torch.empty((R, K, M, L), dtype=torch.float32, device=dev)

@@ -237,3 +237,10 @@ def test_no_allocation_in_compute_calls(make_engine):
 def test_room_cov(make_engine, K, M, n_fft, L, tuning):
     """k_room_cov (csrc/k_room.h) against the staged route it replaces (DISCO_ROOM_COV=0) and against the float64 oracle."""
     print(pc.check_room_cov(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M > 32 else 2, tuning=tuning))
+
+
+@pytest.mark.parametrize('K,M,n_fft,iters,R', [(4, 4, 512, 1, 5), (1, 4, 512, 1, 4), (8, 8, 1024, 2, 2), (2, 8, 512, 2, 3)])
+def test_overlapped_halves(make_engine, K, M, n_fft, iters, R):
+    """disco_set_option("overlap_solves"): the whole-path calls as two half-batch children, the second on the context's side stream
+    (fork / join with events): bit-identical to the plain call, two launches per stage, no allocation."""
+    print(pc.check_overlapped_halves(make_engine, K=K, M=M, L=20000, n_fft=n_fft, R=R, iters=iters))

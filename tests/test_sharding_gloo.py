@@ -209,6 +209,12 @@ def test_bench_self_launches_ranks():
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1 and lines[0]['n_gpus'] == 2                      # one line, from rank 0, of a 2-rank job
     assert lines[0]['value'] == pytest.approx((1000.0 + 2000.0) / 0.6)     # sum of units / max of times over the ranks
+    # EVERY rank checks rooms of its own batch; the line carries each rank's rooms / device and the worst error over all ranks
+    ps = lines[0]['parity_sample']
+    assert ps['worst_rel_all_ranks'] == pytest.approx(2e-6) and ps['worst_rel'] == pytest.approx(1e-6) and ps['ok']
+    assert [r['rank'] for r in ps['ranks']] == [0, 1] and [r['device'] for r in ps['ranks']] == [0, 1]
+    assert ps['ranks'][0]['rooms_checked'] == [0, 4, 9] and ps['ranks'][1]['first_room'] == 10
+    assert len(ps['ranks'][1]['rooms_checked']) == 1 and 10 <= ps['ranks'][1]['rooms_checked'][0] < 20
     # a world size that contradicts --gpus is an error, not a silent single-rank run
     p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '1', '--selftest-launch'],
                        env=dict(env, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0'), capture_output=True, text=True, timeout=120)
