@@ -308,12 +308,12 @@ class TorchStageMarks:
         e.record()
         self.ev.append((name, e))
 
-    def report(self):
+    def report(self, rooms):
         self.torch.cuda.synchronize()
         out = {}
         for (_, a), (name, b) in zip(self.ev[:-1], self.ev[1:]):
-            ms, n = out.get(name, (0.0, 0))
-            out[name] = (ms + a.elapsed_time(b), n + 1)
+            ms, n, r = out.get(name, (0.0, 0, 0))
+            out[name] = (ms + a.elapsed_time(b), n + 1, r + rooms)
         return out
 
 
@@ -430,6 +430,9 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
         src = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
         dst = torch.empty_like(src)
         torch.neg(src, out=dst)             # 4 GiB read + 4 GiB written by ONE elementwise kernel (a plain copy_ goes to the DMA engines)
+        # the same bytes with ONE dword per lane and load (the access width of the STFT kernels' sample reads): copy, then read-only
+        eng._chk(lib.disco_selftest_stream(eng.ctx, src.data_ptr(), dst.data_ptr(), src.numel(), 1, None))
+        eng._chk(lib.disco_selftest_stream(eng.ctx, src.data_ptr(), dst.data_ptr(), src.numel(), 0, None))
         torch.cuda.synchronize()
         del src, dst
     for _ in range(warmup):
@@ -479,7 +482,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
             if mask_kind == 'crnn':
                 marks = TorchStageMarks(torch)
                 eager_step(marks)
-                per_rep.append(marks.report())
+                per_rep.append(marks.report(R))
             else:
                 eng.stage_timing(True)
                 eager_step()                    # (a captured graph carries no events: the stage pass always launches eagerly)
@@ -491,14 +494,17 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
         for nm in per_rep[0]:
             ms_list = sorted(r_[nm][0] for r_ in per_rep if nm in r_)
             per_step = ms_list[len(ms_list) // 2] if len(ms_list) % 2 else 0.5 * (ms_list[len(ms_list) // 2 - 1] + ms_list[len(ms_list) // 2])
-            launches = per_rep[0][nm][1]
-            ent = {'ms': round(per_step, 4), 'launches_per_step': float(launches), 'ms_min': round(ms_list[0], 4), 'ms_max': round(ms_list[-1], 4)}
+            launches, rooms_done = per_rep[0][nm][1], per_rep[0][nm][2]
+            # rooms_done: rooms processed by all launches of the stage in one step (an iterated stage runs twice over the batch, an
+            # overlapped call launches every stage once per half-batch)
+            ent = {'ms': round(per_step, 4), 'launches_per_step': float(launches), 'rooms_per_step': int(rooms_done),
+                   'ms_min': round(ms_list[0], 4), 'ms_max': round(ms_list[-1], 4)}
             if nm in kab:
-                ent['alg_bytes'] = kab[nm] * R * K * T * launches     # per step (all launches of the stage)
+                ent['alg_bytes'] = kab[nm] * rooms_done * K * T        # per step (all launches of the stage)
                 ent['GBps'] = round(ent['alg_bytes'] / (per_step * 1e-3) / 1e9, 1)
             if nm in ('crnn_z', 'crnn_w'):
                 from disco_amd.dnn.crnn import flops_per_frame
-                ent['flops'] = flops_per_frame(1 if nm == 'crnn_z' else K) * R * K * T
+                ent['flops'] = flops_per_frame(1 if nm == 'crnn_z' else K) * rooms_done * K * T
                 ent['TFLOPs'] = round(ent['flops'] / (per_step * 1e-3) / 1e12, 2)
             stages[nm] = ent
         pipeline_b = b_alg(M, K, F, H, iters)

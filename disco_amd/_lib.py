@@ -86,6 +86,7 @@ PROTOTYPES = {
     'disco_tango_reference': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, C.POINTER(DiscoRefOutputs), _vp, _sz, _vp]),
     'disco_tango_enhance_iterated': (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     'disco_online_mwf': (_int, [_vp, _vp, _vp, _vp, _int, _f, _f, _int, _f, _vp, _vp, _vp]),
+    'disco_selftest_stream': (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     'disco_selftest_pk': (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'disco_tango_online': (_int, [_vp, _vp, _vp, _vp, _f, _int, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

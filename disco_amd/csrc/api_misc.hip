@@ -46,6 +46,16 @@ extern "C" int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco
     return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
 }
 
+extern "C" int disco_selftest_stream(disco_ctx* ctx, const float* src, float* dst, int64_t n, int write, disco_stream s) {
+    DISCO_ENTER(ctx);
+    if (!src || !dst || n < 1) return fail(ctx, DISCO_E_ARG, "disco_selftest_stream: bad argument");
+    if (write)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_stream<true>), dim3(256 * 16), dim3(256), 0, (hipStream_t)s, src, dst, (long long)n);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_stream<false>), dim3(256 * 16), dim3(256), 0, (hipStream_t)s, src, dst, (long long)n);
+    return check_launch(ctx, "k_selftest_stream");
+}
+
 extern "C" int disco_crnn_windows(disco_ctx* ctx, const float* feat, int64_t B, int C, int Tp, int T, int W, int n_keep, float* out,
                                   disco_stream s) {
     if (!feat || !out || B < 1 || C < 1 || T < 1 || W < 1 || Tp < T + W - 1 || n_keep < 4 || n_keep % 4 || n_keep > C * W * 4 ||

@@ -197,6 +197,33 @@ static __global__ void k_maxpool_last4(const float* __restrict__ x, const float*
     }
 }
 
+// Streaming kernel of KNOWN traffic with the access width of the STFT kernels' sample reads: every lane moves ONE dword per
+// instruction (256 B per wave load), UNROLL independent loads in flight.  write = 0: read-only (one float per workgroup is stored).
+// Calibrates the HBM counters (FETCH_SIZE / WRITE_SIZE) for 4-byte-per-lane loads, which torch's 16-byte-vectorised elementwise
+// kernels do not exercise (tools/pmc_traffic.py).
+template <bool write>
+__global__ __launch_bounds__(256) void k_selftest_stream(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    constexpr int UNROLL = 8;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+        float v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (write) dst[i + u * stride] = v[u];
+            else acc += v[u];
+        }
+    }
+    for (; i < n; i += stride) {
+        if (write) dst[i] = src[i];
+        else acc += src[i];
+    }
+    if (!write && acc == 123.456f) dst[blockIdx.x] = acc;      // keeps the loads alive; practically never taken
+}
+
 // The recurrent layer's input windows (crnn.py:59 `.view`): out[(b T + t) * n_keep + e] = feat[b][c][t + w][fy] with
 // e = (c W + w) 4 + fy < n_keep -- the leading n_keep floats of window t's (C, W, 4) block, moved 16 bytes at a time.
 // feat [B][C][Tp][4] (Tp >= T + W - 1), n_keep a multiple of 4.

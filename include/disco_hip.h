@@ -419,6 +419,11 @@ int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorptio
  * it pins the instruction encodings against their C++ statement, which is what the CPU-side kernel tests execute.)
  * a, b, c: [n] complex64 operands -> out_hw, out_ref: [n][DISCO_PK_SELFTEST_OPS] complex64, the same operations through
  * the instruction forms and through plain C++.  ctx may be NULL. */
+/* Streaming kernel of known traffic with ONE dword per lane and instruction -- the access width of the STFT kernels' sample reads --
+ * for calibrating HBM traffic counters (no reference counterpart): write != 0 copies src[0:n] to dst[0:n] (4n bytes read, 4n written);
+ * write == 0 only reads (dst needs >= 4096 floats and is practically never written). */
+int disco_selftest_stream(disco_ctx* ctx, const float* src, float* dst, int64_t n, int write, disco_stream s);
+
 #define DISCO_PK_SELFTEST_OPS 16
 int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco_c32* b, const disco_c32* c, int64_t n,
                       disco_c32* out_hw, disco_c32* out_ref, disco_stream s);

@@ -2,7 +2,7 @@
 TAG=${1:-r01_f}
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
-B="python bench.py ${BARGS} --no-parity --steps 1 --warmup 0 --no-cpu-baseline --no-stage-timing"
+B="python bench.py ${BARGS} --extras none --no-parity --steps 1 --warmup 0 --no-cpu-baseline --no-stage-timing"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d gpurun_out/pmc -o alu1 -- $B > gpurun_out/pmc_alu1.log 2>&1; echo "alu1 rc $?"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc -o alu2 -- $B > gpurun_out/pmc_alu2.log 2>&1; echo "alu2 rc $?"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY -d gpurun_out/pmc -o alu3 -- $B > gpurun_out/pmc_alu3.log 2>&1; echo "alu3 rc $?"

@@ -47,6 +47,13 @@ for k, v in raw.items():
         out['_calibration']['torch_neg_4GiB'] = dict({c: x['per_dispatch'] * 1024 for c, x in v.items()}, known_bytes_each_way_per_dispatch=2 * 2 ** 30,
                                                       note='torch splits the 4 GiB tensor into two dispatches of 2 GiB (32-bit indexing): FETCH_SIZE x2 and WRITE_SIZE x1 reproduce 2 GiB each way',
                                                       kernel=k[:80])
+    if 'k_selftest_stream<' in k:
+        # bench.py --pmc-calibrate: 2^30 floats moved ONE dword per lane and load (the access width of the STFT kernels' sample reads)
+        wr = 'k_selftest_stream<true>' in k
+        out['_calibration']['dword_per_lane_copy_4GiB' if wr else 'dword_per_lane_read_4GiB'] = dict(
+            {c: x['per_dispatch'] * 1024 for c, x in v.items()}, known_bytes_read_per_dispatch=4 * 2 ** 30,
+            known_bytes_written_per_dispatch=4 * 2 ** 30 if wr else 0, kernel=k[:80])
+        continue
     if 'disco::' not in k:
         continue
     name = k.replace('void disco::', '')
