@@ -376,6 +376,13 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
         torch.manual_seed(0)
         model_z = build_crnn(1, device=dev)
         model_w = build_crnn(K, device=dev) if K > 1 else None
+        # random weights leave every mask within a few percent of 0.5, i.e. Rss ~ Rnn in every bin: a degenerate eigenproblem whose
+        # dominant vector no two implementations agree on.  Spreading the output layer (as tests/test_gpu_crnn_inloop.py does) gives
+        # masks over (0, 1) like a trained network's, at identical cost.
+        with torch.no_grad():
+            for mdl in (model_z, model_w):
+                if mdl is not None:
+                    mdl.ff.layers[0].weight.mul_(40.0)
 
     gather_events = []                     # (start, stop) torch events around every all-gather of z (--shard nodes)
 

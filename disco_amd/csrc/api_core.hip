@@ -163,6 +163,8 @@ int ensure_halves(disco_ctx* ctx) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        ctx->step_events.resize(64, nullptr);
+        for (auto& e : ctx->step_events) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     return 0;
 }
@@ -175,6 +177,8 @@ extern "C" void disco_destroy(disco_ctx* ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (auto& e : ctx->step_events)
+        if (e) (void)hipEventDestroy(e);
     stage_clear(ctx);
     if (ctx->d_win) (void)hipFree(ctx->d_win);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);

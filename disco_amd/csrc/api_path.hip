@@ -1,5 +1,7 @@
 // libdisco_hip.so -- host side of the C ABI declared in include/disco_hip.h (gfx950 only): whole-path entry points
 #include "host.h"
+
+#include <functional>
 #include "k_apply.h"
 #include "k_cov.h"
 #include "k_stft.h"
@@ -31,39 +33,81 @@ WsLayout ws_layout(const disco_ctx* ctx) {
 }
 }  // namespace disco_host
 
-// The two half-batch children of a whole-path call, the second on the context's side stream: fork from / join to the caller's
-// stream with events (no host synchronisation, capturable).  call(child, first room of the child, its workspace slice, its
-// size, its stream) launches the child's whole path.
-template <class Call>
-static int run_halves(disco_ctx* ctx, char* ws, disco_stream s, Call&& call) {
+// ---- a whole-path call as a list of steps -----------------------------------------------------------------------------------
+// Every whole-path entry point builds the list of its stages (one kernel family each) and runs it: in order on the caller's stream,
+// or -- the overlapped form, DISCO_OPT_OVERLAP_SOLVES -- software-pipelined over the two half-batch children:
+//     caller's stream:  stft_cov1(A) stft_cov1(B) step2_cov(A) step2_cov(B) apply(A) apply(B)
+//     side stream    :               solve1(A)    solve1(B)    solve2(A)    solve2(B)
+// The streaming kernels keep the chip to themselves one after the other (a half-batch still fills it), and every solve -- a compute
+// kernel that moves almost no data -- runs beside the OTHER half's streaming kernel instead of between two of them.  A step waits
+// for its own child's previous step through an event when that one ran on the other stream; nothing synchronises with the host,
+// and the side stream is forked from / joined to the caller's, so the sequence can still be captured into one hipGraph.
+namespace {
+struct Step {
+    const char* name;                          // stage name for the timers; nullptr: the callee brackets its own stages
+    bool side;                                 // a solve: runs on the side stream of an overlapped call
+    std::function<int(disco_stream)> run;
+};
+using Steps = std::vector<Step>;
+
+int run_step(disco_ctx* ctx, Step& x, disco_stream st) { return x.name ? STAGE(ctx, st, x.name, x.run(st)) : x.run(st); }
+
+int run_steps(disco_ctx* ctx, Steps& steps, disco_stream s) {
+    for (auto& x : steps) {
+        const int rc = run_step(ctx, x, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int run_pipelined(disco_ctx* ctx, Steps (&steps)[2], disco_stream s) {
     hipStream_t s0 = (hipStream_t)s, s1 = ctx->side_stream;
+    const size_t n = steps[0].size();
+    if (steps[1].size() != n || 2 * n > ctx->step_events.size()) return fail(ctx, DISCO_E_ARG, "overlapped call: step lists do not match");
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s0));
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_fork, 0));
-    size_t room0 = 0;
     int rc = 0;
-    for (int h = 0; h < 2 && !rc; ++h) {
-        disco_ctx* c = ctx->half[h];
-        const size_t need = ws_layout(c).total;
-        rc = call(c, room0, ws, need, (disco_stream)(h ? s1 : s0));
-        if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", c->err);
-        room0 += (size_t)c->cfg.rooms;
-        ws += align_up(need);
-    }
+    for (size_t i = 0; i < n && !rc; ++i)
+        for (int h = 0; h < 2 && !rc; ++h) {
+            disco_ctx* ch = ctx->half[h];
+            Step& x = steps[h][i];
+            hipStream_t cur = x.side ? s1 : s0;
+            if (i > 0 && steps[h][i - 1].side != x.side) HIPCHK(ctx, hipStreamWaitEvent(cur, ctx->step_events[2 * (i - 1) + h], 0));
+            rc = run_step(ch, x, (disco_stream)cur);
+            if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", ch->err);
+            // the child's next step runs on the other stream: mark the end of this one there
+            if (!rc && i + 1 < n && steps[h][i + 1].side != x.side) HIPCHK(ctx, hipEventRecord(ctx->step_events[2 * i + h], cur));
+        }
     HIPCHK(ctx, hipEventRecord(ctx->ev_join, s1));             // joined even after a failure: the caller's stream must not be left forked
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_join, 0));
     return rc;
 }
 
-extern "C" size_t disco_workspace_bytes(const disco_ctx* ctx) { return ctx ? ws_layout(ctx).total : 0; }
-
-static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
-                               disco_c32* z_y, disco_c32* yf, char* ws, const WsLayout& l, disco_stream s);
-
-static int solve_from_partials(disco_ctx* ctx, int chunks, int P, disco_c32* w, disco_stream s) {
-    (void)chunks;
-    (void)P;                     // geometry is the pending state the covariance call just recorded
-    return disco_gevd_mwf_r1_pending(ctx, ctx->cfg.mu, w, nullptr, s);
+// arguments of one (half-)batch of a whole-path call
+struct PathArgs {
+    const float *y, *mask_z, *mask_w;
+    float* out;
+    disco_c32 *z_y, *yf;
+    char* ws;
+};
+// the slice of the caller's arrays / workspace that child h (rooms [r0, r0 + rooms_h)) works on
+PathArgs child_args(const disco_ctx* ctx, const PathArgs& a, int h) {
+    const disco_cfg& c = ctx->cfg;
+    const size_t r0 = h ? (size_t)ctx->half[0]->cfg.rooms : 0;
+    const size_t K = c.nodes, TF = (size_t)ctx->T * ctx->F, sy = K * c.mics * c.length, sm = K * TF, so = K * c.length;
+    PathArgs b;
+    b.y = a.y + r0 * sy;
+    b.mask_z = a.mask_z + r0 * sm;
+    b.mask_w = a.mask_w == a.mask_z ? b.mask_z : a.mask_w + r0 * sm;
+    b.out = a.out + r0 * so;
+    b.z_y = a.z_y ? a.z_y + r0 * sm : nullptr;
+    b.yf = a.yf ? a.yf + r0 * sm : nullptr;
+    b.ws = a.ws + (h ? align_up(ws_layout(ctx->half[0]).total) : 0);
+    return b;
 }
+}  // namespace
+
+extern "C" size_t disco_workspace_bytes(const disco_ctx* ctx) { return ctx ? ws_layout(ctx).total : 0; }
 
 namespace disco_host {
 // caller's workspace if given (size-checked), else the context's own (grown on demand)
@@ -106,100 +150,107 @@ int reserve_scratch(disco_ctx* ctx) {
 }
 }  // namespace disco_host
 
+// offline_tango's y branch as a list of steps (tango.py:326-450 + 528); `a` names this context's slice of the batch
+static void enhance_steps(disco_ctx* ctx, const PathArgs& a, Steps& st) {
+    const disco_cfg& c = ctx->cfg;
+    const WsLayout l = ws_layout(ctx);
+    const float *y = a.y, *mask_z = a.mask_z, *mask_w = a.mask_w;
+    float* out = a.out;
+    disco_c32 *z_y = a.z_y, *yf = a.yf;
+    disco_c32* X = (disco_c32*)(a.ws + l.X);
+    disco_c32* z = z_y ? z_y : (disco_c32*)(a.ws + l.z);
+    disco_c32* yo = yf ? yf : (disco_c32*)(a.ws + l.yf);
+    disco_c32* w = (disco_c32*)(a.ws + l.w);
+    disco_c32* w2 = (disco_c32*)(a.ws + l.w2);
+    const int64_t G = (int64_t)c.rooms * c.nodes;
+    const int M = c.mics, P2 = c.mics + c.nodes - 1;
+    const bool same_mask = mask_w == mask_z;
+    auto solve_pending = [ctx](disco_c32* w_out) { return [ctx, w_out](disco_stream s) { return disco_gevd_mwf_r1_pending(ctx, ctx->cfg.mu, w_out, nullptr, s); }; };
+
+    if (c.nodes == 1 && same_mask && !z_y && !yf && c.n_fft == 512 && M <= 4) {
+        // single node, enhanced output only (config C2): nothing is materialised -- one pass over the samples for the
+        // statistics, one for filter + iSTFT with the spectra recomputed (get_z_signals.py:274-315 + tango.py:528)
+        st.push_back({nullptr, false, [=](disco_stream s) { int ch = 1; return stft_cov_partials(ctx, y, mask_z, nullptr, &ch, s, false); }});
+        st.push_back({"solve1", true, solve_pending(w)});
+        st.push_back({"stft_apply_istft", false, [=](disco_stream s) { return stft_apply_istft(ctx, y, w, out, s); }});
+        return;
+    }
+    // step 1 (tango.py:326-376): STFT + covariance in one pass, solve straight from the partial sums
+    st.push_back({nullptr, false, [=](disco_stream s) { int ch = 1; return stft_cov_partials(ctx, y, mask_z, X, &ch, s); }});
+    st.push_back({"solve1", true, solve_pending(w)});
+
+    if (c.nodes > 1 && P2 <= 8 && !(c.flags & DISCO_FLAG_STAGED_STEP2)) {
+        // step 2 on the on-chip z exchange (default whenever all nodes of a room share the GPU and P <= 8)
+        // same mask array in both steps (oracle masks; a DNN mask re-used, tango.py:388-389): the leading M x M block of the
+        // step-2 covariances IS the step-1 covariance still held as partial sums -> not recomputed
+        st.push_back({"step2_cov", false, [=](disco_stream s) {
+            int ch = 1;
+            if (same_mask && ctx->loc_M == M) return disco_step2_cov_fused_reuse(ctx, X, mask_w, w, z_y, s);
+            return step2_cov_partials(ctx, X, mask_w, w, z_y, &ch, s);
+        }});
+        st.push_back({"solve2", true, solve_pending(w2)});
+        const bool from_samples = !yf && c.n_fft == 512 && ctx->opt[DISCO_OPT_STEP2_FROM_SAMPLES] && from_samples_shape(c);
+        if (from_samples) {            // yf not asked for, spectra re-transformed instead of read back
+            st.push_back({"step2_stft_apply_istft", false, [=](disco_stream s) { return step2_stft_apply_istft(ctx, y, w, w2, out, s); }});
+            return;
+        }
+        if (!yf && c.n_fft == 512) {   // yf not asked for: filter + iSTFT in one pass, yf stays on chip (shapes the kernel takes)
+            if (step2_apply_istft_ok(ctx)) {
+                st.push_back({"step2_apply_istft", false, [=](disco_stream s) { return disco_step2_apply_istft_fused(ctx, X, w, w2, out, s); }});
+                return;
+            }
+        }
+        st.push_back({"step2_apply", false, [=](disco_stream s) { return disco_step2_apply_fused(ctx, X, w, w2, nullptr, yo, s); }});
+        st.push_back({"istft", false, [=](disco_stream s) { return disco_istft(ctx, yo, G, out, s); }});
+        return;
+    }
+    if (c.nodes == 1 && same_mask) {
+        if (!z_y && !yf && step2_apply_istft_ok(ctx)) {
+            // single node, enhanced output only: filter + iSTFT in one pass over X, z never reaches HBM
+            st.push_back({"step2_apply_istft", false, [=](disco_stream s) { return disco_step2_apply_istft_fused(ctx, X, w, w, out, s); }});
+            return;
+        }
+        // single node, same mask: step 2 would rebuild the very same statistics from the very same inputs
+        // (P = M, nothing to append), so w_glo == w_loc and yf == z_y bit for bit (config C2).
+        st.push_back({"apply1", false, [=](disco_stream s) { return disco_apply(ctx, X, nullptr, w, M, 1, z, s); }});
+        st.push_back({"istft", false, [=](disco_stream s) {
+            if (yf) HIPCHK(ctx, hipMemcpyAsync(yf, z, (size_t)G * ctx->T * ctx->F * sizeof(c32), hipMemcpyDeviceToDevice, (hipStream_t)s));
+            return disco_istft(ctx, z, G, out, s);
+        }});
+        return;
+    }
+    // exchange + step 2 (tango.py:378-450) with z materialised, mask_for_z = 'local': wide shapes take z + the step-2 statistics of a
+    // whole room in one pass (k_room_cov) when the context's state allows it, else the filter pass + the covariance pass
+    st.push_back({nullptr, false, [=](disco_stream s) {
+        int ch = 1, rc;
+        if (c.nodes > 1 && same_mask && room_cov_ok(ctx, X, mask_w))
+            return STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w, z, &ch, s));
+        if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w, M, 1, z, s)))) return rc;
+        return STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &ch, s, same_mask && c.nodes > 1));
+    }});
+    st.push_back({"solve2", true, solve_pending(w)});
+    st.push_back({"apply2", false, [=](disco_stream s) { return disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w, P2, 1, yo, s); }});
+    st.push_back({"istft", false, [=](disco_stream s) { return disco_istft(ctx, yo, G, out, s); }});
+}
+
 extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
                                    disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes, disco_stream s) {
     DISCO_ENTER(ctx);
     if (!y || !mask_z || !mask_w || !out) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance: null argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: node shard active, drive the staged calls around an all-gather of z");
-    const disco_cfg& c = ctx->cfg;
     const WsLayout l = ws_layout(ctx);
     char* ws = nullptr;
     int rcw = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance");
     if (rcw) return rcw;
+    const PathArgs a{y, mask_z, mask_w, out, z_y, yf, ws};
     if (overlap_applies(ctx) && ctx->half[0]) {
-        const size_t K = c.nodes, TF = (size_t)ctx->T * ctx->F, sy = K * c.mics * c.length, sm = K * TF, so = K * c.length;
-        const bool same_mask = mask_w == mask_z;
-        return run_halves(ctx, ws, s, [&](disco_ctx* ch, size_t r0, char* wsc, size_t wsn, disco_stream st) {
-            const float* mz = mask_z + r0 * sm;
-            return disco_tango_enhance(ch, y + r0 * sy, mz, same_mask ? mz : mask_w + r0 * sm, out + r0 * so, z_y ? z_y + r0 * sm : nullptr,
-                                       yf ? yf + r0 * sm : nullptr, wsc, wsn, st);
-        });
+        Steps st[2];
+        for (int h = 0; h < 2; ++h) enhance_steps(ctx->half[h], child_args(ctx, a, h), st[h]);
+        return run_pipelined(ctx, st, s);
     }
-    if (c.nodes > 1 && c.mics + c.nodes - 1 <= 8 && !(c.flags & DISCO_FLAG_STAGED_STEP2))
-        return tango_enhance_fused(ctx, y, mask_z, mask_w, out, z_y, yf, ws, l, s);
-    disco_c32* X = (disco_c32*)(ws + l.X);
-    disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
-    disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
-    disco_c32* w = (disco_c32*)(ws + l.w);
-    const int64_t G = (int64_t)c.rooms * c.nodes;
-    const int M = c.mics, P2 = c.mics + c.nodes - 1;
-    int rc;
-    int chunks1 = 1;
-    if (c.nodes == 1 && mask_w == mask_z && !z_y && !yf && c.n_fft == 512 && M <= 4) {
-        // single node, enhanced output only (config C2): nothing is materialised -- one pass over the samples for the
-        // statistics, one for filter + iSTFT with the spectra recomputed (get_z_signals.py:274-315 + tango.py:528)
-        if ((rc = stft_cov_partials(ctx, y, mask_z, nullptr, &chunks1, s, false))) return rc;
-        if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks1, M, w, s)))) return rc;
-        return STAGE(ctx, s, "stft_apply_istft", stft_apply_istft(ctx, y, w, out, s));
-    }
-    // step 1 (tango.py:326-376): STFT + covariance in one pass, solve straight from the partial sums
-    if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks1, s))) return rc;
-    if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks1, M, w, s)))) return rc;
-    if (c.nodes == 1 && mask_w == mask_z && !z_y && !yf && c.n_fft == 512) {
-        // single node, enhanced output only (config C2): filter + iSTFT in one pass over X, z never reaches HBM
-        rc = STAGE(ctx, s, "step2_apply_istft", disco_step2_apply_istft_fused(ctx, X, w, w, out, s));
-        if (rc != DISCO_E_UNSUPPORTED) return rc;
-    }
-    const bool room = c.nodes > 1 && mask_w == mask_z && room_cov_ok(ctx, X, mask_w);       // wide shapes: z + step-2 statistics in one pass
-    if (!room && (rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w, M, 1, z, s)))) return rc;
-    if (c.nodes == 1 && mask_w == mask_z) {
-        // single node, same mask: step 2 would rebuild the very same statistics from the very same inputs
-        // (P = M, nothing to append), so w_glo == w_loc and yf == z_y bit for bit (config C2).
-        if (yf) HIPCHK(ctx, hipMemcpyAsync(yf, z, (size_t)G * ctx->T * ctx->F * sizeof(c32), hipMemcpyDeviceToDevice, (hipStream_t)s));
-        return STAGE(ctx, s, "istft", disco_istft(ctx, z, G, out, s));
-    }
-    // exchange + step 2 (tango.py:378-450), mask_for_z = 'local'
-    int chunks2 = 1;              // partial sums stay pending; the local M x M block is step 1's when the mask is the same
-    if (room) {
-        if ((rc = STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w, z, &chunks2, s)))) return rc;
-    } else if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, z, z, 1, P2, &chunks2, s, mask_w == mask_z)))) return rc;
-    if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w, nullptr, s)))) return rc;
-    if ((rc = STAGE(ctx, s, "apply2", disco_apply(ctx, X, z, w, P2, 1, yo, s)))) return rc;
-    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
-}
-
-// The same path with step 2 on the in-register z exchange (default whenever all nodes of a room share the GPU).
-static int tango_enhance_fused(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float* out,
-                               disco_c32* z_y, disco_c32* yf, char* ws, const WsLayout& l, disco_stream s) {
-    const disco_cfg& c = ctx->cfg;
-    disco_c32* X = (disco_c32*)(ws + l.X);
-    disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
-    disco_c32* w_loc = (disco_c32*)(ws + l.w);
-    disco_c32* w_glo = (disco_c32*)(ws + l.w2);
-    const int64_t G = (int64_t)c.rooms * c.nodes;
-    const int M = c.mics, P2 = c.mics + c.nodes - 1;
-    int rc;
-    int chunks = 1;
-    if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
-    if ((rc = STAGE(ctx, s, "solve1", solve_from_partials(ctx, chunks, M, w_loc, s)))) return rc;
-    // same mask array in both steps (oracle masks; a DNN mask re-used, tango.py:388-389): the leading M x M block of the
-    // step-2 covariances IS the step-1 covariance still held as partial sums -> not recomputed
-    if (mask_w == mask_z && ctx->loc_M == M && c.nodes > 1)
-        rc = STAGE(ctx, s, "step2_cov", disco_step2_cov_fused_reuse(ctx, X, mask_w, w_loc, z_y, s));
-    else
-        rc = STAGE(ctx, s, "step2_cov", step2_cov_partials(ctx, X, mask_w, w_loc, z_y, &chunks, s));
-    if (rc) return rc;
-    if ((rc = STAGE(ctx, s, "solve2", solve_from_partials(ctx, chunks, P2, w_glo, s)))) return rc;
-    if (!yf && c.n_fft == 512) {           // yf not asked for: filter + iSTFT in one pass, yf stays on chip
-        if (ctx->opt[DISCO_OPT_STEP2_FROM_SAMPLES] && from_samples_shape(c)) {       // ... and the spectra are re-transformed, not read back
-            rc = STAGE(ctx, s, "step2_stft_apply_istft", step2_stft_apply_istft(ctx, y, w_loc, w_glo, out, s));
-            if (rc != DISCO_E_UNSUPPORTED) return rc;
-        }
-        rc = STAGE(ctx, s, "step2_apply_istft", disco_step2_apply_istft_fused(ctx, X, w_loc, w_glo, out, s));
-        if (rc != DISCO_E_UNSUPPORTED) return rc;
-    }
-    if ((rc = STAGE(ctx, s, "step2_apply", disco_step2_apply_fused(ctx, X, w_loc, w_glo, nullptr, yo, s)))) return rc;
-    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
+    Steps st;
+    enhance_steps(ctx, a, st);
+    return run_steps(ctx, st, s);
 }
 
 // ---- reference outputs: all nine returns of offline_tango, device resident ------------------------------------------------
@@ -403,57 +454,65 @@ extern "C" int disco_tango_reference(disco_ctx* ctx, const float* y, const float
 }
 // ---- iterated (DANSE-style) continuation -------------------------------------------------------------------------------
 
+static void iterated_steps(disco_ctx* ctx, const PathArgs& a, int iters, Steps& st) {
+    const disco_cfg& c = ctx->cfg;
+    const WsLayout l = ws_layout(ctx);
+    const float *y = a.y, *mask_z = a.mask_z, *mask_w = a.mask_w;
+    float* out = a.out;
+    disco_c32* X = (disco_c32*)(a.ws + l.X);
+    disco_c32* z = a.z_y ? a.z_y : (disco_c32*)(a.ws + l.z);
+    disco_c32* yo = a.yf ? a.yf : (disco_c32*)(a.ws + l.yf);
+    disco_c32* w_loc = (disco_c32*)(a.ws + l.w);
+    disco_c32* w_glo = (disco_c32*)(a.ws + l.w2);
+    const int64_t G = (int64_t)c.rooms * c.nodes;
+    const int M = c.mics, P2 = c.mics + c.nodes - 1;
+    const bool same_mask = mask_w == mask_z;
+    st.push_back({nullptr, false, [=](disco_stream s) { int ch = 1; return stft_cov_partials(ctx, y, mask_z, X, &ch, s); }});
+    st.push_back({"solve1", true, [=](disco_stream s) { return disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s); }});
+    for (int it = 0; it < iters; ++it) {
+        // compression with the current w_loc (step 1's, then the local part of the previous iteration's filter) and the step-2
+        // statistics: ONE pass over X for every node of a room where the shape allows it (k_room_cov), else the filter pass
+        // followed by the covariance pass that reads X again and the K - 1 remote z's
+        st.push_back({nullptr, false, [=](disco_stream s) {
+            int ch = 1, rc;
+            if (same_mask && room_cov_ok(ctx, X, mask_w))
+                return STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w_loc, z, &ch, s));
+            if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
+            return STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &ch, s,
+                                                      same_mask && c.nodes > 1));
+        }});
+        const bool last = it + 1 == iters;
+        st.push_back({"solve2", true, [=](disco_stream s) {
+            int rc = disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s);
+            if (rc || last) return rc;
+            // yf of this iteration is not needed; the next one re-compresses with the local part of this iteration's filter
+            const long long nb = (long long)G * ctx->F;
+            hipLaunchKernelGGL(k_filter_head, dim3((unsigned)std::min<long long>((nb * M + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)s,
+                               (const c32*)w_glo, (c32*)w_loc, nb, M, P2);
+            return check_launch(ctx, "k_filter_head");
+        }});
+    }
+    st.push_back({"apply2", false, [=](disco_stream s) { return disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s); }});
+    st.push_back({"istft", false, [=](disco_stream s) { return disco_istft(ctx, yo, G, out, s); }});
+}
+
 extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, int iters,
                                             float* out, disco_c32* z_y, disco_c32* yf, void* workspace, size_t workspace_bytes,
                                             disco_stream s) {
     DISCO_ENTER(ctx);
     if (!y || !mask_z || !mask_w || !out || iters < 1) return fail(ctx, DISCO_E_ARG, "disco_tango_enhance_iterated: bad argument");
     if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance_iterated: node shard active");
-    const disco_cfg& c = ctx->cfg;
     const WsLayout l = ws_layout(ctx);
     char* ws = nullptr;
     int rc = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance_iterated");
     if (rc) return rc;
-    if (overlap_applies(ctx) && ctx->half[0]) {
-        const size_t K = c.nodes, TF = (size_t)ctx->T * ctx->F, sy = K * c.mics * c.length, sm = K * TF, so = K * c.length;
-        const bool same_mask = mask_w == mask_z;
-        return run_halves(ctx, ws, s, [&](disco_ctx* ch, size_t r0, char* wsc, size_t wsn, disco_stream st) {
-            const float* mz = mask_z + r0 * sm;
-            return disco_tango_enhance_iterated(ch, y + r0 * sy, mz, same_mask ? mz : mask_w + r0 * sm, iters, out + r0 * so,
-                                                z_y ? z_y + r0 * sm : nullptr, yf ? yf + r0 * sm : nullptr, wsc, wsn, st);
-        });
+    const PathArgs a{y, mask_z, mask_w, out, z_y, yf, ws};
+    if (overlap_applies(ctx) && ctx->half[0] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
+        Steps st[2];
+        for (int h = 0; h < 2; ++h) iterated_steps(ctx->half[h], child_args(ctx, a, h), iters, st[h]);
+        return run_pipelined(ctx, st, s);
     }
-    disco_c32* X = (disco_c32*)(ws + l.X);
-    disco_c32* z = z_y ? z_y : (disco_c32*)(ws + l.z);
-    disco_c32* yo = yf ? yf : (disco_c32*)(ws + l.yf);
-    disco_c32* w_loc = (disco_c32*)(ws + l.w);
-    disco_c32* w_glo = (disco_c32*)(ws + l.w2);
-    const int64_t G = (int64_t)c.rooms * c.nodes;
-    const int M = c.mics, P2 = c.mics + c.nodes - 1;
-    int chunks = 1;
-    if ((rc = stft_cov_partials(ctx, y, mask_z, X, &chunks, s))) return rc;
-    if ((rc = STAGE(ctx, s, "solve1", disco_gevd_mwf_r1_pending(ctx, c.mu, w_loc, nullptr, s)))) return rc;
-    for (int it = 0; it < iters; ++it) {
-        // compression with the current w_loc (step 1's, then the local part of the previous iteration's filter) and the step-2
-        // statistics: ONE pass over X for every node of a room where the shape allows it (k_room_cov), else the filter pass
-        // followed by the covariance pass that reads X again and the K - 1 remote z's
-        int chunks2 = 1;
-        if (mask_w == mask_z && room_cov_ok(ctx, X, mask_w)) {
-            if ((rc = STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w_loc, z, &chunks2, s)))) return rc;
-        } else {
-            if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
-            if ((rc = STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2,
-                                                         &chunks2, s, mask_w == mask_z && c.nodes > 1)))) return rc;
-        }
-        if ((rc = STAGE(ctx, s, "solve2", disco_gevd_mwf_r1_pending(ctx, c.mu, w_glo, nullptr, s)))) return rc;
-        if (it + 1 < iters) {
-            // yf of this iteration is not needed; the next one re-compresses with the local part of this iteration's filter
-            const long long nb = (long long)G * ctx->F;
-            hipLaunchKernelGGL(k_filter_head, dim3((unsigned)std::min<long long>((nb * M + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)s,
-                               (const c32*)w_glo, (c32*)w_loc, nb, M, P2);
-            if ((rc = check_launch(ctx, "k_filter_head"))) return rc;
-        }
-    }
-    if ((rc = STAGE(ctx, s, "apply2", disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s)))) return rc;
-    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
+    Steps st;
+    iterated_steps(ctx, a, iters, st);
+    return run_steps(ctx, st, s);
 }

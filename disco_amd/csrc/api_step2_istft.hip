@@ -16,6 +16,19 @@ static bool launch_apply_istft(const Step2Args& a, float* out, const float* win,
     }
 }
 
+namespace disco_host {
+// does disco_step2_apply_istft_fused take this context's shape?  (512-point STFT, P <= 8, the kernel's tile within the 160 KiB LDS)
+bool step2_apply_istft_ok(const disco_ctx* ctx) {
+    const disco_cfg& c = ctx->cfg;
+    const int M = c.mics, K = c.nodes;
+    if (c.n_fft != 512 || M + K - 1 > 8 || sharded(ctx)) return false;
+#define X_(M_, KR_) if (M == M_ && K == KR_ + 1) return sizeof(ApplyIstftShared<512, M_, KR_ + 1>) <= 160 * 1024;
+    DISCO_FOR_MKR(X_)
+#undef X_
+    return false;
+}
+}  // namespace disco_host
+
 extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc,
                                              const disco_c32* w_glo, float* out, disco_stream s) {
     DISCO_ENTER(ctx);

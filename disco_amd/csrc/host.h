@@ -75,6 +75,7 @@ struct disco_ctx {
     disco_ctx* parent;               // set in a child
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
+    std::vector<hipEvent_t> step_events;   // (step, child) hand-over events of the pipelined form
     // per-stage hipEvent timers of the whole-path entry points (disco_stage_timing / disco_stage_report)
     struct StageRec {
         char name[32];
@@ -226,5 +227,6 @@ int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask_w, 
                        disco_stream s, bool skiploc = false);
 int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, float* out, disco_stream s);
 bool from_samples_shape(const disco_cfg& c);
+bool step2_apply_istft_ok(const disco_ctx* ctx);
 int step2_stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w_loc, const disco_c32* w_glo, float* out, disco_stream s);
 }  // namespace disco_host

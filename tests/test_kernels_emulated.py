@@ -138,9 +138,10 @@ def test_emu_step2_from_samples_and_from_spectra(make_engine, K, M, L, tuning, f
     print(pc.check_tango_end_to_end(make_engine, y, s, n, tol=1e-4, tuning=tuning, from_samples=from_samples))
 
 
-@pytest.mark.parametrize('staged', [False, True])
-def test_emu_enhanced_path_vs_long_reference_golden(make_engine, golden_dir, staged):
-    print(pc.check_enhanced_path_vs_long_golden(make_engine, golden_dir, staged=staged))
+@pytest.mark.parametrize('idx,staged', [(3, False), (3, True), (1, False)])
+def test_emu_reference_run_scenes_per_bin(make_engine, golden_dir, idx, staged):
+    """The kernel sources on the long reference-run scenes, per (node, bin) (tests/golden/make_golden_scenes.py)."""
+    print(pc.check_reference_scene_per_bin(make_engine, golden_dir, idx, staged=staged))
 
 
 def test_emu_no_allocation_in_compute_calls(make_engine):
