@@ -126,12 +126,12 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
 }
 
 namespace disco_host {
-// The overlapped form applies to batches that still fill the chip when halved (rooms x nodes >= 2048; option value 2 forces it for
-// any batch of >= 2 rooms: tests), when every node of a room is here.
+// The overlapped form applies to batches that still fill the chip when halved (rooms x nodes >= 1024; option values 2 / 3 force it
+// for any batch of >= 2 rooms: tests), when every node of a room is here.
 bool overlap_applies(const disco_ctx* ctx) {
     const int o = ctx->opt[DISCO_OPT_OVERLAP_SOLVES];
     if (!o || ctx->parent || ctx->cfg.rooms < 2 || sharded(ctx)) return false;
-    return o >= 2 || (long long)ctx->cfg.rooms * ctx->cfg.nodes >= 2048;
+    return o >= 2 || (long long)ctx->cfg.rooms * ctx->cfg.nodes >= 1024;
 }
 
 int ensure_halves(disco_ctx* ctx) {

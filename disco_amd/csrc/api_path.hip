@@ -35,13 +35,17 @@ WsLayout ws_layout(const disco_ctx* ctx) {
 
 // ---- a whole-path call as a list of steps -----------------------------------------------------------------------------------
 // Every whole-path entry point builds the list of its stages (one kernel family each) and runs it: in order on the caller's stream,
-// or -- the overlapped form, DISCO_OPT_OVERLAP_SOLVES -- software-pipelined over the two half-batch children:
-//     caller's stream:  stft_cov1(A) stft_cov1(B) step2_cov(A) step2_cov(B) apply(A) apply(B)
-//     side stream    :               solve1(A)    solve1(B)    solve2(A)    solve2(B)
-// The streaming kernels keep the chip to themselves one after the other (a half-batch still fills it), and every solve -- a compute
-// kernel that moves almost no data -- runs beside the OTHER half's streaming kernel instead of between two of them.  A step waits
-// for its own child's previous step through an event when that one ran on the other stream; nothing synchronises with the host,
-// and the side stream is forked from / joined to the caller's, so the sequence can still be captured into one hipGraph.
+// or -- the overlapped forms, DISCO_OPT_OVERLAP_SOLVES -- over the two half-batch children:
+//   1 / 2 (default / forced)  child A entirely on the caller's stream, child B entirely on the side stream: the two sequences drift
+//         against each other, so a solve -- a compute kernel that moves almost no data -- mostly meets a streaming kernel of the other
+//         half, and each half's kernel tails are filled by the other half.  Measured on C3: 19.67 -> 19.14 ms.
+//   3     software-pipelined: the streaming kernels one after the other on the caller's stream, only the solves on the side stream,
+//             caller's stream:  stft_cov1(A) stft_cov1(B) step2_cov(A) step2_cov(B) apply(A) apply(B)
+//             side stream    :               solve1(A)    solve1(B)    solve2(A)    solve2(B)
+//         -- kept as the record of it: every solve is hidden, but two half-batch launches of a streaming kernel cost more than one
+//         whole-batch launch (two tails): C3 18.99 -> 19.29 ms, slower than not overlapping at all.
+// A step waits for its own child's previous step through an event when that one ran on the other stream; nothing synchronises with
+// the host, and the side stream is forked from / joined to the caller's, so either sequence can still be captured into one hipGraph.
 namespace {
 struct Step {
     const char* name;                          // stage name for the timers; nullptr: the callee brackets its own stages
@@ -67,6 +71,16 @@ int run_pipelined(disco_ctx* ctx, Steps (&steps)[2], disco_stream s) {
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s0));
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_fork, 0));
     int rc = 0;
+    if (ctx->opt[DISCO_OPT_OVERLAP_SOLVES] != 3) {             // one child per stream
+        for (int h = 0; h < 2 && !rc; ++h)
+            for (size_t i = 0; i < n && !rc; ++i) {
+                rc = run_step(ctx->half[h], steps[h][i], (disco_stream)(h ? s1 : s0));
+                if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", ctx->half[h]->err);
+            }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, s1));
+        HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_join, 0));
+        return rc;
+    }
     for (size_t i = 0; i < n && !rc; ++i)
         for (int h = 0; h < 2 && !rc; ++h) {
             disco_ctx* ch = ctx->half[h];

@@ -729,22 +729,26 @@ static __global__ void k_cov_finalize(const float4* __restrict__ part, c32* __re
         int q = 0;
         for (int i = 0; i < P; ++i)
             for (int j = i; j < P; ++j, ++q) {
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                // the chunk sums are combined in float64 and rounded once, exactly as the solvers' own loaders do (k_solve.h,
+                // k_solve_small.h): the matrices handed out are bit-identical to the pencils the pending solve works on
+                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
                 for (int c = 0; c < chunks; ++c) {
                     const float4 p = part[(((g * chunks + c) * F) + f) * (long long)NP + q];
-                    s.x += p.x;
-                    s.y += p.y;
-                    s.z += p.z;
-                    s.w += p.w;
+                    sx += (double)p.x;
+                    sy += (double)p.y;
+                    sz += (double)p.z;
+                    sw += (double)p.w;
                 }
+                const double it = (double)inv_T;
+                float4 s = make_float4((float)(sx * it), (float)(sy * it), (float)(sz * it), (float)(sw * it));
                 if (i == j) s.y = s.w = 0.f;
                 c32* rs = Rss + gf * P * P;
                 c32* rn = Rnn + gf * P * P;
-                rs[i * P + j] = make_float2(s.x * inv_T, s.y * inv_T);
-                rn[i * P + j] = make_float2(s.z * inv_T, s.w * inv_T);
+                rs[i * P + j] = make_float2(s.x, s.y);
+                rn[i * P + j] = make_float2(s.z, s.w);
                 if (i != j) {
-                    rs[j * P + i] = make_float2(s.x * inv_T, -s.y * inv_T);
-                    rn[j * P + i] = make_float2(s.z * inv_T, -s.w * inv_T);
+                    rs[j * P + i] = make_float2(s.x, -s.y);
+                    rn[j * P + i] = make_float2(s.z, -s.w);
                 }
             }
     }

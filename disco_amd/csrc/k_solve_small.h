@@ -237,16 +237,17 @@ __device__ __forceinline__ void solve_load_tri(const SolveSrc& src, long long pi
                 const float4* base = loc ? src.part_loc : src.part;
                 const int nch = loc ? src.chunks_loc : src.chunks;
                 const long long npq = loc ? (long long)(src.M_loc * (src.M_loc + 1) / 2) : (long long)NP;
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;                      // float64 combination, one rounding (as k_solve.h)
                 for (int ch = 0; ch < nch; ++ch) {
                     const float4 v = base[(((g * nch + ch) * src.F) + f) * npq + q];
-                    s.x += v.x;
-                    s.y += v.y;
-                    s.z += v.z;
-                    s.w += v.w;
+                    sx += (double)v.x;
+                    sy += (double)v.y;
+                    sz += (double)v.z;
+                    sw += (double)v.w;
                 }
-                rs = make_float2(s.x * src.inv_T, -s.y * src.inv_T);              // stored (k, i) -> R[i][k] = conj
-                rn = make_float2(s.z * src.inv_T, -s.w * src.inv_T);
+                const double it = (double)src.inv_T;
+                rs = make_float2((float)(sx * it), -(float)(sy * it));             // stored (k, i) -> R[i][k] = conj
+                rn = make_float2((float)(sz * it), -(float)(sw * it));
             }
             if (i == k) {
                 a_d[i] = rs.x;

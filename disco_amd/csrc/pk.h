@@ -118,6 +118,11 @@ struct Pk {
         const c32 r = mul<0, 0, 0, 1, 0, 0, SB>(a, t);                 // (a.x t.x, a.x t.y)
         return fma<1, 1, 1, 0, 1, 0, SB>(a, t, r);                     // (-a.y t.y + ., a.y t.x + .)
     }
+    // acc + a t = (acc.x + a.x t.x - a.y t.y, acc.y + a.x t.y + a.y t.x)
+    static __device__ __forceinline__ c32 cfma(c32 a, c32 t, c32 acc) {
+        const c32 r = fma<0, 0, 0, 1>(a, t, acc);                      // (a.x t.x + ., a.x t.y + .)
+        return fma<1, 1, 1, 0, 1, 0>(a, t, r);                         // (-a.y t.y + ., a.y t.x + .)
+    }
     // a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
     static __device__ __forceinline__ c32 cmul_aconjb(c32 a, c32 b) {
         const c32 r = mul<0, 0, 1, 0>(a, b);                           // (a.x b.x, a.y b.x)
@@ -151,6 +156,7 @@ __device__ __forceinline__ c32 cmul_pk(c32 a, c32 t) { return PkD::cmul<false>(a
 __device__ __forceinline__ c32 cmul_pk_sb(c32 a, c32 t) { return PkD::cmul<true>(a, t); }
 __device__ __forceinline__ c32 cmul_aconjb(c32 a, c32 b) { return PkD::cmul_aconjb(a, b); }
 __device__ __forceinline__ c32 cfma_conj(c32 w, c32 x, c32 acc) { return PkD::cfma_conj(w, x, acc); }
+__device__ __forceinline__ c32 cfma_pk(c32 a, c32 t, c32 acc) { return PkD::cfma(a, t, acc); }
 __device__ __forceinline__ c32 cfma_scale(c32 s, c32 hh, c32 e) { return PkD::cfma_scale(s, hh, e); }
 __device__ __forceinline__ c32 cfms_scale(c32 s, c32 hh, c32 e) { return PkD::cfms_scale(s, hh, e); }
 template <int S>
@@ -160,7 +166,7 @@ __device__ __forceinline__ c32 fma_by_half(c32 p, c32 w, c32 acc) { return PkD::
 
 // Self-test (disco_selftest_pk): every operation above through the instruction forms (out_hw) and through the C++ forms
 // (out_ref) on the same operands; the GPU test demands bit equality of the two and agreement with complex arithmetic in NumPy.
-constexpr int PK_SELFTEST_OPS = 16;
+constexpr int PK_SELFTEST_OPS = 17;
 template <bool HW>
 __device__ __forceinline__ void pk_selftest_ops(c32 a, c32 b, c32 c, c32* o) {
     const c32 hh = make_float2(0.70710678118654752440f, 0.70710678118654752440f);
@@ -181,6 +187,7 @@ __device__ __forceinline__ void pk_selftest_ops(c32 a, c32 b, c32 c, c32* o) {
     o[13] = Pk<HW>::template scale_by_half<0>(a, b);
     o[14] = Pk<HW>::template scale_by_half<1>(a, b);
     o[15] = Pk<HW>::template fma_by_half<1>(a, b, c);
+    o[16] = Pk<HW>::cfma(a, b, c);
 }
 static __global__ void k_pk_selftest(const c32* __restrict__ a, const c32* __restrict__ b, const c32* __restrict__ c, long long n,
                               c32* __restrict__ out_hw, c32* __restrict__ out_ref) {

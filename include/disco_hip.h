@@ -139,10 +139,11 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *   "room_cov"           (DISCO_ROOM_COV, 1)   wide shapes: z + step-2 statistics of a whole room in one pass ("room_cov2") instead of
  *                         disco_apply + disco_cov_masked ("apply1" + "cov2")
  *   "room_dma"           (DISCO_ROOM_DMA, 1)   that pass on its LDS-DMA ring ("room_cov2"); 0: register-staged ("room_cov2_reg")
- *   "overlap_solves"     (DISCO_OVERLAP_SOLVES, 1)  disco_tango_enhance / _iterated on batches of rooms x nodes >= 2048 run as two
+ *   "overlap_solves"     (DISCO_OVERLAP_SOLVES, 1)  disco_tango_enhance / _iterated on batches of rooms x nodes >= 1024 run as two
  *                         half-batches, the second on an internal stream forked from / joined to the caller's with events (still one
  *                         capturable launch sequence): one half's solves overlap the other half's streaming kernels.  Each stage
- *                         then shows 2 launches of R/2 rooms.  2: force it for any batch of >= 2 rooms (tests); 0: off.  The
+ *                         then shows 2 launches of R/2 rooms.  2: force it for any batch of >= 2 rooms (tests); 3: forced, and only
+ *                         the solves go to the side stream (software-pipelined; measured slower, kept as a record); 0: off.  The
  *                         half-batch contexts (own partial-sum blocks) are created by disco_create / disco_set_option
  *   "solve_f32"          (DISCO_SOLVE_F32, 1)  group solver (P >= 5): float32 squarings + float64 polish; 0: float64 throughout
  * Unknown key: DISCO_E_ARG. */
@@ -424,7 +425,7 @@ int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorptio
  * write == 0 only reads (dst needs >= 4096 floats and is practically never written). */
 int disco_selftest_stream(disco_ctx* ctx, const float* src, float* dst, int64_t n, int write, disco_stream s);
 
-#define DISCO_PK_SELFTEST_OPS 16
+#define DISCO_PK_SELFTEST_OPS 17
 int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco_c32* b, const disco_c32* c, int64_t n,
                       disco_c32* out_hw, disco_c32* out_ref, disco_stream s);
 

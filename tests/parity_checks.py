@@ -789,7 +789,7 @@ def check_pk_selftest(make_engine, n=4096, seed=11):
     h = 0.70710678118654752440
     kt = 0.92387953251128675613 - 0.38268343236508977173j
     want = [A + np.conj(B), -1j * (A - np.conj(B)), A - 1j * B, A + 1j * B, np.conj(A + 1j * B), (1 - 1j) * A, (1 + 1j) * A,
-            A * B, A * kt, A * np.conj(B), C_ + np.conj(A) * B, C_ + h * A, C_ - h * A, A * B.real, A * B.imag, C_ + A * B.imag]
+            A * B, A * kt, A * np.conj(B), C_ + np.conj(A) * B, C_ + h * A, C_ - h * A, A * B.real, A * B.imag, C_ + A * B.imag, C_ + A * B]
     errs = {}
     for q, w in enumerate(want):
         errs[q] = float(np.abs(hw[:, q] - w).max() / np.abs(w).max())
@@ -886,7 +886,7 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
     return errs
 
 
-def check_overlapped_halves(make_engine, K=2, M=2, L=6000, n_fft=512, R=3, iters=1):
+def check_overlapped_halves(make_engine, K=2, M=2, L=6000, n_fft=512, R=3, iters=1, mode=2):
     """Option "overlap_solves" (include/disco_hip.h): the whole-path calls run the batch as two half-batch children, the second on the
     context's side stream.  Rooms are independent and the children keep the launch geometry of the whole batch, so the outputs
     must equal the plain call's BIT FOR BIT; the stage report shows two launches per stage covering R rooms together; nothing is
@@ -896,8 +896,8 @@ def check_overlapped_halves(make_engine, K=2, M=2, L=6000, n_fft=512, R=3, iters
     plain = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
     plain.set_option('overlap_solves', 0)
     over = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
-    over.set_option('overlap_solves', 2)                      # 2: also for batches far too small to be worth it
-    assert plain.get_option('overlap_solves') == 0 and over.get_option('overlap_solves') == 2
+    over.set_option('overlap_solves', mode)                   # 2 / 3: also for batches far too small to be worth it
+    assert plain.get_option('overlap_solves') == 0 and over.get_option('overlap_solves') == mode
     m = plain.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, plain.T, plain.F).numpy()
     over.reserve(1)
     own = over.owned_bytes()

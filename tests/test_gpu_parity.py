@@ -244,8 +244,9 @@ def test_room_cov(make_engine, K, M, n_fft, L, tuning):
     print(pc.check_room_cov(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M > 32 else 2, tuning=tuning))
 
 
+@pytest.mark.parametrize('mode', [2, 3])
 @pytest.mark.parametrize('K,M,n_fft,iters,R', [(4, 4, 512, 1, 5), (1, 4, 512, 1, 4), (8, 8, 1024, 2, 2), (2, 8, 512, 2, 3)])
-def test_overlapped_halves(make_engine, K, M, n_fft, iters, R):
+def test_overlapped_halves(make_engine, K, M, n_fft, iters, R, mode):
     """disco_set_option("overlap_solves"): the whole-path calls as two half-batch children, the second on the context's side stream
     (fork / join with events): bit-identical to the plain call, two launches per stage, no allocation."""
-    print(pc.check_overlapped_halves(make_engine, K=K, M=M, L=20000, n_fft=n_fft, R=R, iters=iters))
+    print(pc.check_overlapped_halves(make_engine, K=K, M=M, L=20000, n_fft=n_fft, R=R, iters=iters, mode=mode))

@@ -148,7 +148,8 @@ def test_emu_no_allocation_in_compute_calls(make_engine):
     print(pc.check_no_allocation_in_compute_calls(make_engine))
 
 
+@pytest.mark.parametrize('mode', [2, 3])
 @pytest.mark.parametrize('K,M,n_fft,iters,R', [(2, 2, 512, 1, 3), (1, 3, 512, 1, 2), (2, 8, 512, 2, 2), (3, 2, 1024, 2, 3)])
-def test_emu_overlapped_halves(make_engine, K, M, n_fft, iters, R):
+def test_emu_overlapped_halves(make_engine, K, M, n_fft, iters, R, mode):
     """disco_set_option("overlap_solves"): two half-batch children on two streams, bit-identical to the plain call."""
-    print(pc.check_overlapped_halves(make_engine, K=K, M=M, L=3000 if n_fft == 512 else 5000, n_fft=n_fft, R=R, iters=iters))
+    print(pc.check_overlapped_halves(make_engine, K=K, M=M, L=3000 if n_fft == 512 else 5000, n_fft=n_fft, R=R, iters=iters, mode=mode))
