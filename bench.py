@@ -38,6 +38,12 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+# parity bar of the DANSE-style ITERATED scheme (C5).  The reference is strictly two-step (tango.py:1-7): there is no reference output
+# for a second iteration, the float64 oracle defines it ("no reference parity").  Measured:
+# float32 accumulation of the 313-frame, 15 x 15 covariances is what separates the HIP path from that oracle -- the oracle itself with
+# sequential float32 accumulation is 1.0-2.2e-4 away from the all-float64 one on the worst of three sampled rooms, 8e-6 ... 2.4e-5
+# on the others; with 8 covariance chunks per node instead of 2 the HIP path is at 4e-5.  The two-step workloads keep 1e-4.
+ITER_TOL = 3.0e-4
 HBM_PEAK = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
 F32_MATRIX_PEAK = 157.3e12  # same guide: f32-input MFMA = the f32 vector rate (what a float32 library GEMM / convolution can reach)
 
@@ -464,7 +470,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
 
     # ---- sampled rooms of the last timed step -> the oracle workers (every rank, its own rooms)
     ticket = {'name': name, 'jobs': [], 'rooms_global': [first_room + r for r in sample_rooms], 'first_room': first_room,
-              'tol': 1e-4, 'finite': finite}
+              'tol': 1e-4 if iters == 1 else ITER_TOL, 'finite': finite}
     if want_parity:
         pool = env['pool']
         for r in sample_rooms:
@@ -483,6 +489,12 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
     roofline, stages = None, None
     if rank == 0 and not args.no_stage_timing and not node_sharded:
         reps = max(2, min(steps, 5 if headline else 3))
+        # The timed region above runs the library's default: on the fused route, two half-batches on two streams (option
+        # "overlap_solves").  Overlapped kernels share the chip, so an event pair around one of them measures the mix, not the kernel;
+        # the per-kernel figures -- the roofline object -- are therefore taken with the option OFF: every kernel alone on the chip, the
+        # whole batch per launch.  `pipeline` (whole path, timed region) is what the overlap improves.
+        overlap_was = eng.get_option('overlap_solves')
+        eng.set_option('overlap_solves', 0)
         eager_step()                            # the event objects are created inside the library: warm that path once
         torch.cuda.synchronize()
         # one report per step, and the MEDIAN over the steps: an event pair also spans whatever the host does between the two
@@ -499,6 +511,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                 per_rep.append(eng.stage_report())
         if mask_kind != 'crnn':
             eng.stage_timing(False)
+        eng.set_option('overlap_solves', overlap_was)
         kab = kernel_alg_bytes(M, K, F, H)
         stages = {}
         for nm in per_rep[0]:
@@ -551,7 +564,9 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                     traffic = None
             roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved / 1e9, 1), 'peak': HBM_PEAK / 1e9,
                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': traffic,
-                        'alg_bytes_per_launch': launch_bytes, 'avg_launch_ms': round(launch_ms, 4), 'pipeline': pipeline}
+                        'alg_bytes_per_launch': launch_bytes, 'avg_launch_ms': round(launch_ms, 4), 'pipeline': pipeline,
+                        'measured': 'HIP events around every stage, kernels one at a time (option overlap_solves = 0 for this pass; '
+                                    f'the timed region ran with overlap_solves = {overlap_was}); pipeline = whole path over the timed region'}
             if online_every > 0:
                 roofline['note'] = ('the online kernels re-solve a P x P GEVD per (bin, frame): float64-issue-bound, not HBM-bound; the '
                                     'fraction says how far they are from the streaming bound of their inputs')

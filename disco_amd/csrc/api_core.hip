@@ -279,7 +279,7 @@ const OptionInfo* option_table() {
         {"room_cov", "DISCO_ROOM_COV", 1},
         {"room_dma", "DISCO_ROOM_DMA", 1},
         {"overlap_solves", "DISCO_OVERLAP_SOLVES", 1},
-        {"solve_f32", "DISCO_SOLVE_F32", 1},
+        {"solve_f32", "DISCO_SOLVE_F32", 0},
     };
     return t;
 }

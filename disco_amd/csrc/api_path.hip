@@ -257,7 +257,10 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     int rcw = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance");
     if (rcw) return rcw;
     const PathArgs a{y, mask_z, mask_w, out, z_y, yf, ws};
-    if (overlap_applies(ctx) && ctx->half[0]) {
+    const disco_cfg& c0 = ctx->cfg;
+    const bool fused_route = c0.nodes > 1 && c0.mics + c0.nodes - 1 <= 8 && !(c0.flags & DISCO_FLAG_STAGED_STEP2);
+    // by default only where it was measured to pay: the fused route (C3: 19.67 -> 19.14 ms); forced (2 / 3) for every route
+    if (overlap_applies(ctx) && ctx->half[0] && (fused_route || ctx->opt[DISCO_OPT_OVERLAP_SOLVES] >= 2)) {
         Steps st[2];
         for (int h = 0; h < 2; ++h) enhance_steps(ctx->half[h], child_args(ctx, a, h), st[h]);
         return run_pipelined(ctx, st, s);
@@ -521,7 +524,9 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     int rc = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance_iterated");
     if (rc) return rc;
     const PathArgs a{y, mask_z, mask_w, out, z_y, yf, ws};
-    if (overlap_applies(ctx) && ctx->half[0] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
+    // (the wide shapes gain nothing from the overlapped form -- C5: 46.4 ms plain, 48.0 / 48.4 ms overlapped: their room pass takes a
+    // whole CU per workgroup -- so it is used here only when forced, option values 2 / 3)
+    if (ctx->opt[DISCO_OPT_OVERLAP_SOLVES] >= 2 && overlap_applies(ctx) && ctx->half[0] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
         Steps st[2];
         for (int h = 0; h < 2; ++h) iterated_steps(ctx->half[h], child_args(ctx, a, h), iters, st[h]);
         return run_pipelined(ctx, st, s);

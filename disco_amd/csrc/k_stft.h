@@ -182,6 +182,19 @@ struct alignas(16) StftPairsShared {
     c32 buf[STFT_WAVES][fft_buf_len<N>()];
     c32 tile[N / 2 + 1][2 * STFT_WAVES];
 };
+// Where the 16-byte granule (bin f, channel pair p) of the tile lives, in granules.  Lane = bin, so a wave's ds_write_b128 puts
+// 16 consecutive bins at a pitch of chp granules: with chp = 4 (or 2) only 4 (8) of the 16 granule slots of a 256-byte LDS row
+// are hit -- a 4-way (2-way) bank conflict on every store (round 2's counters: 41 % of the kernel's LDS cycles).  XOR-ing the
+// pair index with bits of the bin spreads the 16 bins over all 16 slots; the copy-out undoes it with the same expression, and
+// its 16 consecutive granules still cover 16 different slots.
+__device__ __forceinline__ int pairs_tile_slot(int f, int p, int chp) {
+    const int sw = chp == 4 ? ((f >> 2) & 3) : (chp == 2 ? ((f >> 3) & 1) : 0);
+    return f * chp + (p ^ sw);
+}
+// the same for a linear granule index i = f * chp + p (the copy-out's): no division
+__device__ __forceinline__ int pairs_tile_slot_linear(int i, int chp) {
+    return chp == 4 ? (i ^ ((i >> 4) & 3)) : (chp == 2 ? (i ^ ((i >> 4) & 1)) : i);
+}
 
 template <int N>
 __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_pairs(const float* __restrict__ x, c32* __restrict__ X,
@@ -213,7 +226,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_
             apply_window<N>(v, raw, w, two);
             fft_wave<N>(v, wtw, sh.buf[wave], lane);
             rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
-                *reinterpret_cast<float4*>(&tile[(f * chp + wave) * 2]) = make_float4(a.x, a.y, b.x, b.y);
+                *reinterpret_cast<float4*>(&tile[pairs_tile_slot(f, wave, chp) * 2]) = make_float4(a.x, a.y, b.x, b.y);
             });
         }
 #pragma unroll
@@ -230,9 +243,12 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_
             float4* dst = reinterpret_cast<float4*>(Xo);
             const int shift = (int)((reinterpret_cast<unsigned long long>(dst) >> 4) & 7);      // whole 128-byte lines per wave store (see k_stft_cov)
             for (int i = tid - shift; i < F * chp; i += 64 * STFT_WAVES)
-                if (i >= 0) dst[i] = src[i];
+                if (i >= 0) dst[i] = src[pairs_tile_slot_linear(i, chp)];
         } else {
-            for (int i = tid; i < F * chans; i += 64 * STFT_WAVES) Xo[i] = tile[(i / chans) * 2 * chp + i % chans];
+            for (int i = tid; i < F * chans; i += 64 * STFT_WAVES) {
+                const int f = i / chans, c = i % chans;
+                Xo[i] = tile[pairs_tile_slot(f, c >> 1, chp) * 2 + (c & 1)];
+            }
         }
         __syncthreads();                               // the tile is rewritten by the next frame
     }

@@ -145,7 +145,9 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *                         then shows 2 launches of R/2 rooms.  2: force it for any batch of >= 2 rooms (tests); 3: forced, and only
  *                         the solves go to the side stream (software-pipelined; measured slower, kept as a record); 0: off.  The
  *                         half-batch contexts (own partial-sum blocks) are created by disco_create / disco_set_option
- *   "solve_f32"          (DISCO_SOLVE_F32, 1)  group solver (P >= 5): float32 squarings + float64 polish; 0: float64 throughout
+ *   "solve_f32"          (DISCO_SOLVE_F32, 0)  1: group solver (P >= 5) with float32 squarings on packed instructions and a float64
+ *                         Rayleigh-quotient finish (same accuracy; measured SLOWER than the all-float64 default on the MI355X: 1.26 vs
+ *                         1.07 ms at P = 7, 16.2 vs 14.4 ms at P = 15 -- after round 2 only 3-4 squarings are left to speed up)
  * Unknown key: DISCO_E_ARG. */
 int  disco_set_option(disco_ctx* ctx, const char* key, int value);
 int  disco_get_option(const disco_ctx* ctx, const char* key, int* value);

@@ -937,11 +937,14 @@ def _per_bin_err(a, b):
     return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-300)
 
 
-def check_reference_scene_per_bin(make_engine, golden_dir, idx, staged=False, max_excluded=0.5, tol=1e-4):
+def check_reference_scene_per_bin(make_engine, golden_dir, idx, staged=False, max_excluded=0.5, tol=1e-4, tol_bin=2e-4):
     """The HIP path against the REFERENCE'S OWN offline_tango on one of the five long scenes of tests/golden/tango_ref_scenes.npz
     (fixed consecutive seeds, 201 frames; make_golden_scenes.py says how they were made and why the comparison is per bin):
-      * every (node, bin) whose dominant-eigenvector sensitivity kappa = cond(Rnn) / (1 - d1/d0) is <= the fixture's cut at BOTH
-        steps: z_y and yf within `tol` of the reference's own output (relative l2 over the frames of the bin);
+      * the (node, bin)s whose dominant-eigenvector sensitivity kappa = cond(Rnn) / (1 - d1/d0) is <= the fixture's cut at BOTH
+        steps: z_y and yf of all of them TOGETHER (one signal per node) within `tol` = 1e-4 of the reference's own output, and
+        every single one of them within `tol_bin` = 2e-4 (relative l2 over the frames of the bin).  Why 2e-4 per bin: on these
+        very bins the reference's own complex64 LAPACK output is up to 9.3e-5 away from the float64 restatement of its own
+        algorithm (make_golden_scenes.py prints it) -- a per-bin 1e-4 would test the reference's rounding, not this code;
       * the other bins are counted; their share must stay under `max_excluded`;
       * against the float64 restatement of the reference's algorithm: every KEPT bin within `tol`, ALL bins together (one signal per
         node) within `tol`, and no single bin -- however ill-conditioned -- beyond 2e-3 (float32 spectra perturb a pencil of
@@ -974,12 +977,12 @@ def check_reference_scene_per_bin(make_engine, golden_dir, idx, staged=False, ma
             if (~ok[k]).any():
                 res['ref_excluded'] = max(res['ref_excluded'], float(e_ref[~ok[k]].max()))
             res['ref_kept_signal'] = max(res['ref_kept_signal'], relerr(got[ok[k]], ref[ok[k]]))       # all kept bins as one signal
-    assert res['ref_kept'] < tol and res['ref_kept_signal'] < tol, res
+    assert res['ref_kept'] < tol_bin and res['ref_kept_signal'] < tol, res
     assert res['f64_kept'] < tol and res['f64_signal'] < tol and res['f64_worst_bin'] < 2e-3, res
     return res
 
 
-def check_short_reference_scene_per_bin(make_engine, golden_dir, scene, kappa_cut=2e3, tol=1e-4):
+def check_short_reference_scene_per_bin(make_engine, golden_dir, scene, kappa_cut=2e3, tol=1e-4, tol_bin=2e-4):
     """The three short scenes of make_golden.py (17-25 frames) the same way: per (node, bin), against the reference's own output on
     the bins whose sensitivity is <= kappa_cut (2e3: with so few frames the statistics are poorer and the cut is tighter; the
     4 x 4 scene keeps only a few bins); against the float64 restatement on the kept bins and on all bins together (one signal
@@ -1010,11 +1013,11 @@ def check_short_reference_scene_per_bin(make_engine, golden_dir, scene, kappa_cu
                 res['f64_kept'] = max(res['f64_kept'], float(e_64[ok[k]].max()))
             res['f64_worst_bin'] = max(res['f64_worst_bin'], float(e_64.max()))
             res['f64_signal'] = max(res['f64_signal'], relerr(got, o[nm][k]))
-    assert res['ref_kept'] < tol and res['f64_kept'] < tol and res['f64_signal'] < tol and res['f64_worst_bin'] < 2e-3, res
+    assert res['ref_kept'] < tol_bin and res['f64_kept'] < tol and res['f64_signal'] < tol and res['f64_worst_bin'] < 2e-3, res
     return res
 
 
-def check_reference_surface_scene_per_bin(offline_tango, golden_dir, idx, tol=1e-4):
+def check_reference_surface_scene_per_bin(offline_tango, golden_dir, idx, tol=1e-4, tol_bin=2e-4):
     """The Python call surface (`offline_tango`, the reference's own signature) on one long reference-run scene: z_y and yf per
     (node, bin) against the reference's own output on the bins the fixture's sensitivity cut keeps (make_golden_scenes.py)."""
     import os
@@ -1025,10 +1028,11 @@ def check_reference_surface_scene_per_bin(offline_tango, golden_dir, idx, tol=1e
     assert ms.checksum(y, s, n) == str(g[f'sc{idx}_sha'])
     res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mods=[None, None])
     ok = ms.kappa(g[f'sc{idx}_cond1'], g[f'sc{idx}_gap1'], g[f'sc{idx}_cond2'], g[f'sc{idx}_gap2']) <= float(g['kappa_cut'])
-    worst = 0.0
+    worst, worst_sig = 0.0, 0.0
     for k in range(K):
         for i, nm in ((0, 'yf'), (3, 'z_y')):
-            e = _per_bin_err(np.asarray(res[i][k]), g[f'sc{idx}_{nm}{k}'])
-            worst = max(worst, float(e[ok[k]].max()))
-    assert worst < tol, worst
-    return worst
+            got, ref = np.asarray(res[i][k]), g[f'sc{idx}_{nm}{k}']
+            worst = max(worst, float(_per_bin_err(got, ref)[ok[k]].max()))
+            worst_sig = max(worst_sig, relerr(got[ok[k]], ref[ok[k]]))
+    assert worst < tol_bin and worst_sig < tol, (worst, worst_sig)         # see check_reference_scene_per_bin for the two bars
+    return worst, worst_sig
