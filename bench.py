@@ -45,6 +45,7 @@ sys.path.insert(0, REPO)
 # on the others; with 8 covariance chunks per node instead of 2 the HIP path is at 4e-5.  The two-step workloads keep 1e-4.
 ITER_TOL = 3.0e-4
 HBM_PEAK = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
+BF16_MATRIX_PEAK = 2.5e15   # same guide: dense bf16 MFMA peak (the headline figures with 2:1 sparsity are never used)
 F32_MATRIX_PEAK = 157.3e12  # same guide: f32-input MFMA = the f32 vector rate (what a float32 library GEMM / convolution can reach)
 
 CONFIGS = {
@@ -59,6 +60,7 @@ EXTRAS = {
     'C2': (dict(CONFIGS['C2']), 10, 3, 3),
     'C2x4000': (dict(CONFIGS['C2'], rooms=4000), 5, 2, 2),
     'C4': (dict(CONFIGS['C4']), 3, 1, 2),
+    'C4_bf16': (dict(CONFIGS['C4'], dnn_dtype='bf16'), 3, 1, 2),      # the networks' convolutions / GEMMs on bf16 operands (explicit switch)
     'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 1),
 }
 
@@ -77,7 +79,7 @@ def kernel_alg_bytes(M, K, F, H):
     return {
         'mask_oracle': 2 * H * 4 + F * 4,                     # s_ref, n_ref hop samples in, mask out
         'stft': M * H * 4 + M * F * 8,                        # hop samples of M mics in, M*F bins out
-        'stft_cov1': M * H * 4 + M * F * 8 + F * 4,           # samples + mask in, X out (covariances amortised over T)
+        'stft_cov1': M * H * 4 + M * F * 8 + F * 4,           # samples + mask in, X out (covariances amortised over T); C5: k_stft_pairs_cov
         'stft_cov1_nostore': M * H * 4 + F * 4,               # samples + mask in (X not materialised)
         'cov1': M * F * 8 + F * 4,                            # X + mask in (covariances: amortised over T)
         'apply1': M * F * 8 + F * 8,                          # X in, z out
@@ -379,7 +381,9 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
     G = R * Kl
 
     dnn = {}
+    dnn_dtype = None
     if mask_kind == 'crnn':
+        dnn_dtype = torch.bfloat16 if w.get('dnn_dtype') == 'bf16' else None
         from disco_amd.dnn.crnn import build_crnn
         from disco_amd.dnn.inloop import tango_enhance_dnn
         torch.manual_seed(0)
@@ -397,7 +401,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
 
     def step(mark=None):
         if mask_kind == 'crnn':
-            o, mz, mw = tango_enhance_dnn(eng, y, model_z, model_w, want_masks=True, mark=mark)
+            o, mz, mw = tango_enhance_dnn(eng, y, model_z, model_w, want_masks=True, mark=mark, compute_dtype=dnn_dtype)
             out.copy_(o)
             dnn['mz'], dnn['mw'] = mz, mw
             return
@@ -540,9 +544,10 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
             # the dominant stage is the mask-estimation DNN: float32 library GEMMs (rocBLAS / hipBLASLt) and MIOpen convolutions driven
             # by PyTorch -- not a HIP kernel of this library; priced against the float32 matrix peak
             achieved = stages[dom]['flops'] / lps / (launch_ms * 1e-3)
-            roofline = {'bound': 'mfma', 'kernel': f'{dom}: PyTorch-ROCm CRNN forward (float32 rocBLAS GEMMs + MIOpen convolutions, not a kernel of this library)',
-                        'achieved': round(achieved / 1e12, 2), 'peak': F32_MATRIX_PEAK / 1e12, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / F32_MATRIX_PEAK, 4), 'traffic': None, 'avg_launch_ms': round(launch_ms, 4),
+            peak = BF16_MATRIX_PEAK if dnn_dtype is not None else F32_MATRIX_PEAK
+            roofline = {'bound': 'mfma', 'kernel': f'{dom}: PyTorch-ROCm CRNN forward ({"bf16" if dnn_dtype is not None else "float32"} rocBLAS GEMMs + MIOpen convolutions, not a kernel of this library)',
+                        'achieved': round(achieved / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / peak, 4), 'traffic': None, 'avg_launch_ms': round(launch_ms, 4),
                         'flops_per_launch': stages[dom]['flops'] / lps, 'pipeline': pipeline}
         else:
             cand = [n_ for n_ in stages if 'alg_bytes' in stages[n_]]
@@ -584,7 +589,15 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                     'link_GBps': (R * Kl * T * F * 8 / (sum(gather_ms) / len(gather_ms) * 1e-3) / 1e9) if (gather_ms and world > 1) else None,
                     'note': 'xGMI is point-to-point: each of the W-1 peers sends its R*Kl*T*F*8-byte block over its own link'}
 
-    mask_desc = 'oracle irm1 mask' if mask_kind == 'oracle' else 'CRNN masks in the loop (random weights, PyTorch-ROCm)'
+    mask_error = None
+    if dnn_dtype is not None:
+        # what the low-precision operands cost: the same networks evaluated in float32 on the same batch
+        _, mz32, mw32 = tango_enhance_dnn(eng, y, model_z, model_w, want_masks=True)
+        mask_error = {'vs': 'the float32 evaluation of the same networks on the same batch',
+                      'mask_z_max_abs': float((dnn['mz'] - mz32).abs().max()), 'mask_z_mean_abs': float((dnn['mz'] - mz32).abs().mean()),
+                      'mask_w_max_abs': float((dnn['mw'] - mw32).abs().max()), 'mask_w_mean_abs': float((dnn['mw'] - mw32).abs().mean())}
+        del mz32, mw32
+    mask_desc = 'oracle irm1 mask' if mask_kind == 'oracle' else ('CRNN masks in the loop (random weights, PyTorch-ROCm' + (', convolutions / GEMMs on bf16 operands)' if dnn_dtype is not None else ')'))
     par = (f'nodes of every room split over {world} GPU(s) ({Kl} per rank), one RCCL all-gather of z per step-2 iteration'
            if node_sharded else f'rooms sharded over {world} GPU(s), no data-path collective')
     res = {
@@ -601,6 +614,8 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
     }
     if exchange:
         res['exchange'] = exchange
+    if mask_error:
+        res['mask_error'] = mask_error
     del y, s_ref, n_ref, mask, out, ws, eng
     torch.cuda.empty_cache()
     return res, ticket

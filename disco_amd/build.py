@@ -18,7 +18,7 @@ OBJ = os.path.join(HERE, 'lib', 'obj')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-fPIC']
 # kernels that count their vector-memory queue by hand (csrc/k_room.h): a compiler spill inside their loops would shift that
 # count -- a build in which one of them uses scratch is refused
-NO_SPILL = ('k_room_cov_dma', 'k_stft_pairs_cov')
+NO_SPILL = ('k_room_cov_dma',)
 
 
 def units():

@@ -8,11 +8,12 @@
 // (restated in oracle/online_oracle.py, pinned on the reference's two functions by tests/golden/online_ref.npz).
 //
 // Mapping: as the batch solver -- a group of G lanes owns one (room, node, bin) problem for the whole signal, lane j owns
-// row j of both smoothed matrices (float32 registers: the forgetting factor keeps rounding from accumulating).  The filter
-// update TRACKS the dominant generalized eigenvector from update to update (gevd_track_group, k_solve.h: Rayleigh-quotient
-// iteration on the pencil itself, no whitening, no squaring, certified by the inertia of its own factorisation); the full
-// float64 group solve runs at the first update and whenever a group of the wave fails that certificate (two eigenvalues
-// crossed, no convergence).  DISCO_ONLINE_TRACK=0: the full solve at every update (round 2).  Consecutive groups of a block are consecutive bins, so the per-frame loads of
+// row j of both smoothed matrices (float32 registers: the forgetting factor keeps rounding from accumulating) and calls
+// the float64 group solve every update.  (Round 3 tried to TRACK the dominant eigenvector from update to update instead --
+// Rayleigh-quotient iteration on the pencil itself, warm-started, no whitening and no squaring, certified by the inertia of
+// its own factorisation, full solve on failure: parity-green and 2.6x SLOWER, 1515 vs 588 ms for step 2 of 1000 rooms.  At
+// P = 7 the solve is bound by the latency of its sequential Cholesky / substitution chains, not by the squarings, and every
+// tracking step has such a chain of its own.  Dropped; see DESIGN.md.)  Consecutive groups of a block are consecutive bins, so the per-frame loads of
 // X / Z / mask are contiguous across the block.  The walk over t is causal, which makes the two-step pipeline two
 // launches of this kernel (step 1: P = M, Z = NULL -> z; step 2: P = M + K - 1, Z = z) with no other barrier.
 #pragma once
@@ -36,9 +37,6 @@ struct OnlineArgs {
     long long R;
 };
 
-#ifndef DISCO_ONLINE_TRACK
-#define DISCO_ONLINE_TRACK 1
-#endif
 #ifndef DISCO_ONLINE_WPE
 #define DISCO_ONLINE_WPE 3        // 168 VGPRs, 3 waves/SIMD: 10 % faster than the 174-VGPR / 2-wave allocation
 #endif
@@ -74,11 +72,6 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
     const float lam = a.lambda_cor, oml = 1.f - a.lambda_cor;
     c32 wj = make_float2(0.f, 0.f);
     int until_update = 0;
-    static_assert(P * SolveGeom<P>::YW >= SolveGeom<P>::BWV, "the tracking solve borrows the full solve's second LDS matrix");
-    c64 q[P];                                             // the tracked generalized eigenvector (every lane holds all of it)
-#pragma unroll
-    for (int c = 0; c < P; ++c) q[c] = make_double2(c == 0 ? 1.0 : 0.0, 0.0);
-    bool have_q = false;                                   // wave-uniform by construction (set for the whole wave at once)
     for (int t = 0; t < a.T; ++t) {
         c32 v[P];
 #pragma unroll
@@ -107,22 +100,9 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
             }
         }
         if (until_update == 0) {                           // block-uniform: every group updates at the same frames
-            c64 t1 = make_double2(0.0, 0.0);
-            double gain = 0.0;
-            bool tracked = false;
-            if (DISCO_ONLINE_TRACK && have_q) tracked = gevd_track_group<P>(rowA, rowB, q, &s_Y[slot][0][0], j, a.mu, t1, gain);
-            if (__any(!tracked)) {                         // first update, or a group of this wave lost its certificate: full solve
-                c64 t1f, qf[P];
-                double gainf;
-                gevd_solve_group<P, true>(rowA, rowB, s_L[slot], s_Y[slot], j, a.mu, t1f, gainf, qf);
-                if (!tracked) {
-                    t1 = t1f;
-                    gain = gainf;
-#pragma unroll
-                    for (int c = 0; c < P; ++c) q[c] = qf[c];
-                }
-                have_q = true;
-            }
+            c64 t1;
+            double gain;
+            gevd_solve_group<P, true>(rowA, rowB, s_L[slot], s_Y[slot], j, a.mu, t1, gain);
             wj = make_float2((float)(t1.x * gain), (float)(t1.y * gain));
             until_update = a.update_every;
         }

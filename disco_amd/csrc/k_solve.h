@@ -380,7 +380,7 @@ __device__ __forceinline__ void group_forward_substitute(c64* b, const c64* Lm) 
 // the same number of times.  REENTER: a fence first, so that a previous call's readers of Lm / Ym are done (callers in a loop).
 template <int P, bool REENTER>
 __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* rowB, c64* Lm, c64 (*Ym)[SolveGeom<P>::YW],
-                                                 const int j, const double mu, c64& t1_j, double& gain_out, c64* q_out = nullptr) {
+                                                 const int j, const double mu, c64& t1_j, double& gain_out) {
     constexpr int G = SolveGeom<P>::G;
     using SG = SolveGeom<P>;
     if constexpr (REENTER) DISCO_GROUP_SYNC();
@@ -437,10 +437,6 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
 
     c64 q[P];
     group_back_substitute<P>(v0, Lm, q);
-    if (q_out) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) q_out[i] = q[i];
-    }
     const double l00 = Lm[SG::lt(0, 0)].y;
     // ---- d0 = v0^H C v0 = q^H Rxx q  (q^H Rnn q = |v0|^2 = 1): lane j forms (Rxx q)_j from its row of Rxx
     double d0;
@@ -472,7 +468,7 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
 // Mixed-precision route (option "solve_f32"; NOT the default: measured on the MI355X it is slower than the all-float64 route
 // above -- 1.26 vs 1.07 ms per C3 launch at P = 7, 16.2 vs 14.4 ms per C5 step at P = 15 -- because with the power-step finish only
 // 3-4 squarings are left to speed up and the Rayleigh-quotient finish costs about as much as it saves; kept, tested, as the record
-// of it and because its finish is what the online mode's tracking solve is built from).  The idea: the covariances arrive as
+// of it).  The idea: the covariances arrive as
 // float32, and the squarings are P^2 complex float64 multiply-adds per lane each.  Here
 //   * the whitening stays float64 (Cholesky of Rnn, the two substitutions: cond(Rnn) reaches 1e5 on real rooms);
 //   * the SQUARINGS run in float32 on packed instructions (v_pk_fma_f32: 2 per complex multiply-add instead of 4 v_fma_f64,
@@ -832,157 +828,6 @@ __device__ __forceinline__ void gevd_solve_group_mixed(LoadRows&& load_rows, c64
         if (i == j) t1_j = zmul(q[i], gsc);
     }
     gain_out = gain;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Tracking solve for the online mode: the pencil of frame t differs from frame t-1's by one forgetting-factor update, so the
-// previous dominant generalized eigenvector q is a good start and no whitening or squaring is needed at all.  Rayleigh-quotient
-// iteration directly on the pencil: with theta = q^H Rxx q / q^H Rnn q, the matrix M = theta Rnn - Rxx has the wanted vector
-// as its (near-)null vector; rotated by the Householder reflector that sends q / |q| to the last coordinate, that direction is
-// the last one, the Cholesky recursion of the leading (P-1) x (P-1) block never meets it, and the null vector comes out of ONE
-// back substitution that does not divide by the last pivot (quadratic convergence: |theta - d0| = O(err^2)).
-// The same factorisation certifies the answer: M is congruent to theta I - C, so its leading block is positive definite exactly
-// when theta lies above every OTHER generalized eigenvalue (Sylvester's law of inertia) -- a tracked vector that has stopped
-// being the dominant one (two eigenvalues crossed) shows up as a broken pivot, and the caller re-acquires with the full solve.
-// Per step and lane: ~3 P complex float64 multiply-adds for the two matrix-vector products and the update, P^2/6 for the
-// factorisation, P^2/2 for the substitution -- against ~8 P^2 for whitening + squarings.
-#ifndef DISCO_TRACK_STEPS
-#define DISCO_TRACK_STEPS 3
-#endif
-#ifndef DISCO_TRACK_TOL
-#define DISCO_TRACK_TOL 3e-8
-#endif
-// q: previous eigenvector (any scale; all of it in every lane), replaced by the new one.  rowA / rowB: row j of Rxx / Rnn.  Fm:
-// SolveGeom<P>::BWV c64 words of LDS.  Returns false when the iteration did not converge or the certificate failed (outputs are
-// then undefined: run the full solve).  Wave-level fences and votes inside: every lane of the wave must call it.
-template <int P>
-__device__ __forceinline__ bool gevd_track_group(const c32* rowA, const c32* rowB, c64* q, c64* Fm, const int j, const double mu,
-                                                 c64& t1_j, double& gain_out) {
-    using SG = SolveGeom<P>;
-    constexpr int G = SG::G, t = P - 1;
-    c64* Wv = Fm + SG::BW;
-    bool good = false, certified = false;
-    double theta = 0.0, den = 1.0;
-    c64 bj = make_double2(0.0, 0.0);
-    DISCO_GROUP_SYNC();
-    for (int it = 0; it <= DISCO_TRACK_STEPS; ++it) {
-        // ---- generalized Rayleigh quotient and residual of the current q
-        c64 aj = make_double2(0.0, 0.0), qj = make_double2(0.0, 0.0);
-        bj = make_double2(0.0, 0.0);
-        double n2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < P; ++c) {
-            aj.x = fma((double)rowA[c].x, q[c].x, fma(-(double)rowA[c].y, q[c].y, aj.x));
-            aj.y = fma((double)rowA[c].x, q[c].y, fma((double)rowA[c].y, q[c].x, aj.y));
-            bj.x = fma((double)rowB[c].x, q[c].x, fma(-(double)rowB[c].y, q[c].y, bj.x));
-            bj.y = fma((double)rowB[c].x, q[c].y, fma((double)rowB[c].y, q[c].x, bj.y));
-            n2 = fma(q[c].x, q[c].x, fma(q[c].y, q[c].y, n2));
-            if (c == j) qj = q[c];
-        }
-        if (j >= P) aj = bj = make_double2(0.0, 0.0);
-        double num = qj.x * aj.x + qj.y * aj.y, dn = qj.x * bj.x + qj.y * bj.y;
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) {
-            num += __shfl_xor(num, off, G);
-            dn += __shfl_xor(dn, off, G);
-        }
-        const bool sane = dn > 0.0 && num > 0.0 && n2 > 0.0 && n2 < 1.7e308;
-        theta = sane ? num * rcp64(dn) : 0.0;
-        den = dn;
-        const double rx = aj.x - theta * bj.x, ry = aj.y - theta * bj.y;
-        double r2 = rx * rx + ry * ry, b2 = bj.x * bj.x + bj.y * bj.y;
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) {
-            r2 += __shfl_xor(r2, off, G);
-            b2 += __shfl_xor(b2, off, G);
-        }
-        const bool conv = sane && r2 <= (DISCO_TRACK_TOL * DISCO_TRACK_TOL) * theta * theta * b2;
-        good = conv && certified;                              // converged, and the LAST factorisation (at a theta this close) was clean
-        const bool go = sane && !good && it < DISCO_TRACK_STEPS;
-        if (!__any(go)) break;
-        // ---- one step: M = theta Rnn - Rxx rotated by H = I - beta u u^H, u = v - alpha e_t, v = q / |q|
-        const double rq = rsqrt64(sane ? n2 : 1.0);
-        const double at = sqrt(q[t].x * q[t].x + q[t].y * q[t].y) * rq;
-        const double rat = at > 0.0 ? rcp64(at) : 0.0;
-        const c64 alpha = at > 0.0 ? make_double2(-q[t].x * rq * rat, -q[t].y * rq * rat) : make_double2(-1.0, 0.0);
-        const double beta = rcp64(1.0 + at);
-        const c64 ut = zsub(zscale(q[t], rq), alpha);
-        // p = M u: lane j from row j of M (row j of Rnn, Rxx are in its registers)
-        c64 pj = make_double2(0.0, 0.0), uj = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int c = 0; c < P; ++c) {
-            const c64 uc = c == t ? ut : zscale(q[c], rq);
-            const c64 m = make_double2(theta * (double)rowB[c].x - (double)rowA[c].x, theta * (double)rowB[c].y - (double)rowA[c].y);
-            pj = zadd(pj, zmul(m, uc));
-            if (c == j) uj = uc;
-        }
-        if (j >= P) pj = make_double2(0.0, 0.0);
-        double up = j < P ? uj.x * pj.x + uj.y * pj.y : 0.0;
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) up += __shfl_xor(up, off, G);
-        const double c2 = 0.5 * beta * beta * up;
-        const c64 wj = make_double2(beta * pj.x - c2 * uj.x, beta * pj.y - c2 * uj.y);
-        DISCO_GROUP_SYNC();
-        if (j < P) Wv[j] = wj;
-        DISCO_GROUP_SYNC();
-        // row j (lower part) of H M H = M - u w^H - w u^H
-        if (j < P) {
-#pragma unroll
-            for (int c = 0; c < P; ++c) {
-                if (c <= j) {
-                    const c64 uc = c == t ? ut : zscale(q[c], rq);
-                    c64 m = make_double2(theta * (double)rowB[c].x - (double)rowA[c].x, theta * (double)rowB[c].y - (double)rowA[c].y);
-                    m = zsub(m, zadd(zmulc(uj, Wv[c]), zmulc(wj, uc)));
-                    Fm[SG::lt(j, c)] = m;
-                }
-            }
-        }
-        DISCO_GROUP_SYNC();
-        const int broke = group_cholesky_factor<P>(Fm, j);
-        certified = broke == 0;
-        c64 yv[P];
-        yv[t] = make_double2(1.0, 0.0);
-#pragma unroll
-        for (int i = P - 2; i >= 0; --i) {
-            DISCO_SCHED_FENCE();
-            c64 a = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Fm[SG::lt(k, i)].x, -Fm[SG::lt(k, i)].y), yv[k]));
-            yv[i] = zscale(a, Fm[SG::lt(i, i)].x);
-            DISCO_CONSUME(yv[i].x);
-            DISCO_CONSUME(yv[i].y);
-        }
-        // x = H y = y - beta u (u^H y)
-        c64 uy = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const c64 ui = i == t ? ut : zscale(q[i], rq);
-            uy = zadd(uy, zmul(make_double2(ui.x, -ui.y), yv[i]));
-        }
-        uy = zscale(uy, beta);
-        double x2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const c64 ui = i == t ? ut : zscale(q[i], rq);
-            yv[i] = zsub(yv[i], zmul(ui, uy));
-            x2 = fma(yv[i].x, yv[i].x, fma(yv[i].y, yv[i].y, x2));
-        }
-        const bool okx = go && x2 > 0.0 && x2 < 1.7e308;
-        const double rx2 = okx ? rsqrt64(x2) : 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) q[i] = okx ? zscale(yv[i], rx2) : q[i];
-    }
-    // ---- outputs from the Rnn-normalised vector: d0 = theta, (Q^-1)[0,0] = conj((Rnn q)_0) / sqrt(q^H Rnn q)
-    const double rden = good ? rcp64(den) : 0.0;
-    const c64 b0 = make_double2(__shfl(bj.x, 0, G), __shfl(bj.y, 0, G));
-    const double dcl = fmin(fmax(theta, SOLVE_EPS), SOLVE_ETA);
-    gain_out = dcl / (dcl + mu);
-    t1_j = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        if (i == j) t1_j = zscale(zmul(q[i], make_double2(b0.x, -b0.y)), rden);
-    }
-    return good;
 }
 
 template <int P, bool FROM_PART, bool MIXED = false>

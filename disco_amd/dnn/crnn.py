@@ -144,8 +144,10 @@ class CRNN(nn.Module):
         wins = x.unfold(1, WIN_LEN, 1).permute(1, 0, 3, 2)          # (T, C, 21, F)
         return self.forward(wins.contiguous())[:, sel, :]
 
-    def _cnn_folded(self, x):
-        """The convolutional stack with every BatchNorm2d (inference statistics) folded into the convolution before it:
+    def _cnn_folded(self, x, compute_dtype=None):
+        """compute_dtype (torch.bfloat16 / torch.float16): the convolutions run in that type (inputs, weights and feature maps;
+        MIOpen accumulates in float32), the result is returned in float32.  None: float32 throughout.
+        The convolutional stack with every BatchNorm2d (inference statistics) folded into the convolution before it:
         w' = w g / sqrt(var + eps), b' = (b - mean) g / sqrt(var + eps) + beta -- the same function, one kernel less per
         layer (MIOpen's inference batch-norm was 10 % of the GPU time of a step).  Folded weights are cached per parameter
         version, so loading a checkpoint afterwards is picked up."""
@@ -158,6 +160,15 @@ class CRNN(nn.Module):
                 folded.append(((conv.weight * g.view(-1, 1, 1, 1)).contiguous(), ((conv.bias - bn.running_mean) * g + bn.bias).contiguous(),
                                conv.padding))
             self._folded, self._fold_key = folded, key
+            self._folded_lp = {}
+        if compute_dtype is not None and x.dtype != compute_dtype:
+            lp = self._folded_lp.get(compute_dtype)
+            if lp is None:
+                lp = self._folded_lp[compute_dtype] = [(w.to(compute_dtype), b.to(compute_dtype), pad) for w, b, pad in self._folded]
+            x = x.to(compute_dtype)
+            for (w, b, pad), pool in zip(lp, mods[2::3]):
+                x = pool(torch.nn.functional.conv2d(x, w, b, stride=1, padding=pad))
+            return x.float()
         for (w, b, pad), pool in zip(self._folded, mods[2::3]):
             if x.is_cuda and x.dtype == torch.float32 and tuple(pool.kernel_size) == (1, 4):
                 x = _maxpool4_hip(torch.nn.functional.conv2d(x, w, None, stride=1, padding=pad), b)      # bias added after the max
@@ -167,13 +178,17 @@ class CRNN(nn.Module):
 
     # ---- sequence evaluation
     @torch.no_grad()
-    def predict_masks(self, mag, chunk=256, frame_to_pred=PRED_FRAME, norm_type=None):
+    def predict_masks(self, mag, chunk=256, frame_to_pred=PRED_FRAME, norm_type=None, compute_dtype=None):
         """mag: (B, n_ch, T, F) magnitudes (un-clipped |STFT| of the node's reference mic, then |z| of the other nodes)
         -> masks (B, T, F), equal to reshape_mask(model(prepare_data(..., frame_to_pred, norm_type)), frame_to_pred) of the
         reference for every item (speech_enhancement/utils.py:13-66, 69-138; tango.py:228-240).
         frame_to_pred: 'mid' (tango.py:35, what offline_tango uses) or 'last' (prepare_data's own default);
         norm_type: None | 'scale_to_unit_norm' | 'scale_to_1' | 'center_and_scale' (per frequency over the whole sequence,
-        utils.py:36-66; 'pcen' is librosa's and not offered)."""
+        utils.py:36-66; 'pcen' is librosa's and not offered).
+        compute_dtype: None (float32, the default and what the parity tests pin) or torch.bfloat16 / torch.float16 -- the
+        convolutions and the GRU / output GEMMs take their inputs in that type and accumulate in float32 (matrix cores at full
+        rate instead of the float32 rate); the gate arithmetic, the recurrent state and the masks stay float32.  An explicit
+        accuracy-for-speed switch: bench.py's C4_bf16 entry states the mask error it costs against the float32 evaluation."""
         if self.training:
             raise RuntimeError('predict_masks is the inference path (BatchNorm folded on its running statistics): call model.eval() first')
         B, C, T, F = mag.shape
@@ -198,7 +213,7 @@ class CRNN(nn.Module):
         elif norm_type is not None:
             raise NotImplementedError(f"norm_type '{norm_type}' (librosa's pcen is third-party and absent)")
         x = torch.nn.functional.pad(x, (0, 0, pad[0], pad[1]))      # zeros AFTER clipping / scaling, as prepare_data does
-        feat = self._cnn_folded(x)                                  # (B, 64, T + 20 - 6, 4)
+        feat = self._cnn_folded(x, compute_dtype)                   # (B, 64, T + 20 - 6, 4)
         Cc, Fy = feat.shape[1], self.y_out
         # The reference's `.view` (crnn.py:59) re-interprets each window's (64, 15, 4) block as (15, 256) WITHOUT a transpose:
         # GRU step s reads elements [256 s, 256 (s + 1)) of the flattened block, i.e. only the first ceil(256 steps / 60)
@@ -207,6 +222,20 @@ class CRNN(nn.Module):
         gru = self.rnn.model[0].rnn_layer
         H = gru.hidden_size
         w_ih, w_hh, b_ih, b_hh = gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0
+        if compute_dtype is not None:
+            w_ih_t, w_hh_t = w_ih.t().to(compute_dtype), w_hh.t().to(compute_dtype)
+
+            def gemm(bias, a, wt):                                  # float32 out = bias + a @ wt with low-precision operands
+                a = a.to(compute_dtype)
+                try:
+                    return torch.addmm(bias, a, wt, out_dtype=torch.float32)
+                except (TypeError, RuntimeError):
+                    return torch.addmm(bias.to(compute_dtype), a, wt).float()
+        else:
+            w_ih_t, w_hh_t = w_ih.t(), w_hh.t()
+
+            def gemm(bias, a, wt):
+                return torch.addmm(bias, a, wt)
         out = torch.empty((B, T, F), dtype=mag.dtype, device=mag.device)
         feat = feat.contiguous()
         sB, sC = feat.stride(0), feat.stride(1)
@@ -223,16 +252,16 @@ class CRNN(nn.Module):
             # The GRU over `steps` steps from a zero state, for all nb * T windows at once, as plain GEMMs: one for the input
             # projections of every step, one per step for the recurrent part (torch's / MIOpen's nn.GRU kernel is an order of
             # magnitude slower on this shape: a quarter of a million 8-step sequences).  Gate order r, z, n; same arithmetic.
-            gi = torch.addmm(b_ih, seq.reshape(-1, Cc * Fy), w_ih.t()).view(nb * T, steps, 3 * H)
+            gi = gemm(b_ih, seq.reshape(-1, Cc * Fy), w_ih_t).view(nb * T, steps, 3 * H)
             fused = gi.is_cuda and gi.dtype == torch.float32          # pointwise gate math in one HIP kernel (libdisco_hip.so)
             h = None
             for st in range(steps):
                 g = gi[:, st]
                 if fused:
-                    gh = None if h is None else torch.addmm(b_hh, h, w_hh.t())
+                    gh = None if h is None else gemm(b_hh, h, w_hh_t)
                     h = _gru_gates_hip(g, gh, b_hh, h, H)
                     continue
-                gh = b_hh.expand(nb * T, -1) if h is None else torch.addmm(b_hh, h, w_hh.t())
+                gh = b_hh.expand(nb * T, -1) if h is None else gemm(b_hh, h, w_hh_t)
                 r = torch.sigmoid(g[:, :H] + gh[:, :H])
                 zg = torch.sigmoid(g[:, H:2 * H] + gh[:, H:2 * H])
                 nn_ = torch.tanh(g[:, 2 * H:] + r * gh[:, 2 * H:])

@@ -13,9 +13,10 @@ def _c64(t):
     return torch.view_as_complex(t)
 
 
-def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk=64, mark=None):
+def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk=64, mark=None, compute_dtype=None):
     """eng: disco_amd.engine.Engine (rooms R, nodes K, mics M); y: torch float32 (R, K, M, L) on the engine's device.
     model_z: CRNN(n_ch=1); model_w: CRNN(n_ch=K) or None (= reuse mask_z, tango.py:388-389).
+    compute_dtype: None (float32) or torch.bfloat16 / torch.float16 for the networks' convolutions and GEMMs (CRNN.predict_masks).
     mark: optional callable(name) invoked after every phase (stft, crnn_z, cov1, solve1, apply1, crnn_w, step2_cov, solve2,
     step2_apply_istft) -- bench.py records an event on the launch stream in it to time the phases.
     Returns out (R, K, L) torch float32 [, mask_z, mask_w (R, K, T, F)]."""
@@ -31,7 +32,7 @@ def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk
     Xc = _c64(X)                                                       # (R, K, T, F, M) complex64 view
     ref = eng.cfg.ref_mic
     mag_ref = Xc[..., ref].abs().reshape(G, 1, T, F)                   # |Y| at the reference mic (tango.py:338)
-    mask_z = model_z.predict_masks(mag_ref, chunk=dnn_chunk).reshape(R, K, T, F).contiguous()
+    mask_z = model_z.predict_masks(mag_ref, chunk=dnn_chunk, compute_dtype=compute_dtype).reshape(R, K, T, F).contiguous()
     mark('crnn_z')
     eng._chk(lib.disco_cov_masked(ctx, p(X), p(mask_z), None, None, 0, M, None, None, None))
     mark('cov1')
@@ -50,7 +51,7 @@ def tango_enhance_dnn(eng, y, model_z, model_w=None, want_masks=False, dnn_chunk
         for k in range(K):
             inp[:, k, 0] = mag0[:, k]
             inp[:, k, 1:] = get_z_for_mask(zmag.transpose(0, 1), None, k, K, 'zs_hat').transpose(0, 1)
-        mask_w = model_w.predict_masks(inp.reshape(G, K, T, F), chunk=dnn_chunk).reshape(R, K, T, F).contiguous()
+        mask_w = model_w.predict_masks(inp.reshape(G, K, T, F), chunk=dnn_chunk, compute_dtype=compute_dtype).reshape(R, K, T, F).contiguous()
         mark('crnn_w')
     out = torch.empty((R, K, L), dtype=torch.float32, device=dev)
     if K == 1:

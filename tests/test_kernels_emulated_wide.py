@@ -32,9 +32,15 @@ def test_emu_cov_split_shapes(make_engine, K, M, n_fft):
     print(pc.check_cov_solve_apply(make_engine, R=1, K=K, M=M, L=(2 * (M + K) + 3) * (n_fft // 2), n_fft=n_fft))
 
 
-@pytest.mark.parametrize('R,K,M,L,n_fft', [(3, 4, 4, 24000, 512), (2, 2, 3, 30000, 512), (2, 1, 8, 20000, 512), (2, 2, 2, 25000, 1024)])
+@pytest.mark.parametrize('R,K,M,L,n_fft', [(3, 4, 4, 24000, 512), (2, 2, 3, 30000, 512), (2, 1, 8, 20000, 512), (2, 2, 2, 25000, 1024),
+                                          (1, 2, 8, 12000, 1024), (1, 1, 7, 9000, 1024)])
 def test_emu_stft_cov_fused_gpu_shapes(make_engine, R, K, M, L, n_fft):
     print(pc.check_stft_cov_fused(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft))
+
+
+@pytest.mark.parametrize('chunks', [1, 3])
+def test_emu_stft_cov_fused_wide_chunks(make_engine, chunks):
+    print(pc.check_stft_cov_fused(make_engine, R=1, K=1, M=8, L=8000, n_fft=1024, tuning=(0, chunks, 0, 0)))
 
 
 @pytest.mark.parametrize('R,K,M', [(3, 4, 4), (2, 3, 2), (1, 5, 4), (2, 8, 1), (2, 2, 7)])
