@@ -79,7 +79,7 @@ def kernel_alg_bytes(M, K, F, H):
     return {
         'mask_oracle': 2 * H * 4 + F * 4,                     # s_ref, n_ref hop samples in, mask out
         'stft': M * H * 4 + M * F * 8,                        # hop samples of M mics in, M*F bins out
-        'stft_cov1': M * H * 4 + M * F * 8 + F * 4,           # samples + mask in, X out (covariances amortised over T); C5: k_stft_pairs_cov
+        'stft_cov1': M * H * 4 + M * F * 8 + F * 4,           # samples + mask in, X out (covariances amortised over T)
         'stft_cov1_nostore': M * H * 4 + F * 4,               # samples + mask in (X not materialised)
         'cov1': M * F * 8 + F * 4,                            # X + mask in (covariances: amortised over T)
         'apply1': M * F * 8 + F * 8,                          # X in, z out
@@ -293,7 +293,7 @@ def parse_args(argv=None):
     if args.extras == 'auto':
         args.extras = 'all' if (plain and args.config == 'C3' and args.shard == 'rooms' and not args.graph and args.length == 160000) else 'none'
     if args.extras == 'all':
-        args.extra_names = list(EXTRAS)
+        args.extra_names = [n for n in EXTRAS if n != 'C4_bf16']       # the bf16 variant on request only (--extras C4,C4_bf16)
     elif args.extras == 'none':
         args.extra_names = []
     else:

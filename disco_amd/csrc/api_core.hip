@@ -280,7 +280,6 @@ const OptionInfo* option_table() {
         {"room_dma", "DISCO_ROOM_DMA", 1},
         {"overlap_solves", "DISCO_OVERLAP_SOLVES", 1},
         {"solve_f32", "DISCO_SOLVE_F32", 0},
-        {"wide_stft_cov", "DISCO_WIDE_STFT_COV", 1},
     };
     return t;
 }

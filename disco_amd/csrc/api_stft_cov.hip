@@ -55,38 +55,15 @@ int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics;
     if (M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: more than 8 mics per node");
-    if (c.n_fft == 1024 && M > 6) {
+    if (c.n_fft == 1024 && M > 6) {        // staged form of the same two operations
+        // (Round 3 built the one-pass form for this shape -- four transform waves with a channel pair each plus eight fold waves, one
+        // bin per thread, two LDS tiles, one barrier per frame: parity-green and SLOWER, 12.8 ms against 5.1 + 3.9 ms per C5 launch.
+        // The 144 accumulator registers per bin force 12 waves and 100 KiB of LDS into one workgroup, i.e. ONE workgroup and four
+        // transform waves per CU where k_stft_pairs keeps eight; the transforms set the pace.  Dropped, see DESIGN.md.)
         if (!store) return fail(ctx, DISCO_E_UNSUPPORTED, "stft_cov without store: shape needs the staged kernels");
-        if (!ctx->opt[DISCO_OPT_WIDE_STFT_COV]) {          // staged form of the same two operations: X written, then read back
-            int rc0 = STAGE(ctx, s, "stft", disco_stft(ctx, y, (int64_t)c.rooms * c.nodes, M, X, s));
-            if (rc0) return rc0;
-            return STAGE(ctx, s, "cov1", cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s));
-        }
-        // one pass: four transform waves (a channel pair each) + eight fold waves per workgroup (k_stft_pairs_cov)
-        const long long Gw = (long long)c.rooms * c.nodes;
-        const int chunks_w = cov_chunks(ctx);
-        const int NPw = M * (M + 1) / 2;
-        int rcw = ensure_scratch(ctx, (size_t)Gw * chunks_w * ctx->F * NPw * sizeof(float4));
-        if (rcw) return rcw;
-        if (Gw * chunks_w > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: batch too large");
-        {
-            StageScope stage_scope_(ctx, s, "stft_cov1");
-            if (M == 8)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_pairs_cov<1024, 8>), dim3((unsigned)(Gw * chunks_w)), dim3(SPC_THREADS), 0, (hipStream_t)s, y,
-                                   mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length, ctx->T, c.pad_mode, chunks_w);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_pairs_cov<1024, 7>), dim3((unsigned)(Gw * chunks_w)), dim3(SPC_THREADS), 0, (hipStream_t)s, y,
-                                   mask_z, (c32*)X, (float4*)ctx->scratch, ctx->d_win, ctx->d_tw, c.length, ctx->T, c.pad_mode, chunks_w);
-        }
-        *chunks_out = chunks_w;
-        ctx->pending_chunks = chunks_w;
-        ctx->pending_P = M;
-        ctx->pending_skiploc = 0;
-        ctx->loc_chunks = chunks_w;
-        ctx->loc_M = M;
-        ctx->loc_X = X;
-        ctx->loc_mask = mask_z;
-        return check_launch(ctx, "k_stft_pairs_cov");
+        int rc0 = STAGE(ctx, s, "stft", disco_stft(ctx, y, (int64_t)c.rooms * c.nodes, M, X, s));
+        if (rc0) return rc0;
+        return STAGE(ctx, s, "cov1", cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s));
     }
     const long long G = (long long)c.rooms * c.nodes;
     int runw = 0;

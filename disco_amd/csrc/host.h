@@ -34,7 +34,6 @@ enum {
     DISCO_OPT_ROOM_DMA,                 // "room_dma": its LDS-DMA ring (0: register-staged variant)
     DISCO_OPT_OVERLAP_SOLVES,           // "overlap_solves": whole-path calls run the batch as two halves on two streams
     DISCO_OPT_SOLVE_F32,                // "solve_f32": float32 squarings + float64 Rayleigh-quotient finish in the group solver (default 0: all float64)
-    DISCO_OPT_WIDE_STFT_COV,            // "wide_stft_cov": 1024-point STFT with 7-8 mics: STFT + step-1 covariance in one pass (0: two passes)
     DISCO_N_OPTIONS
 };
 namespace disco_host {

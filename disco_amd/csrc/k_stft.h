@@ -254,141 +254,6 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_
     }
 }
 
-// STFT + step-1 covariance in ONE pass for the shapes k_stft_cov cannot take (1024-point STFT with 7 or 8 microphones: its
-// per-wave tiles would need 131 KiB): k_stft_pairs' split -- wave p of the four TRANSFORM waves owns channel pair p of the frame
-// -- plus eight FOLD waves, one thread per bin (512 bins + the Nyquist bin as k_stft_cov does it), that copy the frame's tile out
-// to X and fold it into the masked covariances while the transform waves are already on the next frame: two tiles, ONE
-// workgroup barrier per frame (at barrier t the fold waves are done with tile (t-1) & 1, which frame t+1 overwrites).  The
-// transform waves set the pace (a 1024-point transform is ~5x the fold's arithmetic), so the statistics come for free and the
-// separate covariance pass over X (disco_cov_masked: 16.4 GB read back per C5 launch, 4.2 ms) disappears.
-// A workgroup streams the frames [c, c + 1) * ceil(T / chunks) of one node; partial sums as k_stft_cov: part[g][chunk][f][q].
-constexpr int SPC_FOLD_WAVES = 8;
-constexpr int SPC_THREADS = 64 * (STFT_WAVES + SPC_FOLD_WAVES);
-
-template <int N>
-struct alignas(16) StftPairsCovShared {
-    c32 buf[STFT_WAVES][fft_buf_len<N>()];
-    c32 tile[2][N / 2 + 1][2 * STFT_WAVES];
-};
-
-template <int N, int M>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__(SPC_THREADS, 1) void k_stft_pairs_cov(const float* __restrict__ x, const float* __restrict__ mask,
-                                                                   c32* __restrict__ X, float4* __restrict__ part,
-                                                                   const float* __restrict__ win, const c32* __restrict__ tw,
-                                                                   int L, int T, int pad_mode, int chunks) {
-    static_assert(N == 1024 && (M == 7 || M == 8) && STFT_WAVES == 4, "four channel pairs, 512 + 1 bins");
-    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, CHP = 4, NP = M * (M + 1) / 2;
-    __shared__ StftPairsCovShared<N> sh;
-    const int wave = wave_id(), lane = threadIdx.x & 63;
-    const long long g = blockIdx.x / chunks;
-    const int c = (int)(blockIdx.x % chunks);
-    const int per = (T + chunks - 1) / chunks;
-    const int t0 = c * per, t1 = min(T, t0 + per);
-    const bool fft_wave_ = wave < STFT_WAVES;                  // wave-uniform role
-
-    if (fft_wave_) {
-        // ---- transform waves: channel pair `wave` of every frame of the run
-        const bool two = 2 * wave + 1 < M;
-        WaveTw<N> wtw;
-        wtw.init(tw, lane);
-        float w[E];
-        load_window_half<N>(w, win, lane);
-        const float* xa = x + (g * M + 2 * wave) * (long long)L;
-        const float* xb = two ? xa + L : xa;
-        c32 raw[E];
-        if (t0 < t1) load_frame_slots<N, 0, E>(raw, xa, xb, t0, L, pad_mode, lane);
-        for (int t = t0; t < t1; ++t) {
-            c32* tile = &sh.tile[t & 1][0][0];
-            c32 v[E];
-            apply_window<N>(v, raw, w, two);
-            // the next frame's new half-window goes straight into the upper half of `raw` (these waves store nothing to global
-            // memory, so no store has to be kept ahead of the loads' waitcnt): it lands under the transform, no staging registers
-#pragma unroll
-            for (int e = 0; e < EH; ++e) raw[e] = raw[e + EH];
-            load_frame_slots<N, EH, E>(raw + EH, xa, xb, min(t + 1, T - 1), L, pad_mode, lane);
-            fft_wave<N>(v, wtw, sh.buf[wave], lane);
-            rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
-                *reinterpret_cast<float4*>(&tile[pairs_tile_slot(f, wave, CHP) * 2]) = make_float4(a.x, a.y, b.x, b.y);
-            });
-            __syncthreads();                               // barrier t: tile t & 1 is complete; the fold waves are done with the other one
-        }
-        __syncthreads();                                   // the fold waves' last frame (they pass one barrier more than they fold)
-        return;
-    }
-
-    // ---- fold waves: thread ft owns bin ft (0 .. 511); the Nyquist bin is split over the first 2 NP threads, one entry each
-    const int ft = threadIdx.x - 64 * STFT_WAVES;
-    c32 acc_s[NP], acc_n[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
-    c32 acc_ny = make_float2(0.f, 0.f);
-    int ny_i = 0, ny_j = 0;
-    {
-        int q = ft >> 1, i = 0;
-        while (i < M - 1 && q >= M - i) {
-            q -= M - i;
-            ++i;
-        }
-        ny_i = i;
-        ny_j = i + q;
-    }
-    const float* mg = mask + g * T * (long long)F;
-    float m_cur = 0.f, mny_cur = 0.f;
-    if (t0 < t1) {
-        m_cur = mg[(long long)t0 * F + ft];
-        mny_cur = mg[(long long)t0 * F + F - 1];
-    }
-    __syncthreads();                                       // barrier t0: the first tile is there
-    for (int t = t0; t < t1; ++t) {
-        const int tn = min(t + 1, T - 1);                  // next frame's mask, requested before this frame's work
-        const float m_nxt = mg[(long long)tn * F + ft], mny_nxt = mg[(long long)tn * F + F - 1];
-        const c32* tile = &sh.tile[t & 1][0][0];
-        c32* Xo = X + ((g * T + t) * (long long)F) * M;
-        if ((M & 1) == 0) {
-            // the tile row IS the X row: 16 bytes per lane, whole 128-byte lines per wave store (see k_stft_cov)
-            const float4* src = reinterpret_cast<const float4*>(tile);
-            float4* dst = reinterpret_cast<float4*>(Xo);
-            const int shift = (int)((reinterpret_cast<unsigned long long>(dst) >> 4) & 7);
-            for (int i = ft - shift; i < F * CHP; i += 64 * SPC_FOLD_WAVES)
-                if (i >= 0) dst[i] = src[pairs_tile_slot_linear(i, CHP)];
-        } else {
-            for (int i = ft; i < F * M; i += 64 * SPC_FOLD_WAVES) {
-                const int f = i / M, ch = i % M;
-                Xo[i] = tile[pairs_tile_slot(f, ch >> 1, CHP) * 2 + (ch & 1)];
-            }
-        }
-        {
-            c32 xv[2 * CHP];
-#pragma unroll
-            for (int p = 0; p < CHP; ++p) {
-                const float4 q4 = *reinterpret_cast<const float4*>(&tile[pairs_tile_slot(ft, p, CHP) * 2]);
-                xv[2 * p] = make_float2(q4.x, q4.y);
-                xv[2 * p + 1] = make_float2(q4.z, q4.w);
-            }
-            const float m = m_cur, mc = 1.f - m_cur;
-            cov_accumulate_shared<M>(xv, m * m, mc * mc, acc_s, acc_n);
-        }
-        if (ft < 2 * NP) {
-            const float m = (ft & 1) ? 1.f - mny_cur : mny_cur;
-            const c32 a = tile[pairs_tile_slot(F - 1, ny_i >> 1, CHP) * 2 + (ny_i & 1)];
-            const c32 b2 = tile[pairs_tile_slot(F - 1, ny_j >> 1, CHP) * 2 + (ny_j & 1)];
-            const float m2 = m * m;
-            acc_ny.x = fmaf(m2, a.x * b2.x + a.y * b2.y, acc_ny.x);
-            if (ny_i != ny_j) acc_ny.y = fmaf(m2, a.y * b2.x - a.x * b2.y, acc_ny.y);
-        }
-        m_cur = m_nxt;
-        mny_cur = mny_nxt;
-        __syncthreads();                                   // barrier t + 1
-    }
-    float4* o = part + ((g * chunks + c) * F) * (long long)NP;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) o[(long long)ft * NP + q] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
-    if (ft < 2 * NP) {
-        float2* o2 = reinterpret_cast<float2*>(o + (long long)(F - 1) * NP + (ft >> 1));
-        o2[ft & 1] = acc_ny;
-    }
-}
-
 // tf_mask (dnn/utils.py:57-67) on one bin.  v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE div/sqrt expansions:
 // ~12 instructions instead of ~60 per bin, error 2-3 ulp on a mask that is compared at 1e-5.
 __device__ __forceinline__ float ipow(float r, int p) {

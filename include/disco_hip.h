@@ -148,9 +148,6 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *   "solve_f32"          (DISCO_SOLVE_F32, 0)  1: group solver (P >= 5) with float32 squarings on packed instructions and a float64
  *                         Rayleigh-quotient finish (same accuracy; measured SLOWER than the all-float64 default on the MI355X: 1.26 vs
  *                         1.07 ms at P = 7, 16.2 vs 14.4 ms at P = 15 -- after round 2 only 3-4 squarings are left to speed up)
- *   "wide_stft_cov"      (DISCO_WIDE_STFT_COV, 1)  1024-point STFT with 7 or 8 microphones: disco_stft_cov_fused and the whole-path
- *                         calls take STFT + step-1 covariance in one pass (stage "stft_cov1"; k_stft_pairs_cov); 0: disco_stft followed
- *                         by disco_cov_masked (stages "stft" + "cov1": X written, then read back)
  * Unknown key: DISCO_E_ARG. */
 int  disco_set_option(disco_ctx* ctx, const char* key, int value);
 int  disco_get_option(const disco_ctx* ctx, const char* key, int* value);

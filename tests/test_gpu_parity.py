@@ -66,12 +66,6 @@ def test_stft_cov_fused(make_engine, R, K, M, L, n_fft):
     pc.check_stft_cov_fused(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft)
 
 
-@pytest.mark.parametrize('chunks', [1, 2, 5])
-def test_stft_cov_fused_wide_chunks(make_engine, chunks):
-    """k_stft_pairs_cov at the chunk counts a batch can take (C5: 2), incl. a last chunk shorter than the others."""
-    pc.check_stft_cov_fused(make_engine, R=1, K=2, M=8, L=30000, n_fft=1024, tuning=(0, chunks, 0, 0))
-
-
 @pytest.mark.parametrize('R,K,M', [(3, 4, 4), (2, 2, 2), (2, 3, 2), (2, 1, 3), (1, 5, 4), (2, 8, 1), (2, 2, 7)])
 def test_step2_fused(make_engine, R, K, M):
     pc.check_step2_fused(make_engine, R=R, K=K, M=M, L=16000)

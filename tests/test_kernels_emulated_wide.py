@@ -38,10 +38,6 @@ def test_emu_stft_cov_fused_gpu_shapes(make_engine, R, K, M, L, n_fft):
     print(pc.check_stft_cov_fused(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft))
 
 
-@pytest.mark.parametrize('chunks', [1, 3])
-def test_emu_stft_cov_fused_wide_chunks(make_engine, chunks):
-    print(pc.check_stft_cov_fused(make_engine, R=1, K=1, M=8, L=8000, n_fft=1024, tuning=(0, chunks, 0, 0)))
-
 
 @pytest.mark.parametrize('R,K,M', [(3, 4, 4), (2, 3, 2), (1, 5, 4), (2, 8, 1), (2, 2, 7)])
 def test_emu_step2_fused_gpu_shapes(make_engine, R, K, M):
