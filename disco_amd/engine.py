@@ -292,14 +292,19 @@ class Engine:
         return DevBuf(self, shape, dtype)
 
     # ---- stage kernels (names follow include/disco_hip.h)
-    def stft(self, x):
-        """x (n_sig, chans, L) float32 -> X (n_sig, T, F, chans) complex64   [lb.core.stft, tango.py:335]"""
+    def stft(self, x, out=None):
+        """x (n_sig, chans, L) float32 -> X (n_sig, T, F, chans) complex64   [lb.core.stft, tango.py:335]
+        out: optional caller-owned device array (DevBuf or torch complex64 tensor) of n_sig * T * F * chans elements."""
         n_sig, chans, Ls = x.shape
         assert Ls == self.Lsamp
         px, kx = self.to_device(x, np.float32)
-        X = self.empty((n_sig, self.T, self.F, chans), np.complex64)
-        self._chk(self.lib.disco_stft(self.ctx, px, n_sig, chans, X.ptr, self.stream))
-        return X
+        if out is None:
+            X = self.empty((n_sig, self.T, self.F, chans), np.complex64)
+            self._chk(self.lib.disco_stft(self.ctx, px, n_sig, chans, X.ptr, self.stream))
+            return X
+        po, ko = self.to_device(out, np.complex64)
+        self._chk(self.lib.disco_stft(self.ctx, px, n_sig, chans, po, self.stream))
+        return out
 
     def istft(self, Z, out=None):
         """Z (n_sig, T, F) complex64 -> (n_sig, L) float32   [lb.core.istft, tango.py:528]

@@ -1039,3 +1039,36 @@ def check_reference_surface_scene_per_bin(offline_tango, golden_dir, idx, tol=1e
             worst_sig = max(worst_sig, relerr(got[ok[k]], ref[ok[k]]))
     assert worst < tol_bin and worst_sig < tol, (worst, worst_sig)         # see check_reference_scene_per_bin for the two bars
     return worst, worst_sig
+
+
+def check_reference_steps_state(make_engine, K=2, M=2, L=4000):
+    """disco_tango_reference(steps = 2) continues from the state a steps = 1 call left in the workspace: same inputs, same
+    workspace, nothing in between -- anything else is refused (DISCO_E_ARG) instead of running on whatever the workspace holds
+    (include/disco_hip.h; round-2 advice).  steps = 1 then 2 equals steps = 3."""
+    from disco_amd import synth
+    from disco_amd.engine import DiscoError
+    y, s, n = synth.make_rooms_numpy(1, K=K, M=M, L=L)
+    eng = make_engine(rooms=1, nodes=K, mics=M, length=L)
+    yd, sd, nd = (eng.to_device(a, np.float32)[1] for a in (y, s, n))
+    y2 = eng.to_device(y.copy(), np.float32)[1]
+
+    def refused(fn):
+        try:
+            fn()
+        except DiscoError as e:
+            assert 'steps = 2' in str(e), e
+            return True
+        return False
+    assert refused(lambda: eng.tango_reference(yd, sd, nd, steps=2))                       # no steps = 1 call at all
+    full = {k: v.numpy() for k, v in eng.tango_reference(yd, sd, nd, steps=3).items()}
+    assert refused(lambda: eng.tango_reference(yd, sd, nd, steps=2))                       # a steps = 3 call leaves no state to continue
+    a = {k: v.numpy() for k, v in eng.tango_reference(yd, sd, nd, steps=1).items()}
+    assert refused(lambda: eng.tango_reference(y2, sd, nd, steps=2))                       # other input array
+    b = {k: v.numpy() for k, v in eng.tango_reference(yd, sd, nd, steps=2).items()}        # the legitimate continuation
+    for k, v in {**a, **b}.items():
+        assert np.array_equal(v, full[k]), k
+    eng.tango_reference(yd, sd, nd, steps=1)
+    m = eng.mask_oracle(s[:, :, 0].reshape(K, L), n[:, :, 0].reshape(K, L)).reshape(1, K, eng.T, eng.F)
+    eng.tango_enhance(y, m)                                                                # overwrites the context's own workspace
+    assert refused(lambda: eng.tango_reference(yd, sd, nd, steps=2))
+    return True

@@ -250,3 +250,30 @@ def test_overlapped_halves(make_engine, K, M, n_fft, iters, R, mode):
     """disco_set_option("overlap_solves"): the whole-path calls as two half-batch children, the second on the context's side stream
     (fork / join with events): bit-identical to the plain call, two launches per stage, no allocation."""
     print(pc.check_overlapped_halves(make_engine, K=K, M=M, L=20000, n_fft=n_fft, R=R, iters=iters, mode=mode))
+
+
+def test_reference_steps_state(make_engine):
+    assert pc.check_reference_steps_state(make_engine, K=3, M=2, L=16000)
+
+
+def test_engine_on_another_device():
+    """Every entry point switches to the context's own device -- the plain memory helpers included (round-2 advice): an engine on
+    device 1 while device 0 is current must allocate, copy and compute on device 1 and leave device 0 current.  Needs two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    from disco_amd import _lib
+    from disco_amd.engine import Engine
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 4000)).astype(np.float32)
+    ref = Engine(rooms=2, nodes=1, mics=3, length=4000, device=0, lib=_lib.load()).stft(x).numpy()
+    eng = Engine(rooms=2, nodes=1, mics=3, length=4000, device=1, lib=_lib.load())
+    X = eng.stft(x)                                    # DevBuf allocation + h2d + kernel + d2h, all on device 1
+    assert torch.cuda.current_device() == 0
+    assert np.array_equal(X.numpy(), ref)
+    # and a caller-owned buffer ON device 1 is written by the same context while device 0 stays current
+    t = torch.empty(ref.shape + (2,), dtype=torch.float32, device='cuda:1')
+    eng._chk(eng.lib.disco_stft(eng.ctx, eng.to_device(x, np.float32)[0], 2, 3, t.data_ptr(), None))
+    eng.sync()
+    assert np.array_equal(torch.view_as_complex(t).cpu().numpy(), ref)

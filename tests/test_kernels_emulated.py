@@ -153,3 +153,7 @@ def test_emu_no_allocation_in_compute_calls(make_engine):
 def test_emu_overlapped_halves(make_engine, K, M, n_fft, iters, R, mode):
     """disco_set_option("overlap_solves"): two half-batch children on two streams, bit-identical to the plain call."""
     print(pc.check_overlapped_halves(make_engine, K=K, M=M, L=3000 if n_fft == 512 else 5000, n_fft=n_fft, R=R, iters=iters, mode=mode))
+
+
+def test_emu_reference_steps_state(make_engine):
+    assert pc.check_reference_steps_state(make_engine)
