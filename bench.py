@@ -281,6 +281,10 @@ def parse_args(argv=None):
     ap.add_argument('--no-parity', action='store_true', help='skip the sampled-room oracle check after the timed region')
     ap.add_argument('--parity-rooms', type=int, default=3)
     ap.add_argument('--pmc-calibrate', action='store_true', help='also run a 4 GiB device copy (known bytes) for PMC calibration')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'gloo' + --single-device: a functional test of the N > 1 bookkeeping on a box with ONE GPU (every rank computes on cuda:0, "
+                         'the control collectives go over gloo); not a measurement')
+    ap.add_argument('--single-device', action='store_true', help='every rank uses cuda:0 (test only, see --dist-backend)')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='no GPU work: every rank joins a gloo group, rank 0 prints n_gpus and the all-rank parity merge of fake per-rank '
                          'errors (covers the self-launch path and the all-rank bookkeeping on CPU)')
@@ -464,7 +468,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
     barrier()
     dt_local = time.perf_counter() - t0
     if headline:
-        value, dt = dd.whole_job_throughput(units_per_step * steps, dt_local, world, device=dev)
+        value, dt = dd.whole_job_throughput(units_per_step * steps, dt_local, world, device=env['cdev'])
     else:
         value, dt = units_per_step * steps / dt_local, dt_local       # merged over the ranks at the end (merge_extras)
     finite = bool(torch.isfinite(out).all())
@@ -634,7 +638,7 @@ def finish_parity(ticket, env, timeout=900.0):
         worst = max(worst, e)
     if not ticket['finite']:
         worst = float('inf')
-    rows = gather_rank_rows(rank, world, env['local_rank'], ticket['first_room'], ticket['rooms_global'], worst, env['dist'], env['dev'])
+    rows = gather_rank_rows(rank, world, env['local_rank'], ticket['first_room'], ticket['rooms_global'], worst, env['dist'], env['cdev'])
     ps = merge_parity({'rooms': ticket['rooms_global'], 'per_room': per_room, 'worst_rel': worst}, rows, ticket['tol'])
     if err:
         ps['error'] = err
@@ -647,7 +651,7 @@ def merge_extras(res, env):
     world = env['world']
     if world == 1:
         return res
-    t = torch.tensor([res['seconds_local'], res['units_local']], dtype=torch.float64, device=env['dev'])
+    t = torch.tensor([res['seconds_local'], res['units_local']], dtype=torch.float64, device=env['cdev'])
     outs = [torch.empty_like(t) for _ in range(world)]
     env['dist'].all_gather(outs, t)
     secs = [float(o[0]) for o in outs]
@@ -668,7 +672,7 @@ def main(argv=None):
         if not args.selftest_launch:
             import torch
             have = torch.cuda.device_count()
-            if have < args.gpus:
+            if have < args.gpus and not args.single_device:
                 raise SystemExit(f'--gpus {args.gpus} but only {have} GPU(s) are visible')
         raise SystemExit(dd.launch_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus))
     if args.gpus != world:
@@ -695,19 +699,21 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    cdev = dev if args.dist_backend == 'nccl' else torch.device('cpu')        # where the control collectives' tensors live
     node_sharded = args.shard == 'nodes'
     if world == 1 and node_sharded:
         os.environ.setdefault('MASTER_PORT', str(dd.free_port()))
-    dist = dd.init('nccl', rank, world, device=dev) if (world > 1 or node_sharded) else None    # RCCL (one-rank group for --shard nodes)
+    dist = dd.init(args.dist_backend, rank, world, device=dev) if (world > 1 or node_sharded) else None    # RCCL (one-rank group for --shard nodes)
     lib = _lib.load()
     # oracle workers: fresh interpreters (spawn: a forked HIP context is not usable), single-threaded numpy each
     for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
         os.environ.setdefault(v, '1')
     pool = None if args.no_parity else ProcessPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 8) // max(world, 1))),
                                                            mp_context=mp.get_context('spawn'))
-    env = dict(rank=rank, world=world, local_rank=local_rank, dev=dev, dist=dist, lib=lib, pool=pool)
+    env = dict(rank=rank, world=world, local_rank=dev_index, dev=dev, cdev=cdev, dist=dist, lib=lib, pool=pool)
 
     head_w = {k: getattr(args, k) for k in ('rooms', 'nodes', 'mics', 'n_fft', 'iters', 'mask', 'online_every')}
     cfg_shape = CONFIGS[args.config]
@@ -735,7 +741,7 @@ def main(argv=None):
         # every rank takes part in the same gathers in the same order, whether its own run of the extra succeeded or not
         ok_local = 'error' not in extras[nm]
         if world > 1:
-            flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device=dev)
+            flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             all_ok = bool(flag.item() > 0.5)
         else:

@@ -59,3 +59,24 @@ def test_bench_two_ranks_rccl(shard):
     assert d['n_gpus'] == 2 and d['parity_sample']['ok'] and d['parity_sample']['worst_rel'] < 1e-4
     if shard == 'nodes':
         assert d['exchange']['link_GBps'] is not None and d['scaling'] == 'strong'
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_ranks_bookkeeping_on_one_gpu():
+    """The N > 1 bookkeeping of the plain bench line on a box with ONE GPU: two self-launched ranks, both computing on cuda:0, the
+    control collectives over gloo (`--dist-backend gloo --single-device`; a functional test, not a measurement).  Every rank owns its
+    own rooms and checks rooms of its own batch; the headline and every attached configuration carry both ranks' parity rows and the
+    worst error over both; an attached configuration's value is the units of both ranks over the slower rank's time."""
+    d = _run_bench(['--gpus', '2', '--dist-backend', 'gloo', '--single-device', '--rooms', '8', '--length', '40000', '--steps', '2',
+                    '--warmup', '1', '--extras', 'C2,online1', '--no-cpu-baseline'], timeout=1100)
+    assert d['n_gpus'] == 2 and d['config']['rooms_per_gpu'] == 8
+    ps = d['parity_sample']
+    assert ps['ok'] and ps['worst_rel_all_ranks'] < 1e-4 and len(ps['ranks']) == 2
+    assert [r['first_room'] for r in ps['ranks']] == [0, 8] and [r['rank'] for r in ps['ranks']] == [0, 1]
+    assert all(0 <= x < 8 for x in ps['ranks'][0]['rooms_checked']) and all(8 <= x < 16 for x in ps['ranks'][1]['rooms_checked'])
+    assert set(d['configs']) == {'C2', 'online1'}
+    for nm, v in d['configs'].items():
+        assert 'error' not in v, (nm, v)
+        assert len(v['seconds_per_rank']) == 2 and v['parity_sample']['ok'] and len(v['parity_sample']['ranks']) == 2, nm
+        units = 2 * v['config']['rooms_per_gpu'] * v['config']['nodes'] * v['config']['frames'] * v['steps']
+        assert abs(v['value'] - units / max(v['seconds_per_rank'])) < 1e-6 * v['value'], nm
