@@ -185,6 +185,20 @@ def cpu_baseline(K, M, L, n_fft=512):
 
 
 # ---- the checker: sampled rooms against the float64 CPU oracle (runs in worker processes) ------------------------------------------
+def parity_job_file(path):
+    """parity_job on a room parked in an .npz file (written synchronously by the bench process BEFORE it goes on: handing the arrays
+    -- 40 MB for a C5 room -- to the worker through the executor's pickling thread would hold the interpreter lock of the bench
+    process at an arbitrary later moment, e.g. inside the next workload's timed region).  The file is removed."""
+    import numpy as np
+    with np.load(path, allow_pickle=False) as d:
+        masks = None
+        if 'mz' in d.files:
+            masks = ([m for m in d['mz']], [m for m in d['mw']])
+        args = (str(d['kind']), int(d['room']), d['yr'], d['sr'], d['nr'], d['got'], int(d['k0']), int(d['n_fft']), int(d['iters']), masks)
+    os.remove(path)
+    return parity_job(*args)
+
+
 def parity_job(kind, room, yr, sr, nr, got, k0, n_fft, iters, masks=None):
     """One sampled room of the batch the timed region just processed, against the float64 CPU oracle (test infrastructure used as
     the checker, never as the thing measured).  yr (K,M,L); sr, nr (K,L) target / noise image at the reference mic; got (Kl,L):
@@ -484,14 +498,17 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
         for r in sample_rooms:
             yr, sr, nr = sample_in[r]
             got = out[r].cpu().numpy()
+            rec = dict(room=first_room + r, yr=yr, sr=sr, nr=nr, got=got, k0=k0, n_fft=N)
             if mask_kind == 'crnn':
-                masks = ([dnn['mz'][r, k].T.double().cpu().numpy() for k in range(K)], [dnn['mw'][r, k].T.double().cpu().numpy() for k in range(K)])
-                job = ('masks', first_room + r, yr, sr, nr, got, k0, N, 1, masks)
+                rec.update(kind='masks', iters=1, mz=np.stack([dnn['mz'][r, k].T.double().cpu().numpy() for k in range(K)]),
+                           mw=np.stack([dnn['mw'][r, k].T.double().cpu().numpy() for k in range(K)]))
             elif online_every > 0:
-                job = ('online', first_room + r, yr, sr, nr, got, k0, N, online_every)
+                rec.update(kind='online', iters=online_every)
             else:
-                job = ('batch', first_room + r, yr, sr, nr, got, k0, N, iters)
-            ticket['jobs'].append(pool.submit(parity_job, *job))
+                rec.update(kind='batch', iters=iters)
+            path = os.path.join(env['tmpdir'], f'parity_{name}_{rank}_{first_room + r}.npz')
+            np.savez(path, **rec)
+            ticket['jobs'].append(pool.submit(parity_job_file, path))
 
     # ---- per-stage timing on the launch stream, for the roofline object (rank 0)
     roofline, stages = None, None
@@ -713,7 +730,9 @@ def main(argv=None):
         os.environ.setdefault(v, '1')
     pool = None if args.no_parity else ProcessPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 8) // max(world, 1))),
                                                            mp_context=mp.get_context('spawn'))
-    env = dict(rank=rank, world=world, local_rank=dev_index, dev=dev, cdev=cdev, dist=dist, lib=lib, pool=pool)
+    import tempfile
+    tmpdir = tempfile.mkdtemp(prefix='disco_bench_')
+    env = dict(rank=rank, world=world, local_rank=dev_index, dev=dev, cdev=cdev, dist=dist, lib=lib, pool=pool, tmpdir=tmpdir)
 
     head_w = {k: getattr(args, k) for k in ('rooms', 'nodes', 'mics', 'n_fft', 'iters', 'mask', 'online_every')}
     cfg_shape = CONFIGS[args.config]
@@ -759,6 +778,8 @@ def main(argv=None):
             extras[nm].pop(k, None)
     if pool is not None:
         pool.shutdown(wait=True)
+    import shutil
+    shutil.rmtree(tmpdir, ignore_errors=True)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
