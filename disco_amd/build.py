@@ -18,7 +18,11 @@ OBJ = os.path.join(HERE, 'lib', 'obj')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-fPIC']
 # kernels that count their vector-memory queue by hand (csrc/k_room.h): a compiler spill inside their loops would shift that
 # count -- a build in which one of them uses scratch is refused
-NO_SPILL = ('k_room_cov_dma',)
+NO_SPILL = ('k_room_cov_dma', 'k_gevd_mwf_r1_dpp')
+# units whose kernels read other lanes' registers through DPP inside inline asm (csrc/dpp64.h): hipcc cannot see those reads, so
+# the two DPP hazards (a VALU write of the source within 2 wait states, an EXEC write within 5) are checked on the device
+# assembly of the unit (tools/check_dpp_hazards.py) and a build with a hazard is refused
+DPP_UNITS = ('api_solve_dpp',)
 
 
 def units():
@@ -49,6 +53,9 @@ def _compile(src, hipcc, extra, verbose):
     if _newer(obj, [src] + headers()):
         return obj, '', 0
     cmd = [hipcc] + FLAGS + extra + ['-c', '-o', obj, src, '-Rpass-analysis=kernel-resource-usage']
+    unit = os.path.basename(src)[:-4]
+    if unit in DPP_UNITS:
+        cmd.insert(-1, '--save-temps=obj')
     if verbose:
         print(' '.join(cmd[:-1]), flush=True)
     t0 = time.time()
@@ -57,9 +64,35 @@ def _compile(src, hipcc, extra, verbose):
         os.remove(obj)
     if p.returncode == 0:
         open(obj[:-2] + '.remarks', 'w').write(p.stderr)          # registers / scratch / LDS / occupancy of every kernel of the unit
+    if p.returncode == 0 and unit in DPP_UNITS:
+        hazards = _dpp_hazards(unit)
+        if hazards:
+            os.remove(obj)
+            return obj, 'DPP hazards in the generated code:\n' + '\n'.join(hazards[:20]) + '\n', 1
     if verbose:
         print(f'  {os.path.basename(src)}: {time.time() - t0:.0f} s', flush=True)
     return obj, p.stderr, p.returncode
+
+
+def _dpp_hazards(unit):
+    """Runs tools/check_dpp_hazards.py's check over the device listing --save-temps left beside the object; removes the other temporaries."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tools'))
+    try:
+        import check_dpp_hazards as chk
+    finally:
+        sys.path.pop(0)
+    listing = os.path.join(OBJ, unit + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+    out, n_dpp = [], 0
+    for name, lines in chk.kernels(open(listing).read()).items():
+        n, bad = chk.check(lines, name)
+        n_dpp += n
+        out += [f'{name} +{ln}: {msg}' for ln, msg in bad]
+    if n_dpp == 0:
+        out.append(f'{listing}: no DPP instruction found (listing not understood?)')
+    for f in os.listdir(OBJ):
+        if (f.startswith(unit + '-') or f.startswith(unit + '.hip-')) and f != os.path.basename(listing):
+            os.remove(os.path.join(OBJ, f))
+    return out
 
 
 def build_hip(force=False, verbose=True, jobs=None):

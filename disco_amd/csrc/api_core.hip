@@ -280,6 +280,7 @@ const OptionInfo* option_table() {
         {"room_dma", "DISCO_ROOM_DMA", 1},
         {"overlap_solves", "DISCO_OVERLAP_SOLVES", 1},
         {"solve_f32", "DISCO_SOLVE_F32", 0},
+        {"solve_dpp", "DISCO_SOLVE_DPP", 1},
     };
     return t;
 }

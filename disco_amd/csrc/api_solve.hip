@@ -6,6 +6,11 @@
 using namespace disco;
 using namespace disco_host;
 
+namespace disco_host {
+// api_solve_dpp.hip: 9 <= P <= 16 in registers (k_solve_dpp.h)
+void launch_solve_dpp(int P, const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s);
+}
+
 template <int P>
 static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s, bool mixed) {
     if constexpr (P <= 4) {             // one thread per pencil (k_solve_small.h)
@@ -42,6 +47,10 @@ static int solve_dispatch(disco_ctx* ctx, const SolveSrc& src, int64_t n_prob, i
     if (P < 1 || P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: P must be in 1..16");
     if (n_prob / 4 > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: batch too large");
     hipStream_t st = (hipStream_t)s;
+    if (P >= 9 && ctx->opt[DISCO_OPT_SOLVE_DPP] != 0 && ctx->opt[DISCO_OPT_SOLVE_F32] == 0) {
+        launch_solve_dpp(P, src, n_prob, (double)mu, (c32*)w, (c32*)t1, st);
+        return check_launch(ctx, "k_gevd_mwf_r1_dpp");
+    }
     switch (P) {
 #define C_(P_) case P_: launch_solve<P_>(src, n_prob, (double)mu, (c32*)w, (c32*)t1, st, P_ >= 5 && ctx->opt[DISCO_OPT_SOLVE_F32] != 0); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)

@@ -46,6 +46,8 @@ __device__ __forceinline__ c64 zmulc(c64 a, c64 b) { return make_double2(a.x * b
 __device__ __forceinline__ c64 zadd(c64 a, c64 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ c64 zsub(c64 a, c64 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ c64 zscale(c64 a, double s) { return make_double2(a.x * s, a.y * s); }
+// c ? a : b on VALUES (`c ? x : y` on two c64 lvalues selects an ADDRESS, which keeps both objects out of registers)
+__device__ __forceinline__ c64 zsel(bool c, c64 a, c64 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 
 // Pin the point where a prefetched value must have landed: an empty asm that "modifies" the register makes hipcc
 // place the s_waitcnt for its load HERE instead of wherever register coalescing leaves the first real use

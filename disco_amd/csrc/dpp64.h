@@ -1,0 +1,162 @@
+// float64 arithmetic against a value held by ANOTHER lane of the same 16-lane row, without LDS: gfx950's DPP control
+// `row_newbcast:n` (lane n of every row of 16 as src0) on the two 64-bit VOP2 forms that take it, v_fmac_f64 and v_mov_b64.
+// Measured on the MI355X (tools/gpu/kbench/dpp64_rate.hip): v_fmac_f64_dpp issues at the rate of the plain v_fma_f64
+// (2.0 ns per wave64 instruction and SIMD, dependent chains included); the LDS form it replaces -- one broadcast ds_read_b128
+// per complex multiply-add -- runs at 3.8 ns per v_fma_f64 with every SIMD of a CU reading.
+//
+// A group of 16 lanes that owns one small dense problem (lane j = column j, k_solve_dpp.h) reads "entry i of lane k's column"
+// as `row_newbcast:k` on the register that holds entry i: the register index is the same in every lane, the lane index is an
+// immediate.  What DPP cannot do is read a register whose INDEX depends on the receiving lane (a transposition): those go
+// through LDS once.
+//
+// Hazards the compiler cannot see inside inline asm (GCNHazardRecognizer::checkDPPHazards): a VGPR written by a VALU
+// instruction must not be read through DPP within the next 2 wait states, and EXEC must not have been written within the last 5.
+// Every helper below that starts a run of DPP reads first pins the values it is about to read (an empty asm that takes them as
+// inputs: they are computed BEFORE this point) and then issues s_nop 1; code that leaves a divergent region calls
+// DISCO_DPP_SETTLE() before the next helper.  disco_amd/build.py checks both rules on the generated ISA of every kernel that
+// uses these forms (check_dpp_hazards).
+//
+// The g++ emulator build (tests/hipemu) has no lanes to read from: the same helpers fetch the other lane's values through the
+// emulator's wave exchange area and run the same fused multiply-adds in the same order, so results are bit-identical.
+#pragma once
+#include "common.h"
+
+#include <type_traits>
+
+namespace disco {
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// sign pattern of a complex multiply-add against a broadcast value S (src0, through DPP) and an own value o:
+//   acc.x += (n0 ? -1 : 1) S.x o.x + (n1 ? -1 : 1) S.y o.y;   acc.y += (n2 ? -1 : 1) S.x o.y + (n3 ? -1 : 1) S.y o.x
+enum ZMode {
+    Z_ADD_SO = 0x4,      // acc += S o                 (+, -, +, +)
+    Z_SUB_SO = 0xB,      // acc -= S o                 (-, +, -, -)
+    Z_SUB_OCS = 0xE,     // acc -= o conj(S)           (-, -, -, +)
+    Z_ADD_COS = 0x2,     // acc += conj(o) S           (+, +, -, +)
+    Z_SUB_COS = 0xD,     // acc -= conj(o) S           (-, -, +, -)
+};
+
+#if defined(__clang__)
+#define DISCO_DPP_SETTLE() asm volatile("s_nop 4")
+__device__ __forceinline__ void dpp_pin(const double& a, const double& b) { asm volatile("" ::"v"(a), "v"(b)); }
+__device__ __forceinline__ void dpp_pin(const c64& a) { asm volatile("" ::"v"(a.x), "v"(a.y)); }
+#define DISCO_DPP_SOURCES_READY() asm volatile("s_nop 1")
+
+// acc += (NEG ? -s@lane K : s@lane K) * o
+template <int K, bool NEG>
+__device__ __forceinline__ void fmac_bc(double& acc, const double& s, const double& o) {
+    if constexpr (NEG)
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(o), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(o), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ double mov_bc(const double& s) {
+    double r;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(s), "n"(K));
+    return r;
+}
+template <int K, int MODE>
+__device__ __forceinline__ void zfma_bc(c64& acc, const c64& S, const c64& o) {
+    fmac_bc<K, (MODE & 8) != 0>(acc.x, S.x, o.x);
+    fmac_bc<K, (MODE & 4) != 0>(acc.x, S.y, o.y);
+    fmac_bc<K, (MODE & 2) != 0>(acc.y, S.x, o.y);
+    fmac_bc<K, (MODE & 1) != 0>(acc.y, S.y, o.x);
+}
+#else
+#define DISCO_DPP_SETTLE() ((void)0)
+#endif
+
+// the same multiply-add with S already in hand (emulator build; also the statement of what zfma_bc computes)
+template <int MODE>
+__device__ __forceinline__ void zfma_plain(c64& acc, const c64& S, const c64& o) {
+    acc.x = fma((MODE & 8) ? -S.x : S.x, o.x, acc.x);
+    acc.x = fma((MODE & 4) ? -S.y : S.y, o.y, acc.x);
+    acc.y = fma((MODE & 2) ? -S.x : S.x, o.y, acc.y);
+    acc.y = fma((MODE & 1) ? -S.y : S.y, o.x, acc.y);
+}
+
+// The first N entries of lane K's register array `a` (same array, same indices, in every lane).  The array must not change while
+// the view is in use.
+template <int K, int N, int NA>
+struct BcRow {
+#if defined(__clang__)
+    const c64 (&src)[NA];
+    __device__ __forceinline__ explicit BcRow(const c64 (&a)[NA]) : src(a) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) dpp_pin(a[i]);
+        DISCO_DPP_SOURCES_READY();
+    }
+    template <int MODE>
+    __device__ __forceinline__ void fma(c64& acc, int i, const c64& o) const { zfma_bc<K, MODE>(acc, src[i], o); }
+    __device__ __forceinline__ double re(int i) const { return mov_bc<K>(src[i].x); }
+#else
+    c64 tmp[N];
+    explicit BcRow(const c64 (&a)[NA]) { hipemu::gather_lane(a, sizeof(c64) * N, (hipemu::t_lane & ~15) + K, tmp); }
+    template <int MODE>
+    void fma(c64& acc, int i, const c64& o) const { zfma_plain<MODE>(acc, tmp[i], o); }
+    double re(int i) const { return tmp[i].x; }
+#endif
+};
+
+// One complex value per lane, read from any lane of the row.
+struct BcVec {
+#if defined(__clang__)
+    const c64 v;
+    __device__ __forceinline__ explicit BcVec(const c64& x) : v(x) {
+        dpp_pin(v);
+        DISCO_DPP_SOURCES_READY();
+    }
+    template <int K, int MODE>
+    __device__ __forceinline__ void fma(c64& acc, const c64& o) const { zfma_bc<K, MODE>(acc, v, o); }
+    template <int K>
+    __device__ __forceinline__ c64 get() const { return make_double2(mov_bc<K>(v.x), mov_bc<K>(v.y)); }
+#else
+    c64 all[16];
+    explicit BcVec(const c64& x) { hipemu::gather_row16(&x, sizeof(c64), all); }
+    template <int K, int MODE>
+    void fma(c64& acc, const c64& o) const { zfma_plain<MODE>(acc, all[K], o); }
+    template <int K>
+    c64 get() const { return all[K]; }
+#endif
+};
+
+// One double per lane, read from any lane of the row; sum over the first P lanes in lane order (every lane gets the same bits).
+struct BcReal {
+#if defined(__clang__)
+    const double v;
+    __device__ __forceinline__ explicit BcReal(const double& x) : v(x) {
+        dpp_pin(v, v);
+        DISCO_DPP_SOURCES_READY();
+    }
+    template <int K>
+    __device__ __forceinline__ double get() const { return mov_bc<K>(v); }
+    template <int P>
+    __device__ __forceinline__ double sum() const {
+        double r = mov_bc<0>(v);
+        const double one = 1.0;
+        static_for<1, P>([&](auto K) { fmac_bc<decltype(K)::value, false>(r, v, one); });
+        return r;
+    }
+#else
+    double all[16];
+    explicit BcReal(const double& x) { hipemu::gather_row16(&x, sizeof(double), all); }
+    template <int K>
+    double get() const { return all[K]; }
+    template <int P>
+    double sum() const {
+        double r = all[0];
+        for (int k = 1; k < P; ++k) r = fma(all[k], 1.0, r);
+        return r;
+    }
+#endif
+};
+
+}  // namespace disco

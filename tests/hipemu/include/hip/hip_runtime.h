@@ -64,6 +64,7 @@ struct WaveState {
     Bar bar;
     uint64_t slot[64];
     int n;                       // lanes of this wave (valid shuffle sources)
+    unsigned char xbuf[64][512]; // per-lane exchange area of gather_lane / gather_row16 (DPP broadcast forms, csrc/dpp64.h)
 };
 struct BlockState {
     Bar bar;
@@ -223,6 +224,22 @@ inline T shfl_abs(T v, int src_abs) {
     T out;
     std::memcpy(&out, &r, sizeof(T));
     return out;
+}
+// `bytes` (<= 512) of lane src_abs's `mine` -> out, for every lane of the wave at once (one rendezvous pair)
+inline void gather_lane(const void* mine, size_t bytes, int src_abs, void* out) {
+    std::memcpy(t_wave->xbuf[t_lane], mine, bytes);
+    bar_wait(t_wave->bar);
+    std::memcpy(out, t_wave->xbuf[(src_abs >= 0 && src_abs < t_wave->n) ? src_abs : t_lane], bytes);
+    bar_wait(t_wave->bar);
+}
+// every lane's `mine` (bytes <= 32) of this lane's row of 16 -> out[16][bytes]
+inline void gather_row16(const void* mine, size_t bytes, void* out) {
+    std::memcpy(t_wave->xbuf[t_lane], mine, bytes);
+    bar_wait(t_wave->bar);
+    const int base = t_lane & ~15;
+    for (int l = 0; l < 16; ++l)
+        std::memcpy((unsigned char*)out + l * bytes, t_wave->xbuf[(base + l) < t_wave->n ? base + l : t_lane], bytes);
+    bar_wait(t_wave->bar);
 }
 }  // namespace hipemu
 
