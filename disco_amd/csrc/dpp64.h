@@ -49,26 +49,43 @@ __device__ __forceinline__ void dpp_pin(const double& a, const double& b) { asm 
 __device__ __forceinline__ void dpp_pin(const c64& a) { asm volatile("" ::"v"(a.x), "v"(a.y)); }
 #define DISCO_DPP_SOURCES_READY() asm volatile("s_nop 1")
 
-// acc += (NEG ? -s@lane K : s@lane K) * o
-template <int K, bool NEG>
-__device__ __forceinline__ void fmac_bc(double& acc, const double& s, const double& o) {
-    if constexpr (NEG)
-        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(o), "n"(K));
-    else
-        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(o), "n"(K));
-}
 template <int K>
 __device__ __forceinline__ double mov_bc(const double& s) {
     double r;
     asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(s), "n"(K));
     return r;
 }
+// the four multiply-adds of one complex multiply-add as ONE asm statement: between two asm statements of which the second reads a
+// register the first wrote, hipcc inserts `s_nop 0` (it cannot see inside them; gfx950's forwarding hazards are assumed) -- 437 of
+// the 1 601 instructions of a P = 15 squaring before this.  The hardware interlocks the accumulator chain itself.
+#define DISCO_ZFMA_ASM(N0, N1, N2, N3)                                                                      \
+    asm volatile("v_fmac_f64_dpp %0, " N0 "%2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n"             \
+                 "v_fmac_f64_dpp %0, " N1 "%3, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n"             \
+                 "v_fmac_f64_dpp %1, " N2 "%2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n"             \
+                 "v_fmac_f64_dpp %1, " N3 "%3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"                \
+                 : "+v"(acc.x), "+v"(acc.y)                                                                 \
+                 : "v"(S.x), "v"(S.y), "v"(o.x), "v"(o.y), "n"(K))
 template <int K, int MODE>
 __device__ __forceinline__ void zfma_bc(c64& acc, const c64& S, const c64& o) {
-    fmac_bc<K, (MODE & 8) != 0>(acc.x, S.x, o.x);
-    fmac_bc<K, (MODE & 4) != 0>(acc.x, S.y, o.y);
-    fmac_bc<K, (MODE & 2) != 0>(acc.y, S.x, o.y);
-    fmac_bc<K, (MODE & 1) != 0>(acc.y, S.y, o.x);
+    static_assert(MODE == Z_ADD_SO || MODE == Z_SUB_SO || MODE == Z_SUB_OCS || MODE == Z_ADD_COS || MODE == Z_SUB_COS, "sign pattern");
+    if constexpr (MODE == Z_ADD_SO) DISCO_ZFMA_ASM("", "-", "", "");
+    if constexpr (MODE == Z_SUB_SO) DISCO_ZFMA_ASM("-", "", "-", "-");
+    if constexpr (MODE == Z_SUB_OCS) DISCO_ZFMA_ASM("-", "-", "-", "");
+    if constexpr (MODE == Z_ADD_COS) DISCO_ZFMA_ASM("", "", "-", "");
+    if constexpr (MODE == Z_SUB_COS) DISCO_ZFMA_ASM("-", "-", "", "-");
+}
+// sum over the 16 lanes of the row, in lane order (lanes that do not take part must hold 0): one statement, see above
+__device__ __forceinline__ double sum16_bc(const double& v) {
+    double r;
+    const double one = 1.0;
+#define DISCO_S16(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n"
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" DISCO_S16(1) DISCO_S16(2) DISCO_S16(3) DISCO_S16(4) DISCO_S16(5)
+                     DISCO_S16(6) DISCO_S16(7) DISCO_S16(8) DISCO_S16(9) DISCO_S16(10) DISCO_S16(11) DISCO_S16(12) DISCO_S16(13) DISCO_S16(14)
+                         "v_fmac_f64_dpp %0, %1, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(r)
+                 : "v"(v), "v"(one));
+#undef DISCO_S16
+    return r;
 }
 #else
 #define DISCO_DPP_SETTLE() ((void)0)
@@ -128,7 +145,8 @@ struct BcVec {
 #endif
 };
 
-// One double per lane, read from any lane of the row; sum over the first P lanes in lane order (every lane gets the same bits).
+// One double per lane, read from any lane of the row; sum over the 16 lanes of the row in lane order (every lane gets the same
+// bits; lanes that do not take part must hold 0).
 struct BcReal {
 #if defined(__clang__)
     const double v;
@@ -138,22 +156,15 @@ struct BcReal {
     }
     template <int K>
     __device__ __forceinline__ double get() const { return mov_bc<K>(v); }
-    template <int P>
-    __device__ __forceinline__ double sum() const {
-        double r = mov_bc<0>(v);
-        const double one = 1.0;
-        static_for<1, P>([&](auto K) { fmac_bc<decltype(K)::value, false>(r, v, one); });
-        return r;
-    }
+    __device__ __forceinline__ double sum() const { return sum16_bc(v); }
 #else
     double all[16];
     explicit BcReal(const double& x) { hipemu::gather_row16(&x, sizeof(double), all); }
     template <int K>
     double get() const { return all[K]; }
-    template <int P>
     double sum() const {
         double r = all[0];
-        for (int k = 1; k < P; ++k) r = fma(all[k], 1.0, r);
+        for (int k = 1; k < 16; ++k) r = fma(all[k], 1.0, r);
         return r;
     }
 #endif
