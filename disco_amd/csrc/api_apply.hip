@@ -33,10 +33,24 @@ extern "C" int disco_apply(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     if (!launched) {
         const int tiles = (ctx->F + 63) / 64;
         const long long Gg = (long long)ctx->geom_rooms * ctx->Kl;
-        int t_chunks = (int)std::min<long long>(std::max<long long>(1, (8192 + Gg * tiles - 1) / (Gg * tiles)), std::max(1, ctx->T / 8));
+#ifndef DISCO_APPLY_ITEMS
+#define DISCO_APPLY_ITEMS 32768
+#endif
+        int t_chunks = (int)std::min<long long>(std::max<long long>(1, (DISCO_APPLY_ITEMS + Gg * tiles - 1) / (Gg * tiles)), std::max(1, ctx->T / 8));
         while (G * tiles * t_chunks > 0x7ffffff0LL && t_chunks > 1) t_chunks >>= 1;
         const long long items_m = G * tiles * t_chunks;
         const dim3 grid_m((unsigned)((items_m + DISCO_APPLY_XCD - 1) / DISCO_APPLY_XCD * DISCO_APPLY_XCD));      // ids are dealt over the XCDs
+        if ((M == 4 || M == 8) && KR >= 1) {        // contiguous granule loads through a wave-private LDS tile (k_apply_mq)
+            const int krt = KR <= 1 ? 1 : (KR <= 3 ? 3 : (KR <= 7 ? 7 : 15));
+#define Q_(M_, KRT_)                                                                                                                  \
+    if (M == M_ && krt == KRT_)                                                                                                       \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_mq<M_, KRT_>), grid_m, dim3(64), 0, (hipStream_t)s, (const c32*)X, (const c32*)Z,  \
+                           (const c32*)w, (c32*)out, KR, c.nodes, ctx->T, ctx->F, conj_w, tiles, t_chunks, ctx->Kl, ctx->k0, ctx->zblk, \
+                           (long long)c.rooms);
+            Q_(4, 1) Q_(4, 3) Q_(4, 7) Q_(4, 15) Q_(8, 1) Q_(8, 3) Q_(8, 7) Q_(8, 15)
+#undef Q_
+            return check_launch(ctx, "k_apply_mq");
+        }
         switch (M) {
 #define C_(M_)                                                                                                          \
     case M_:                                                                                                            \

@@ -82,6 +82,31 @@ __device__ __forceinline__ c64 zsel(bool c, c64 a, c64 b) { return make_double2(
 #define DISCO_KERNEL_ALIGN
 #endif
 
+// x + the value of lane (lane ^ 1) / (lane ^ 2) of the same quad: DPP quad_perm moves ride the VALU (a few cycles; the
+// ds_bpermute form of __shfl_xor is an LDS-crossbar round trip of ~100 cycles in the middle of a dependent chain)
+template <int XOR>
+__device__ __forceinline__ float quad_xor_add(float x) {
+#if defined(__clang__)
+    constexpr int ctrl = XOR == 1 ? 0xB1 : 0x4E;       // quad_perm [1,0,3,2] / [2,3,0,1]
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false);
+    return x + __int_as_float(y);
+#else
+    return x + __shfl_xor(x, XOR);
+#endif
+}
+
+// LDS exchange fences.  The exchange buffers are WAVE-PRIVATE, so no s_barrier is needed: a wave's DS
+// instructions execute in issue order, and all that has to be prevented is (a) the compiler moving a read
+// above the writes it depends on through another lane, (b) a read issuing before this wave's own writes have
+// been accepted.  RAW = `s_waitcnt lgkmcnt(0)` (0xC07F: vmcnt/expcnt untouched, so global prefetches stay in
+// flight) + a scheduling barrier; WAR = scheduling barrier only.
+#define DISCO_LDS_RAW()                       \
+    do {                                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   \
+        __builtin_amdgcn_wave_barrier();      \
+    } while (0)
+#define DISCO_LDS_WAR() __builtin_amdgcn_wave_barrier()
+
 // The wave index as a PROVABLY wave-uniform value: anything derived from threadIdx is divergent to hipcc, which
 // then wraps every access guarded by a per-wave condition in exec-mask branches (one per load).
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

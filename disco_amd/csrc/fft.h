@@ -13,18 +13,6 @@
 
 namespace disco {
 
-// LDS exchange fences.  The exchange buffers are WAVE-PRIVATE, so no s_barrier is needed: a wave's DS
-// instructions execute in issue order, and all that has to be prevented is (a) the compiler moving a read
-// above the writes it depends on through another lane, (b) a read issuing before this wave's own writes have
-// been accepted.  RAW = `s_waitcnt lgkmcnt(0)` (0xC07F: vmcnt/expcnt untouched, so global prefetches stay in
-// flight) + a scheduling barrier; WAR = scheduling barrier only.
-#define DISCO_LDS_RAW()                       \
-    do {                                      \
-        __builtin_amdgcn_s_waitcnt(0xC07F);   \
-        __builtin_amdgcn_wave_barrier();      \
-    } while (0)
-#define DISCO_LDS_WAR() __builtin_amdgcn_wave_barrier()
-
 template <int N>
 struct FftPlan;
 template <>

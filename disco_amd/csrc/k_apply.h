@@ -90,8 +90,20 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64) void k_apply_m(const c32* __
         const long long tf = (long long)t * F + f;
         const c32* xp = X + (g * TF + tf) * M;
         c32 x[M];
+#if defined(DISCO_APPLY_TIMING_EXPERIMENT)      // timing only (wrong results): the wave's 4 KB of X as 16-byte-per-lane contiguous loads
+        {
+            const float4* xw = reinterpret_cast<const float4*>(X + (g * TF + (long long)t * F + tile * 64) * M);
+#pragma unroll
+            for (int i = 0; i < M / 2; ++i) {
+                const float4 q = xw[i * 64 + threadIdx.x];
+                x[2 * i] = make_float2(q.x, q.y);
+                x[2 * i + 1] = make_float2(q.z, q.w);
+            }
+        }
+#else
 #pragma unroll
         for (int i = 0; i < M; ++i) x[i] = xp[i];
+#endif
         float ar = 0.f, ai = 0.f;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
@@ -108,6 +120,112 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64) void k_apply_m(const c32* __
             }
         }
         out[g * TF + tf] = make_float2(ar, ai);
+    }
+}
+
+// The same pass for M = 4 / 8 with the node's spectra fetched as CONTIGUOUS 16-byte granules (lane i of load r takes granule
+// r * 64 + i of the tile's frame: 1 KiB per wave-load) instead of "every lane its own bin's M values" (16 bytes every 8 M bytes: one
+// memory request per lane; a timing-only build with contiguous loads measured 4.57 instead of 5.5 ms per C5 launch).  The granules
+// go through a wave-private LDS tile -- written in load order, read back bin-major, XOR-swizzled so that both directions are
+// conflict-free (position (bin, p') holds granule p' ^ swz(bin), as in k_room_cov_dma) -- and the arithmetic is k_apply_m's,
+// bit for bit.  (A first form that kept the granules where they landed and summed the MH lanes of a bin with DPP moves spread
+// the remote rows over those lanes: 8 four-segment z loads per frame instead of 7 contiguous ones, 6.04 ms.)
+// KRT: the number of remote rows the loop is unrolled for, >= KR (1 / 3 / 7 / 15); rows beyond KR re-read row KR - 1 with a zero tap, so that
+// every load of a frame -- the granules and the remote rows -- is issued unconditionally, one frame ahead of its use, and the loop waits once.
+template <int M, int KRT>
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64) void k_apply_mq(const c32* __restrict__ X, const c32* __restrict__ Z,
+                                                  const c32* __restrict__ w, c32* __restrict__ out, int KR,
+                                                  int K, int T, int F, int conj_w, int tiles, int t_chunks, int Kl, int k0, int zblk,
+                                                  long long R) {
+    static_assert(M == 4 || M == 8, "whole 256-byte bank rows per group of bins");
+    constexpr int MH = M / 2, BPR = 16 / MH;            // granules per bin; bins per 256-byte bank row
+    __shared__ float4 sx[64 * MH];
+    const int P = M + KR;
+    const long long n_items = R * Kl * (long long)tiles * t_chunks;
+    long long item = (long long)(blockIdx.x % DISCO_APPLY_XCD) * (gridDim.x / DISCO_APPLY_XCD) + blockIdx.x / DISCO_APPLY_XCD;
+    if (item >= n_items) return;
+    const int kl = (int)(item % Kl);
+    item /= Kl;
+    const int tc = (int)(item % t_chunks);
+    item /= t_chunks;
+    const int tile = (int)(item % tiles);
+    const long long g = (item / tiles) * Kl + kl;
+    const int lane = (int)threadIdx.x;
+    const int f = tile * 64 + lane;
+    const bool live = f < F;
+    const int fc = live ? f : F - 1;                    // the ragged last tile: spare lanes work on bin F - 1 and store nothing
+    const int t_len = (T + t_chunks - 1) / t_chunks;
+    const int t0 = tc * t_len, t1 = min(T, t0 + t_len);
+    if (t0 >= t1) return;
+    const long long r_ = g / Kl;
+    const int k = k0 + (int)(g % Kl);
+    const long long TF = (long long)T * F;
+    const float sgn = conj_w ? -1.f : 1.f;
+    const c32* wf = w + (g * F + fc) * (long long)P;
+    c32 wl[M], wr[KRT];
+#pragma unroll
+    for (int i = 0; i < M; ++i) wl[i] = make_float2(wf[i].x, sgn * wf[i].y);
+    const c32* zrow[KRT];                               // (wave-uniform)
+#pragma unroll
+    for (int jj = 0; jj < KRT; ++jj) {
+        wr[jj] = jj < KR ? make_float2(wf[M + jj].x, sgn * wf[M + jj].y) : make_float2(0.f, 0.f);
+        const int jc = jj < KR ? jj : KR - 1;
+        zrow[jj] = Z + z_plane(r_, jc < k ? jc : jc + 1, K, R, zblk) * TF + fc;
+    }
+    // loader: granule r * 64 + lane of the tile's frame = (bin b, granule lane % MH), clamped like fc; LDS position of that granule
+    int lgo[MH], lpos[MH];
+#pragma unroll
+    for (int r = 0; r < MH; ++r) {
+        const int gi = r * 64 + lane, b = gi / MH, pp = gi % MH;
+        lgo[r] = min(tile * 64 + b, F - 1) * MH + pp;
+        lpos[r] = b * MH + (pp ^ ((b / BPR) % MH));
+    }
+    const int swz = (lane / BPR) % MH;
+    const float4* Xg = reinterpret_cast<const float4*>(X + g * TF * M);
+    float q[MH][4];                                     // (scalars on purpose: a float4 copied global -> private -> LDS stays a memcpy through scratch)
+    c32 zq[KRT];
+    auto fetch = [&](int t) {
+        const long long tF = (long long)t * F;
+#pragma unroll
+        for (int r = 0; r < MH; ++r) {
+            const float4 v = Xg[tF * MH + lgo[r]];
+            q[r][0] = v.x;
+            q[r][1] = v.y;
+            q[r][2] = v.z;
+            q[r][3] = v.w;
+        }
+#pragma unroll
+        for (int jj = 0; jj < KRT; ++jj) zq[jj] = zrow[jj][tF];
+    };
+    fetch(t0);
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int r = 0; r < MH; ++r) sx[lpos[r]] = make_float4(q[r][0], q[r][1], q[r][2], q[r][3]);
+        c32 z[KRT];
+#pragma unroll
+        for (int jj = 0; jj < KRT; ++jj) z[jj] = zq[jj];
+        DISCO_LDS_RAW();
+        fetch(min(t + 1, t1 - 1));                      // the next frame is on its way while this one is filtered (the last one again at the end)
+        c32 x[M];
+#pragma unroll
+        for (int pp = 0; pp < MH; ++pp) {
+            const float4 v = sx[lane * MH + (pp ^ swz)];
+            x[2 * pp] = make_float2(v.x, v.y);
+            x[2 * pp + 1] = make_float2(v.z, v.w);
+        }
+        DISCO_LDS_RAW();                                // the reads have returned before the next frame overwrites the tile
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            ar = fmaf(wl[i].x, x[i].x, fmaf(-wl[i].y, x[i].y, ar));
+            ai = fmaf(wl[i].x, x[i].y, fmaf(wl[i].y, x[i].x, ai));
+        }
+#pragma unroll
+        for (int jj = 0; jj < KRT; ++jj) {
+            ar = fmaf(wr[jj].x, z[jj].x, fmaf(-wr[jj].y, z[jj].y, ar));
+            ai = fmaf(wr[jj].x, z[jj].y, fmaf(wr[jj].y, z[jj].x, ai));
+        }
+        if (live) out[g * TF + (long long)t * F + fc] = make_float2(ar, ai);
     }
 }
 

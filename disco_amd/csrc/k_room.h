@@ -251,19 +251,6 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 #define DISCO_ROOM_DEPTH 4
 #endif
 
-// x + the value of lane (lane ^ 1) / (lane ^ 2) of the same quad: DPP quad_perm moves ride the VALU (a few cycles; the
-// ds_bpermute form of __shfl_xor is an LDS-crossbar round trip of ~100 cycles in the middle of a dependent chain)
-template <int XOR>
-__device__ __forceinline__ float quad_xor_add(float x) {
-#if defined(__clang__)
-    constexpr int ctrl = XOR == 1 ? 0xB1 : 0x4E;       // quad_perm [1,0,3,2] / [2,3,0,1]
-    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false);
-    return x + __int_as_float(y);
-#else
-    return x + __shfl_xor(x, XOR);
-#endif
-}
-
 template <int M, int K>
 struct alignas(16) RoomRing {
     using Gm = RoomGeom<M, K>;
