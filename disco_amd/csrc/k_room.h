@@ -237,7 +237,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 // k_room_cov keeps ONE frame of the tile in flight per workgroup (registers: 112 of a lane's 168 are accumulators, a second
 // frame does not fit) and there is one workgroup per CU: 4.4 MB in flight over the chip (8.6 ms per C5 launch; this variant: 7.1 ms,
 // the two passes it replaces: 11.0 ms).  Here the spectra and masks go from HBM straight into an LDS ring of
-// DISCO_ROOM_DEPTH frames (global_load_lds_dwordx4 / _dword: no registers), issued THREE frames ahead:
+// DISCO_ROOM_DEPTH frames (global_load_lds_dwordx4 / _dword: no registers), issued DISCO_ROOM_AHEAD = 3 frames ahead:
 //   iteration t:  issue frame t + 3  ->  fold frame t  ->  wait until only that issue is outstanding (frame t + 2 has landed)
 //                 ->  form z(t + 1) from the ring (own granule + taps, cross-lane sum), publish it  ->  barrier.
 // An LDS-DMA wave-load writes 64 lanes x 16 B to consecutive LDS bytes, so a lane's LDS position is fixed and the granule it
@@ -247,8 +247,13 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 // LDS read, the ring index being a run-time value): after the wait of iteration t at most the loads of frame t + 3 are
 // outstanding; VMEM operations return in order, the z stores of the previous iteration are older than that issue.  The kernel
 // must not spill (a scratch access in the loop would shift the count): build.py checks the resource usage.
+#ifndef DISCO_ROOM_AHEAD
+#define DISCO_ROOM_AHEAD 3              // frames between a frame's LDS-DMA issue and its fold.  3 = one iteration between an issue and the wait
+                                        // for it; 4 / 5 (two / three iterations, 16 KB of LDS each) measured 14.12 / 14.19 ms against 14.08 ms per
+                                        // C5 step (profiles/r03_n_*): the pass is not waiting for its loads
+#endif
 #ifndef DISCO_ROOM_DEPTH
-#define DISCO_ROOM_DEPTH 4
+#define DISCO_ROOM_DEPTH (DISCO_ROOM_AHEAD + 1)
 #endif
 
 template <int M, int K>
@@ -291,14 +296,20 @@ __device__ __forceinline__ void lds_dma4(const void* gbase, unsigned off, void* 
     reinterpret_cast<float*>(lds_wave)[lane] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gbase) + off);
 #endif
 }
-// at most N vector-memory operations of this wave still outstanding (N <= 3 here)
+// at most N vector-memory operations of this wave still outstanding (N <= 9 here)
 __device__ __forceinline__ void vm_wait(int n) {
 #if defined(__clang__)
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     }
 #else
     (void)n;
@@ -311,7 +322,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
     constexpr int KR = Gm::KR, P = Gm::P, NP = Gm::NP, NB = Gm::NB, NA = Gm::NA, WA = Gm::WA, NT = Gm::NT, MH = Gm::MH;
     constexpr int NITEMS = Gm::NITEMS, NL = Gm::NL, D = DISCO_ROOM_DEPTH;
     constexpr int BPR = 16 / MH;                       // bins per 256-byte bank row of granules
-    static_assert(D >= 4 && NL + 1 <= 3, "three frames ahead; vm_wait knows 0..3");
+    static_assert(D == DISCO_ROOM_AHEAD + 1 && (DISCO_ROOM_AHEAD - 2) * (NL + 1) <= 9, "AHEAD frames ahead; vm_wait knows 0..9");
     const int T = a.T, F = a.F;
     long long item = blockIdx.x;
     const int c = (int)(item % a.chunks);
@@ -447,20 +458,22 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         }
     };
 
-    issue(t0, 0);
-    issue(t0 + 1, 1);
-    issue(t0 + 2, 2);
-    vm_wait(nload);                                     // frames t0 and t0 + 1 have landed (this wave's part)
+    constexpr int AH = DISCO_ROOM_AHEAD;                // frames a load is issued ahead of its fold
+#pragma unroll
+    for (int i = 0; i < AH; ++i) issue(t0 + i, i);
+    vm_wait((AH - 2) * nload);                          // frames t0 and t0 + 1 have landed (this wave's part)
     __syncthreads();                                    // ... and everybody else's; the taps are in place
     form_z(t0, 0);
     store_z(t0);
     __syncthreads();
     int s0 = 0;                                         // ring slot of frame t
     for (int t = t0; t < t1; ++t) {
-        issue(t + 3, (s0 + 3) % D);                     // the slot frame t - 1 was folded from (D = 4)
+        issue(t + AH, (s0 + AH) % D);                   // the slot frame t - 1 was folded from (D = AH + 1)
         if (t + 1 < t1) form_z(t + 1, (s0 + 1) % D);    // frame t + 1 landed (and was published) an iteration ago; into the OTHER z buffer
         fold(t, s0);
-        vm_wait(nload);                                 // only the issue above may still be in flight: frame t + 2 is in LDS
+        vm_wait((AH - 2) * nload);                      // only the last AH - 2 issues may still be in flight: frame t + 2 is in LDS (the z stores
+                                                        // between them are younger than frame t + 2 either way: whether or not stores retire in
+                                                        // order with loads, AH - 2 issues' worth of outstanding operations cannot include it)
         if (t + 1 < t1) store_z(t + 1);                 // after the counted wait: the stores never stand between an issue and its wait
         __syncthreads();
         s0 = (s0 + 1) % D;
