@@ -88,6 +88,7 @@ PROTOTYPES = {
     'disco_online_mwf': (_int, [_vp, _vp, _vp, _vp, _int, _f, _f, _int, _f, _vp, _vp, _vp]),
     'disco_selftest_stream': (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     'disco_selftest_pk': (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'disco_selftest_dpp': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'disco_tango_online': (_int, [_vp, _vp, _vp, _vp, _f, _int, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

@@ -524,9 +524,10 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     int rc = acquire_ws(ctx, workspace, workspace_bytes, l, &ws, "disco_tango_enhance_iterated");
     if (rc) return rc;
     const PathArgs a{y, mask_z, mask_w, out, z_y, yf, ws};
-    // (the wide shapes gain nothing from the overlapped form -- C5: 46.4 ms plain, 48.0 / 48.4 ms overlapped: their room pass takes a
-    // whole CU per workgroup -- so it is used here only when forced, option values 2 / 3)
-    if (ctx->opt[DISCO_OPT_OVERLAP_SOLVES] >= 2 && overlap_applies(ctx) && ctx->half[0] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
+    // The overlapped form on the wide shapes: with the LDS group solver it lost (C5: 46.4 ms plain, 48.0 / 48.4 ms overlapped -- the room
+    // pass takes a whole CU per workgroup and the solver's LDS blocks compete with it); with the register / DPP solver (k_solve_dpp.h:
+    // 15 KB of LDS per wave, float64 VALU only) it pays: 38.40 -> 37.88 ms (profiles/r03_o_C5_overlap*.json).  Default like the fused route.
+    if (overlap_applies(ctx) && ctx->half[0] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
         Steps st[2];
         for (int h = 0; h < 2; ++h) iterated_steps(ctx->half[h], child_args(ctx, a, h), iters, st[h]);
         return run_pipelined(ctx, st, s);

@@ -27,3 +27,11 @@ void launch_solve_dpp(int P, const SolveSrc& src, long long n_prob, double mu, c
 }
 
 }  // namespace disco_host
+
+extern "C" int disco_selftest_dpp(disco_ctx* ctx, const double* a, const double* b, int64_t n, double* out_hw, double* out_ref, disco_stream s) {
+    DISCO_ENTER(ctx);
+    static_assert(DPP_SELFTEST_OPS == DISCO_DPP_SELFTEST_OPS, "header and kernel agree");
+    if (!a || !b || !out_hw || !out_ref || n < 64 || n % 64) return fail(ctx, DISCO_E_ARG, "disco_selftest_dpp: bad argument (n: a multiple of 64)");
+    hipLaunchKernelGGL(k_dpp_selftest, dim3((unsigned)(n / 64)), dim3(64), 0, (hipStream_t)s, (const c64*)a, (const c64*)b, (c64*)out_hw, (c64*)out_ref);
+    return check_launch(ctx, "k_dpp_selftest");
+}

@@ -170,4 +170,53 @@ struct BcReal {
 #endif
 };
 
+// ---- self-test (disco_selftest_dpp): every helper above through its instruction form and through __shfl + the plain statement
+constexpr int DPP_SELFTEST_OPS = 8;
+template <bool HW>
+__device__ __forceinline__ void dpp_selftest_ops(const c64 a, const c64 b, c64* o) {
+    auto via_shfl = [&](int k, c64 v) { return make_double2(__shfl(v.x, k, 16), __shfl(v.y, k, 16)); };
+#pragma unroll
+    for (int q = 0; q < 5; ++q) o[q] = a;
+    if constexpr (HW) {
+        const BcVec bv(b);
+        bv.template fma<0, Z_ADD_SO>(o[0], a);
+        bv.template fma<5, Z_SUB_SO>(o[1], a);
+        bv.template fma<9, Z_SUB_OCS>(o[2], a);
+        bv.template fma<15, Z_ADD_COS>(o[3], a);
+        bv.template fma<3, Z_SUB_COS>(o[4], a);
+        o[5] = make_double2(BcReal(b.x).template get<7>(), BcReal(b.y).template get<12>());
+        o[6] = make_double2(BcReal(a.x).sum(), BcReal(b.y).sum());
+        const c64 arr[2] = {a, b};
+        const BcRow<6, 2, 2> row(arr);
+        o[7] = make_double2(row.re(0), 0.0);
+        row.template fma<Z_ADD_SO>(o[7], 1, a);
+    } else {
+        zfma_plain<Z_ADD_SO>(o[0], via_shfl(0, b), a);
+        zfma_plain<Z_SUB_SO>(o[1], via_shfl(5, b), a);
+        zfma_plain<Z_SUB_OCS>(o[2], via_shfl(9, b), a);
+        zfma_plain<Z_ADD_COS>(o[3], via_shfl(15, b), a);
+        zfma_plain<Z_SUB_COS>(o[4], via_shfl(3, b), a);
+        o[5] = make_double2(__shfl(b.x, 7, 16), __shfl(b.y, 12, 16));
+        double sa = __shfl(a.x, 0, 16), sb = __shfl(b.y, 0, 16);
+        for (int k = 1; k < 16; ++k) {
+            sa = fma(__shfl(a.x, k, 16), 1.0, sa);
+            sb = fma(__shfl(b.y, k, 16), 1.0, sb);
+        }
+        o[6] = make_double2(sa, sb);
+        o[7] = make_double2(__shfl(a.x, 6, 16), 0.0);
+        zfma_plain<Z_ADD_SO>(o[7], via_shfl(6, b), a);
+    }
+}
+static __global__ __launch_bounds__(64) void k_dpp_selftest(const c64* __restrict__ a, const c64* __restrict__ b, c64* __restrict__ out_hw,
+                                                            c64* __restrict__ out_ref) {
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+    c64 o[DPP_SELFTEST_OPS];
+    dpp_selftest_ops<true>(a[i], b[i], o);
+#pragma unroll
+    for (int q = 0; q < DPP_SELFTEST_OPS; ++q) out_hw[i * DPP_SELFTEST_OPS + q] = o[q];
+    dpp_selftest_ops<false>(a[i], b[i], o);
+#pragma unroll
+    for (int q = 0; q < DPP_SELFTEST_OPS; ++q) out_ref[i * DPP_SELFTEST_OPS + q] = o[q];
+}
+
 }  // namespace disco

@@ -206,6 +206,16 @@ class Engine:
         self._chk(self.lib.disco_selftest_pk(self.ctx, pa, pb, pc, n, hw.ptr, ref.ptr, self.stream))
         return hw, ref
 
+    def selftest_dpp(self, a, b):
+        """a, b (n,) complex128, n a multiple of 64 -> (out_hw, out_ref), each (n, 8) complex128: the float64 DPP row-broadcast forms of
+        csrc/dpp64.h through their instructions and through __shfl + plain statements (include/disco_hip.h)."""
+        n = a.shape[0]
+        pa, ka = self.to_device(a, np.complex128)
+        pb, kb = self.to_device(b, np.complex128)
+        hw, ref = self.empty((n, 8), np.complex128), self.empty((n, 8), np.complex128)
+        self._chk(self.lib.disco_selftest_dpp(self.ctx, pa, pb, n, hw.ptr, ref.ptr, self.stream))
+        return hw, ref
+
     def reserve(self, own_workspace=1):
         """Allocate now what the whole-path calls would allocate on first use (0: partial-sum blocks only, 1: + the context's
         own workspace of tango_enhance / _iterated / _online, 2: + tango_reference's).  Afterwards a call is a fixed sequence of

@@ -427,6 +427,13 @@ int disco_ism_rir(disco_ctx* ctx, const float* room_dims, const float* absorptio
  * write == 0 only reads (dst needs >= 4096 floats and is practically never written). */
 int disco_selftest_stream(disco_ctx* ctx, const float* src, float* dst, int64_t n, int write, disco_stream s);
 
+/* Self-test of the float64 cross-lane forms the 9 <= P <= 16 solver is written on (disco_amd/csrc/dpp64.h: v_fmac_f64 / v_mov_b64 with
+ * DPP row_newbcast inside inline asm; no reference counterpart): a, b: [n] complex128 operands (n a multiple of 64; lane i of a
+ * 16-lane row reads the operands of the other lanes of its row) -> out_hw, out_ref: [n][DISCO_DPP_SELFTEST_OPS] complex128, the same
+ * operations through the instruction forms and through __shfl + plain fused multiply-adds.  Bit equality is what is asserted. */
+#define DISCO_DPP_SELFTEST_OPS 8
+int disco_selftest_dpp(disco_ctx* ctx, const double* a, const double* b, int64_t n, double* out_hw, double* out_ref, disco_stream s);
+
 #define DISCO_PK_SELFTEST_OPS 17
 int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco_c32* b, const disco_c32* c, int64_t n,
                       disco_c32* out_hw, disco_c32* out_ref, disco_stream s);

@@ -461,7 +461,7 @@ def check_solver_singular_noise(make_engine):
     rng = np.random.default_rng(0)
     eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
     errs = {}
-    for P in (4, 7):
+    for P in (4, 7, 9, 15):
         for rank in (1, 2, P - 1):
             A = rng.standard_normal((P, rank)) + 1j * rng.standard_normal((P, rank))
             Rnn = (A @ A.conj().T).astype(np.complex64)
@@ -769,6 +769,48 @@ def check_solver_small_gap(make_engine, sizes=(2, 4, 7, 15)):
     return out
 
 
+def check_solver_routes(make_engine, sizes=(9, 12, 15, 16), n=37):
+    """9 <= P <= 16: the register / DPP solver (option "solve_dpp", csrc/k_solve_dpp.h) against the LDS group solver on the same
+    pencils -- covariance-like, nearly singular noise (a broken pivot), a small gap, Rxx = 0, and a batch size that leaves lanes of
+    the last wave without a pencil; both against the float64 closed form where that is well conditioned."""
+    rng = np.random.default_rng(23)
+    a = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    b = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    a.set_option('solve_dpp', 1)
+    b.set_option('solve_dpp', 0)
+    assert a.get_option('solve_dpp') == 1 and b.get_option('solve_dpp') == 0
+    out = {}
+    for P in sizes:
+        T = 4 * P
+        X = (rng.standard_normal((n, P, 1)) + 1j * rng.standard_normal((n, P, 1))) * (rng.standard_normal((n, 1, T)) + 1j * rng.standard_normal((n, 1, T))) \
+            + 0.3 * (rng.standard_normal((n, P, T)) + 1j * rng.standard_normal((n, P, T)))
+        Nn = rng.standard_normal((n, P, T)) + 1j * rng.standard_normal((n, P, T))
+        Rxx = (X @ X.conj().transpose(0, 2, 1) / T)
+        Rnn = (Nn @ Nn.conj().transpose(0, 2, 1) / T)
+        Rnn[1] = Rnn[1][:, :1] @ Rnn[1][:, :1].conj().T + 1e-9 * np.eye(P)          # rank 1: every pivot after the first breaks down
+        Rxx[2] = 0.0                                                               # nothing to enhance
+        Rg, Ng = _pencil_with_spectrum(rng, 1, P, [1.0, 0.999] + [0.3] * (P - 2))   # a gap of 1e-3
+        Rxx[3], Rnn[3] = Rg[0], Ng[0]
+        Rxx, Rnn = Rxx.astype(np.complex64), Rnn.astype(np.complex64)
+        wa, ta = a.gevd_mwf_r1(Rxx, Rnn)
+        wb, tb = b.gevd_mwf_r1(Rxx, Rnn)
+        wa, ta, wb, tb = wa.numpy(), ta.numpy(), wb.numpy(), tb.numpy()
+        assert np.all(np.isfinite(wa.view(np.float32))) and np.all(np.isfinite(ta.view(np.float32))), P
+        reg = np.ones(n, bool)
+        reg[[1, 3]] = False                                                        # compared with their own bars below
+        e_ab = max(relerr(wa[reg], wb[reg]), relerr(ta[reg], tb[reg]))
+        reg[2] = False                                                             # (w = 0: no relative error)
+        wr, t1r, _ = mo.gevd_mwf_r1_hermitian(Rxx[reg], Rnn[reg], 1.0)
+        e_ref = max(relerr(wa[reg], wr), relerr(ta[reg], t1r))
+        assert e_ab < 1e-6 and e_ref < 2e-6, (P, e_ab, e_ref)
+        assert np.abs(wa[2]).max() < 1e-12
+        e_gap = relerr(wa[3], wb[3])
+        assert e_gap < 2e-3, (P, e_gap)                                            # float32 inputs move v0 by ~1e-7 / gap in either solver
+        assert np.abs(wa[1]).max() < 1e3 and relerr(wa[1], wb[1]) < 1e-3, (P, wa[1], wb[1])
+        out[P] = (e_ab, e_ref, e_gap)
+    return out
+
+
 def check_solver_degenerate(make_engine):
     """Rss = 0 (mask 0 everywhere): eigenvalue clamps to eps -> w ~ 0, finite (internal_formulas.py:59-62)."""
     eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
@@ -797,6 +839,28 @@ def check_pk_selftest(make_engine, n=4096, seed=11):
     for q, w in enumerate(want):
         errs[q] = float(np.abs(hw[:, q] - w).max() / np.abs(w).max())
     assert max(errs.values()) < 1e-6, errs
+    return errs
+
+
+def check_dpp_selftest(make_engine, n=1024, seed=13):
+    """csrc/dpp64.h: the float64 DPP row-broadcast forms must equal __shfl + the plain fused multiply-adds bit for bit, and both must
+    mean what the helper says (NumPy): lane i of a 16-lane row reads entries of the other lanes of ITS row."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    hw, ref = eng.selftest_dpp(a, b)
+    hw, ref = hw.numpy(), ref.numpy()
+    assert np.array_equal(hw.view(np.uint64), ref.view(np.uint64)), 'instruction forms differ from __shfl + plain statements'
+    A, B = a.reshape(-1, 16), b.reshape(-1, 16)
+    bc = lambda v, k: np.repeat(v[:, k:k + 1], 16, axis=1)
+    want = [A + bc(B, 0) * A, A - bc(B, 5) * A, A - A * np.conj(bc(B, 9)), A + np.conj(A) * bc(B, 15), A - np.conj(A) * bc(B, 3),
+            bc(B.real, 7) + 1j * bc(B.imag, 12), np.repeat(A.real.sum(1, keepdims=True), 16, 1) + 1j * np.repeat(B.imag.sum(1, keepdims=True), 16, 1),
+            bc(A.real, 6) + bc(B, 6) * A]
+    errs = {}
+    for q, w in enumerate(want):
+        errs[q] = float(np.abs(hw[:, q] - w.reshape(-1)).max() / np.abs(w).max())
+    assert max(errs.values()) < 1e-14, errs
     return errs
 
 

@@ -35,6 +35,11 @@ def test_pk_instruction_forms(make_engine):
     pc.check_pk_selftest(make_engine)
 
 
+@pytest.mark.gpu
+def test_dpp_instruction_forms(make_engine):
+    print(pc.check_dpp_selftest(make_engine, n=4096))
+
+
 @pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 160000, 4), (1024, 2600, 1), (1024, 40000, 8), (1024, 30000, 3),
                                            (512, 20000, 5), (512, 45000, 8), (1024, 21000, 4), (1024, 30000, 7)])
 @pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
@@ -126,6 +131,10 @@ def test_solver_sizes_up_to_16(make_engine):
 
 def test_solver_small_gap(make_engine):
     print(pc.check_solver_small_gap(make_engine))
+
+
+def test_solver_routes_dpp_vs_lds(make_engine):
+    print(pc.check_solver_routes(make_engine, sizes=(9, 10, 11, 12, 13, 14, 15, 16), n=4099))
 
 
 def test_solver_degenerate_inputs(make_engine):

@@ -24,6 +24,10 @@ def test_emu_pk_operations(make_engine):
     pc.check_pk_selftest(make_engine, n=512)
 
 
+def test_emu_dpp_operations(make_engine):
+    print(pc.check_dpp_selftest(make_engine, n=256))
+
+
 @pytest.mark.parametrize('n_fft,L,chans', [(512, 1500, 3), (512, 2048, 2), (1024, 2600, 1), (512, 9000, 4), (1024, 2600, 3), (1024, 9000, 8),
                                            (512, 2000, 5), (512, 4500, 8), (1024, 2100, 4)])
 @pytest.mark.parametrize('pad_mode', ['reflect', 'constant'])
@@ -113,6 +117,10 @@ def test_emu_solver_sizes(make_engine):
 
 def test_emu_solver_small_gap(make_engine):
     print(pc.check_solver_small_gap(make_engine, sizes=(2, 4, 7, 15)))
+
+
+def test_emu_solver_routes(make_engine):
+    print(pc.check_solver_routes(make_engine))
 
 
 def test_emu_solver_degenerate(make_engine):
