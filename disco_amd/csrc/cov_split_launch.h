@@ -7,20 +7,29 @@
 namespace disco_host {
 using namespace disco;
 
+#ifndef DISCO_COV1_LDS
+#define DISCO_COV1_LDS 0            // 1: the step-1 statistics of M = 8 staged through LDS as well (k_cov_split_lds<8, 0>).  Measured equal on the
+                                    // MI355X (C5 cov1 3.88 / 4.05 against 3.79 / 4.20 ms, profiles/r03_p_*): the per-wave fetches of k_cov_split stay
+#endif
+
 template <int M, int KR>
 static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {
-    if constexpr (KR > 0) {
-        // shapes with remote rows (all have an even M, and F - 1 is a multiple of 64 for both FFT sizes): frames staged through
-        // LDS once per workgroup (k_cov.h; 7.3 ms per C5 launch, the per-wave fetches of k_cov_split: 9.6 ms)
-        static_assert(M % 2 == 0, "k_cov_split_lds fetches X in 16-byte granules");
-        const unsigned nb = DISCO_COV_XCD ? (nblk + DISCO_COV_XCD - 1) / DISCO_COV_XCD * DISCO_COV_XCD : nblk;      // see the kernel's id -> item map
-        if (skiploc)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nb), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
-        else
+    // even M (every shape with remote rows, and the step-1 shape M = 8) with F - 1 a multiple of 64 (both FFT sizes of this library): frames
+    // staged through LDS once per workgroup (k_cov.h; with remote rows 7.3 ms per C5 launch, the per-wave fetches of k_cov_split: 9.6 ms)
+    if constexpr (M % 2 == 0) {
+        if (KR > 0 || (DISCO_COV1_LDS && (a.F - 1) % 64 == 0)) {
+            const unsigned nb = DISCO_COV_XCD ? (nblk + DISCO_COV_XCD - 1) / DISCO_COV_XCD * DISCO_COV_XCD : nblk;      // see the kernel's id -> item map
+            if constexpr (KR > 0) {
+                if (skiploc) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, true>), dim3(nb), dim3(64 * cov_split_waves<KR, true>()), 0, st, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split_lds<M, KR, false>), dim3(nb), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+            return;
+        }
     }
+    if constexpr (KR == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
 }
 
 

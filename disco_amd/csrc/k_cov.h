@@ -564,7 +564,7 @@ template <int M, int KR, int S>
 struct alignas(16) CovStage {
     static constexpr int XP = M + 2;          // pitch of a bin's mic row: (M + 2) * 8 B keeps the lanes' ds_read_b128 off each other's banks
     c32 xs[S][64][XP];
-    c32 zs[S][KR][64];
+    c32 zs[S][KR > 0 ? KR : 1][64];
     float ms[S][64];
 };
 
@@ -587,12 +587,14 @@ struct CovStageLoader {
                 const float4* src = reinterpret_cast<const float4*>(a.X + ((g * T + t) * (long long)F + f0) * M);
                 r[n] = src[(slot % XH) * 64 + lane];
             } else if (slot < WSX + WSZ) {
-                const int zz = slot - WSX, jj = zz % KR;
-                int t = ts + zz / KR;
-                t = t < t1 ? t : t1 - 1;
-                const int j = jj < k ? jj : jj + 1;                              // concatenate_signals order
-                const c32 v = a.Zs[(z_plane(r_, j, a.K, a.R, a.zblk) * T + t) * (long long)F + f0 + lane];
-                r[n] = make_float4(v.x, v.y, 0.f, 0.f);
+                if constexpr (KR > 0) {
+                    const int zz = slot - WSX, jj = zz % KR;
+                    int t = ts + zz / KR;
+                    t = t < t1 ? t : t1 - 1;
+                    const int j = jj < k ? jj : jj + 1;                          // concatenate_signals order
+                    const c32 v = a.Zs[(z_plane(r_, j, a.K, a.R, a.zblk) * T + t) * (long long)F + f0 + lane];
+                    r[n] = make_float4(v.x, v.y, 0.f, 0.f);
+                }
             } else if (slot < WS) {
                 int t = ts + (slot - WSX - WSZ);
                 t = t < t1 ? t : t1 - 1;
@@ -608,8 +610,10 @@ struct CovStageLoader {
                 const int i = (slot % XH) * 64 + lane;                           // float4 granule i of the frame's [64][M] block
                 *reinterpret_cast<float4*>(&st.xs[slot / XH][i / XH][2 * (i % XH)]) = r[n];
             } else if (slot < WSX + WSZ) {
-                const int zz = slot - WSX;
-                st.zs[zz / KR][zz % KR][lane] = make_float2(r[n].x, r[n].y);
+                if constexpr (KR > 0) {
+                    const int zz = slot - WSX;
+                    st.zs[zz / KR][zz % KR][lane] = make_float2(r[n].x, r[n].y);
+                }
             } else if (slot < WS) {
                 st.ms[slot - WSX - WSZ][lane] = r[n].x;
             }
@@ -680,7 +684,7 @@ __device__ __forceinline__ void cov_split_wave_lds(const CovArgs& a, const long 
 
 template <int M, int KR, bool SKIPLOC>
 __global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>()), DISCO_COV_LDS_WPE) void k_cov_split_lds(CovArgs a) {
-    static_assert(KR > 0 && M % 2 == 0, "remote rows and 16-byte granules of X");
+    static_assert(M % 2 == 0, "16-byte granules of X");     // KR = 0: the step-1 statistics of a wide node (M = 8), same staging
     constexpr int NW = cov_split_waves<KR, SKIPLOC>();
     __shared__ CovStage<M, KR, DISCO_COV_STAGE_FRAMES> sh[2];
     const int nbin = a.F - 1, tiles = nbin / 64;          // the launcher checks nbin % 64 == 0
@@ -707,14 +711,15 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLO
 #endif
     const int lane = threadIdx.x & 63;
     const int wid = wave_id();
+    const int role = wid + (KR > 0 ? 0 : 6);               // (as in k_cov_split: without remote rows only the local block's two roles exist)
     if (tile == tiles) {                                   // the Nyquist bin: lanes are frames there, no barrier on that path
-        cov_split_roles<M, KR, SKIPLOC>(wid, [&](auto tag) {
+        cov_split_roles<M, KR, SKIPLOC>(role, [&](auto tag) {
             using R_ = decltype(tag);
             cov_split_wave<M, KR, R_::x0, R_::x1, R_::y0, R_::y1, R_::tri>(a, g, c, tile, lane);
         });
         return;
     }
-    cov_split_roles<M, KR, SKIPLOC>(wid, [&](auto tag) {
+    cov_split_roles<M, KR, SKIPLOC>(role, [&](auto tag) {
         cov_split_wave_lds<M, KR, NW, decltype(tag)>(a, g, c, tile, lane, wid, sh);
     });
 }
