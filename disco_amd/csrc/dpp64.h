@@ -102,14 +102,17 @@ __device__ __forceinline__ void zfma_plain(c64& acc, const c64& S, const c64& o)
 
 // The first N entries of lane K's register array `a` (same array, same indices, in every lane).  The array must not change while
 // the view is in use.
-template <int K, int N, int NA>
+// SETTLED: the caller vouches that the entries were pinned and settled by an earlier view and not written since (the k-loop of a squaring).
+template <int K, int N, int NA, bool SETTLED = false>
 struct BcRow {
 #if defined(__clang__)
     const c64 (&src)[NA];
     __device__ __forceinline__ explicit BcRow(const c64 (&a)[NA]) : src(a) {
+        if constexpr (!SETTLED) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) dpp_pin(a[i]);
-        DISCO_DPP_SOURCES_READY();
+            for (int i = 0; i < N; ++i) dpp_pin(a[i]);
+            DISCO_DPP_SOURCES_READY();
+        }
     }
     template <int MODE>
     __device__ __forceinline__ void fma(c64& acc, int i, const c64& o) const { zfma_bc<K, MODE>(acc, src[i], o); }

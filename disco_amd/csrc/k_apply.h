@@ -90,20 +90,8 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64) void k_apply_m(const c32* __
         const long long tf = (long long)t * F + f;
         const c32* xp = X + (g * TF + tf) * M;
         c32 x[M];
-#if defined(DISCO_APPLY_TIMING_EXPERIMENT)      // timing only (wrong results): the wave's 4 KB of X as 16-byte-per-lane contiguous loads
-        {
-            const float4* xw = reinterpret_cast<const float4*>(X + (g * TF + (long long)t * F + tile * 64) * M);
-#pragma unroll
-            for (int i = 0; i < M / 2; ++i) {
-                const float4 q = xw[i * 64 + threadIdx.x];
-                x[2 * i] = make_float2(q.x, q.y);
-                x[2 * i + 1] = make_float2(q.z, q.w);
-            }
-        }
-#else
 #pragma unroll
         for (int i = 0; i < M; ++i) x[i] = xp[i];
-#endif
         float ar = 0.f, ai = 0.f;
 #pragma unroll
         for (int i = 0; i < M; ++i) {

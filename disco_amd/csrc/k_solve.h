@@ -8,6 +8,8 @@
 //     t1 = L^-H v0 * L[0,0] * conj(v0[0]),     w = t1 * d0 / (d0 + mu),   d0 clamped to [eps, 1e6]
 // (oracle/mwf_oracle.py:gevd_mwf_r1_hermitian; checked against the reference's own outputs).
 //
+// (9 <= P <= 16 of the batch solve run on the register / DPP form of the same algorithm by default: k_solve_dpp.h; this file is the
+// LDS form -- P = 5 ... 8, the online kernel, k_mwf_variants, and option "solve_dpp" = 0.)
 // Mapping: a group of G = 4 / 8 / 16 lanes owns one problem, lane j owns column j.  Everything is float64:
 // cooperative Cholesky through LDS, two forward substitutions (column j of L^-1 Rxx, then column j of C),
 // then the DOMINANT eigenpair only (rank = 1 needs nothing else) by repeated squaring of C / tr C, which converges

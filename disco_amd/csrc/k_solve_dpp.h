@@ -234,7 +234,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(DppSolveGeom<P>::THREADS, 2) voi
         for (int i = 0; i < P; ++i) nn[i] = make_double2(0.0, 0.0);
         static_for<0, P>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            const BcRow<k, P, P> bk(g);                         // column k of B
+            const BcRow<k, P, P, (k > 0)> bk(g);                // column k of B (pinned and settled once, by the view of column 0)
 #pragma unroll
             for (int i = 0; i < P; ++i) bk.template fma<Z_ADD_SO>(nn[i], i, g[k]);
         });
