@@ -19,7 +19,7 @@ import os
 STAGE_OF = {'k_stft_cov<': 'stft_cov1', 'k_stft<': 'stft', 'k_mask_oracle<': 'mask_oracle', 'k_istft<': 'istft',
             'k_step2_cov_fused<': 'step2_cov', 'k_step2_apply_istft<': 'step2_apply_istft', 'k_step2_apply_fused<': 'step2_apply',
             'k_stft_apply_istft<': 'stft_apply_istft', 'k_cov_split<': 'cov_split', 'k_cov_split_lds<': 'cov_split', 'k_stft_pairs<': 'stft', 'k_cov_big<': 'cov_big', 'k_cov<': 'cov',
-            'k_room_cov_dma<': 'room_cov2', 'k_room_cov<': 'room_cov2', 'k_apply_m<': 'apply2', 'k_apply<': 'apply', 'k_gevd_mwf_r1_thread<': 'solve_thread', 'k_gevd_mwf_r1<': 'solve'}
+            'k_room_cov_dma<': 'room_cov2', 'k_room_cov<': 'room_cov2', 'k_apply_mq<': 'apply2', 'k_apply_m<': 'apply2', 'k_apply<': 'apply', 'k_gevd_mwf_r1_dpp<': 'solve2', 'k_gevd_mwf_r1_thread<': 'solve_thread', 'k_gevd_mwf_r1<': 'solve'}
 
 
 def csrc_digest():
