@@ -281,6 +281,7 @@ const OptionInfo* option_table() {
         {"overlap_solves", "DISCO_OVERLAP_SOLVES", 1},
         {"solve_f32", "DISCO_SOLVE_F32", 0},
         {"solve_dpp", "DISCO_SOLVE_DPP", 1},
+        {"room_tile16", "DISCO_ROOM_TILE16", 0},
     };
     return t;
 }

@@ -10,6 +10,17 @@ using namespace disco_host;
 // instead of disco_apply + cov_partials; room_cov_ok says whether the shape and the context's state qualify.
 #define DISCO_FOR_ROOM(X_) X_(8, 8) X_(8, 6) X_(8, 4) X_(8, 2) X_(4, 8) X_(4, 6)
 namespace disco_host {
+template <int M, int K>
+static void launch_room_dma(bool tile16, unsigned nblk, hipStream_t st, const RoomArgs& a) {
+    if constexpr (room_tile16_shape<M, K>()) {
+        if (tile16) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M, K, 16>), dim3(nblk), dim3(RoomGeom<M, K, 16>::NT), 0, st, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M, K, 32>), dim3(nblk), dim3(RoomGeom<M, K, 32>::NT), 0, st, a);
+}
+
 bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes;
@@ -42,16 +53,18 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
     a.T = ctx->T;
     a.F = ctx->F;
     a.chunks = chunks;
-    a.tiles = (ctx->F + 31) / 32;
     a.R = c.rooms;
-    const long long nblk = (long long)c.rooms * a.tiles * chunks;
-    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
     // frames through an LDS-DMA ring three ahead (default), or staged through registers one ahead (DISCO_ROOM_DMA=0; k_room.h)
     const bool dma = ctx->opt[DISCO_OPT_ROOM_DMA] != 0;
 #define X_(M_, K_)                                                                                                       \
     if (M == M_ && K == K_) {                                                                                            \
+        const bool t16 = dma && room_tile16_shape<M_, K_>() && ctx->opt[DISCO_OPT_ROOM_TILE16] != 0;       /* 16-bin tiles (k_room.h) */ \
+        const int nb = t16 ? 16 : 32;                                                                                    \
+        a.tiles = (ctx->F + nb - 1) / nb;                                                                                \
+        const long long nblk = (long long)c.rooms * a.tiles * chunks;                                                    \
+        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch"); \
         if (dma)                                                                                                         \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a); \
+            launch_room_dma<M_, K_>(t16, (unsigned)nblk, (hipStream_t)s, a);                                             \
         else                                                                                                             \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);     \
     }

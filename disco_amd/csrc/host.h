@@ -35,6 +35,7 @@ enum {
     DISCO_OPT_OVERLAP_SOLVES,           // "overlap_solves": whole-path calls run the batch as two halves on two streams
     DISCO_OPT_SOLVE_F32,                // "solve_f32": float32 squarings + float64 Rayleigh-quotient finish in the group solver (default 0: all float64)
     DISCO_OPT_SOLVE_DPP,                // "solve_dpp": 9 <= P <= 16 solved in registers with DPP row broadcasts (k_solve_dpp.h; 0: the LDS group solver)
+    DISCO_OPT_ROOM_TILE16,              // "room_tile16": the room pass's DMA variant on 16-bin tiles, two workgroups per CU (measured slower; default 0)
     DISCO_N_OPTIONS
 };
 namespace disco_host {

@@ -29,13 +29,20 @@ namespace disco {
 #define DISCO_ROOM_WPE 3              // waves per SIMD the register allocation must leave room for (a 12-wave workgroup needs 3)
 #endif
 
-template <int M, int K>
+// NB_: bins per workgroup.  32 = two slots per wave, one 12-wave workgroup per CU (C5 shape).  16 = four slots per wave: half the
+// lanes per workgroup, so TWO workgroups share a CU and run out of phase -- each still meets its own barrier once per frame, but no
+// longer the whole CU at once (the DMA variant only; needs whole waves of A slots and of B slots: K a multiple of 4).  Built, parity-green
+// and slower (see room_tile16_shape): option "room_tile16", default 0.
+template <int M, int K, int NB_ = 32>
 struct RoomGeom {
-    static_assert(M % 4 == 0 && K % 2 == 0 && K >= 2 && K <= 8, "4-mic slots, two slots per wave, <= 28 pairs per slot");
+    static_assert(NB_ == 32 || NB_ == 16, "half or quarter of a wave");
+    static constexpr int NB = NB_;                      // bins per workgroup
+    static constexpr int SPW = 64 / NB;                 // slots per wave
+    static_assert(M % 4 == 0 && K % 2 == 0 && K >= 2 && K <= 8, "4-mic slots, <= 28 pairs per slot");
     static constexpr int KR = K - 1, P = M + KR, NP = P * (P + 1) / 2;
-    static constexpr int NB = 32;                       // bins per workgroup (half a wave)
     static constexpr int NA = M / 4;                    // A slots per node
-    static constexpr int WA = K * NA / 2, WB = K / 2;   // waves of A slots, waves of B slots
+    static_assert((K * NA) % SPW == 0 && K % SPW == 0, "whole waves of A slots and of B slots");
+    static constexpr int WA = K * NA / SPW, WB = K / SPW;   // waves of A slots, waves of B slots
     static constexpr int NT = 64 * (WA + WB);
     static constexpr int MH = M / 2;                    // 16-byte granules (two mics) per bin
     static constexpr int NITEMS = K * NB * MH;          // granules of one frame of the tile
@@ -256,9 +263,15 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 #define DISCO_ROOM_DEPTH (DISCO_ROOM_AHEAD + 1)
 #endif
 
+// Shapes for which the DMA variant also exists on 16-bin tiles (option "room_tile16").  Measured SLOWER on the MI355X -- 16.8 against
+// 14.05 ms per C5 step (profiles/r03_s_*): the pass is bound by what a frame costs a workgroup whatever its width (barrier, LDS-DMA
+// issue, z formation), not by phase-locked waves.  Kept selectable, and tested, as the record of it.
 template <int M, int K>
+constexpr bool room_tile16_shape() { return K % 4 == 0; }
+
+template <int M, int K, int NB_>
 struct alignas(16) RoomRing {
-    using Gm = RoomGeom<M, K>;
+    using Gm = RoomGeom<M, K, NB_>;
     float4 xs[DISCO_ROOM_DEPTH][Gm::NITEMS];           // granules, linear in the loader's item index
     float ms[DISCO_ROOM_DEPTH][K * Gm::NB];
     c32 zs[2][K][Gm::NB];
@@ -316,9 +329,9 @@ __device__ __forceinline__ void vm_wait(int n) {
 #endif
 }
 
-template <int M, int K, bool IS_A>
-__device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, K>& sh) {
-    using Gm = RoomGeom<M, K>;
+template <int M, int K, int NB_, bool IS_A>
+__device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, K, NB_>& sh) {
+    using Gm = RoomGeom<M, K, NB_>;
     constexpr int KR = Gm::KR, P = Gm::P, NP = Gm::NP, NB = Gm::NB, NA = Gm::NA, WA = Gm::WA, NT = Gm::NT, MH = Gm::MH;
     constexpr int NITEMS = Gm::NITEMS, NL = Gm::NL, D = DISCO_ROOM_DEPTH;
     constexpr int BPR = 16 / MH;                       // bins per 256-byte bank row of granules
@@ -332,7 +345,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
     const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
     const int f0 = tile * NB;
     const int tid = threadIdx.x, wid = wave_id(), lane = tid & 63;
-    const int bin = lane & (NB - 1), half = lane >> 5;
+    const int bin = lane & (NB - 1), sub = lane / NB;
     const bool live = f0 + bin < F;
 
     const c32* Xr = a.X + (room * K * T) * (long long)F * M;
@@ -401,20 +414,23 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
     };
 
     // ---- the lane's slot
-    // slot = 2 * (wave within its role) + half.  A: k = slot / NA, h = slot % NA; B: k = slot.  kw = the wave's first node (a
+    // slot = SPW * (wave within its role) + sub.  A: k = slot / NA, h = slot % NA; B: k = slot.  kw = the wave's first node (a
     // SCALAR), dk = k - kw in {0, 1} (always 0 when the two halves of a wave share a node, NA even): the remote row jj of a lane
     // is node jj + (jj >= kw + dk), which differs between the halves only for jj == kw -- every other LDS offset of a remote
     // row is a scalar instead of a per-lane select.
+    // With SPW slots per wave: slot = SPW * (wave within its role) + sub; the wave's nodes are kw ... kw + DKMAX and only the remote
+    // rows jj in [kw, kw + DKMAX) take a per-lane select.
     constexpr bool is_a = IS_A;
-    constexpr bool two_nodes = !IS_A || (NA % 2 != 0);
+    constexpr int SPW = Gm::SPW;
+    constexpr int DKMAX = IS_A ? (SPW - 1) / NA : SPW - 1;
     const int wr = is_a ? wid : wid - WA;
-    const int kw = is_a ? (2 * wr) / NA : 2 * wr;
-    const int dk = two_nodes ? half : 0;
+    const int kw = is_a ? (SPW * wr) / NA : SPW * wr;
+    const int dk = is_a ? sub / NA : sub;
     const int k = kw + dk;
-    const int h = is_a ? ((2 * wr) % NA + (two_nodes ? 0 : half)) : 0;
+    const int h = is_a ? sub % NA : 0;
     auto remote = [&](int jj) {                          // concatenate_signals order: jj -> node jj (jj < k), jj + 1 (jj >= k)
-        int j = jj + (jj > kw ? 1 : 0);
-        if (jj == kw) j += two_nodes ? (dk == 0 ? 1 : 0) : 1;
+        int j = jj + (jj >= kw + DKMAX ? 1 : 0);
+        if (DKMAX > 0 && jj >= kw && jj < kw + DKMAX) j = jj + (jj >= k ? 1 : 0);
         return j;
     };
     const int swz = (bin / BPR) % MH;
@@ -500,11 +516,11 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
     }
 }
 
-template <int M, int K>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM_WPE) void k_room_cov_dma(RoomArgs a) {
-    __shared__ RoomRing<M, K> sh;
-    if (wave_id() < RoomGeom<M, K>::WA) room_cov_dma_run<M, K, true>(a, sh);
-    else room_cov_dma_run<M, K, false>(a, sh);
+template <int M, int K, int NB_>
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K, NB_>::NT), DISCO_ROOM_WPE) void k_room_cov_dma(RoomArgs a) {
+    __shared__ RoomRing<M, K, NB_> sh;
+    if (wave_id() < RoomGeom<M, K, NB_>::WA) room_cov_dma_run<M, K, NB_, true>(a, sh);
+    else room_cov_dma_run<M, K, NB_, false>(a, sh);
 }
 
 }  // namespace disco

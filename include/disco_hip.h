@@ -148,6 +148,8 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *   "solve_f32"          (DISCO_SOLVE_F32, 0)  1: group solver (P >= 5) with float32 squarings on packed instructions and a float64
  *                         Rayleigh-quotient finish (same accuracy; measured SLOWER than the all-float64 default on the MI355X: 1.26 vs
  *                         1.07 ms at P = 7, 16.2 vs 14.4 ms at P = 15 -- after round 2 only 3-4 squarings are left to speed up)
+ *   "room_tile16"        (DISCO_ROOM_TILE16, 0) 1: the room pass ("room_dma" = 1, K a multiple of 4) on 16-bin tiles: 6-wave workgroups, two per CU
+ *                         (measured slower than the 32-bin form on the MI355X: 16.8 against 14.05 ms per C5 step; kept, tested, as a record)
  *   "solve_dpp"          (DISCO_SOLVE_DPP, 1)  rank-1 GEVD-MWF solves with 9 <= P <= 16 run in registers, other lanes' entries read through
  *                         DPP row broadcasts (csrc/k_solve_dpp.h: 3.7 instead of 7.2 ms per C5 launch); 0: the LDS group solver, which P <= 8,
  *                         the online mode and "solve_f32" use in any case.  Same algorithm and breakdown rules; the two are tested against

@@ -914,17 +914,19 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
         eng.set_tuning(*tuning)
     m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F)
     res = {}
-    # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route
+    # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route,
+    # 't16': the ring on 16-bin tiles (option "room_tile16"; the shapes with K a multiple of 4 -- elsewhere the option changes nothing)
     engines = {}
-    for mode, cov, dma in (('1', 1, 1), ('reg', 1, 0), ('0', 0, 1)):
+    for mode, cov, dma, t16 in (('1', 1, 1, 0), ('reg', 1, 0, 0), ('0', 0, 1, 0), ('t16', 1, 1, 1)):
         e = eng if mode == '1' else make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
         if mode != '1' and tuning is not None:
             e.set_tuning(*tuning)
         e.set_option('room_cov', cov)
         e.set_option('room_dma', dma)
+        e.set_option('room_tile16', t16)
         engines[mode] = e
     m_np = m.numpy()
-    want_stage = {'1': 'room_cov2', 'reg': 'room_cov2_reg', '0': 'cov2'}
+    want_stage = {'1': 'room_cov2', 'reg': 'room_cov2_reg', '0': 'cov2', 't16': 'room_cov2'}
     for mode, e in engines.items():
         mm = m if e is eng else m_np
         e.stage_timing(True)
@@ -935,9 +937,10 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
         out_e, z_e, yf_e = e.tango_enhance(y, mm)
         res[mode] = (out_i.numpy(), yf_i.numpy(), out_e.numpy(), z_e.numpy(), yf_e.numpy())
     errs = {}
-    for name, a, b, c_ in zip(('out_iter', 'yf_iter', 'out', 'z_y', 'yf'), res['1'], res['0'], res['reg']):
+    for name, a, b, c_, d_ in zip(('out_iter', 'yf_iter', 'out', 'z_y', 'yf'), res['1'], res['0'], res['reg'], res['t16']):
         errs[name + '_vs_staged'] = max(relerr(a[r, k], b[r, k]) for r in range(R) for k in range(K))
         errs[name + '_reg_vs_staged'] = max(relerr(c_[r, k], b[r, k]) for r in range(R) for k in range(K))
+        errs[name + '_t16_vs_staged'] = max(relerr(d_[r, k], b[r, k]) for r in range(R) for k in range(K))
     assert max(errs.values()) < 2e-5, errs
     for r in range(R):
         for it_, (o_idx, yf_idx) in ((iters, (0, 1)), (1, (2, 4))):

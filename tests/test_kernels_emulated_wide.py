@@ -104,7 +104,7 @@ def test_emu_node_sharded_torch_one_rank(make_engine):
 
 
 @pytest.mark.parametrize('K,M,n_fft,L,tuning', [(2, 8, 512, 6000, None), (6, 4, 512, 5000, (0, 3, 0, 0)), (4, 8, 1024, 16000, None),
-                                                (8, 8, 512, 12000, (0, 2, 0, 0)), (2, 8, 512, 5120, (0, 20, 0, 0))])
+                                                (8, 8, 512, 12000, (0, 2, 0, 0)), (2, 8, 512, 5120, (0, 20, 0, 0)), (8, 4, 512, 5000, None)])
 def test_emu_room_cov(make_engine, K, M, n_fft, L, tuning):
     """k_room_cov (z of every node + step-2 statistics of every node of a room in one pass over X) against the route it
     replaces and against the oracle; several frame chunks (down to chunks of one or two frames: shorter than the three-frame
