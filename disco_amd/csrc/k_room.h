@@ -259,8 +259,12 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
                                         // for it; 4 / 5 (two / three iterations, 16 KB of LDS each) measured 14.12 / 14.19 ms against 14.08 ms per
                                         // C5 step (profiles/r03_n_*): the pass is not waiting for its loads
 #endif
+#ifndef DISCO_ROOM_FPB
+#define DISCO_ROOM_FPB 2                // frames per barrier.  2: six ring slots, two frames issued / formed / folded per iteration, one wait for
+                                        // both -- 13.4 against 14.0 ms per C5 step for 1 (profiles/r03_t_*), bit-identical sums
+#endif
 #ifndef DISCO_ROOM_DEPTH
-#define DISCO_ROOM_DEPTH (DISCO_ROOM_AHEAD + 1)
+#define DISCO_ROOM_DEPTH (DISCO_ROOM_FPB == 2 ? 6 : DISCO_ROOM_AHEAD + 1)
 #endif
 
 // Shapes for which the DMA variant also exists on 16-bin tiles (option "room_tile16").  Measured SLOWER on the MI355X -- 16.8 against
@@ -274,7 +278,7 @@ struct alignas(16) RoomRing {
     using Gm = RoomGeom<M, K, NB_>;
     float4 xs[DISCO_ROOM_DEPTH][Gm::NITEMS];           // granules, linear in the loader's item index
     float ms[DISCO_ROOM_DEPTH][K * Gm::NB];
-    c32 zs[2][K][Gm::NB];
+    c32 zs[2 * DISCO_ROOM_FPB][K][Gm::NB];
     c32 wt[K][Gm::NB][M];
 };
 
@@ -335,7 +339,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
     constexpr int KR = Gm::KR, P = Gm::P, NP = Gm::NP, NB = Gm::NB, NA = Gm::NA, WA = Gm::WA, NT = Gm::NT, MH = Gm::MH;
     constexpr int NITEMS = Gm::NITEMS, NL = Gm::NL, D = DISCO_ROOM_DEPTH;
     constexpr int BPR = 16 / MH;                       // bins per 256-byte bank row of granules
-    static_assert(D == DISCO_ROOM_AHEAD + 1 && (DISCO_ROOM_AHEAD - 2) * (NL + 1) <= 9, "AHEAD frames ahead; vm_wait knows 0..9");
+    static_assert(DISCO_ROOM_FPB == 2 ? D == 6 : (D == DISCO_ROOM_AHEAD + 1 && (DISCO_ROOM_AHEAD - 2) * (NL + 1) <= 9), "AHEAD frames ahead; vm_wait knows 0..9");
     const int T = a.T, F = a.F;
     long long item = blockIdx.x;
     const int c = (int)(item % a.chunks);
@@ -402,7 +406,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
                     p.x = quad_xor_add<2>(p.x);
                     p.y = quad_xor_add<2>(p.y);
                 }
-                if (lzs[r] >= 0) (&sh.zs[t & 1][0][0])[lzs[r]] = p;
+                if (lzs[r] >= 0) (&sh.zs[t & (2 * DISCO_ROOM_FPB - 1)][0][0])[lzs[r]] = p;
                 zreg[r] = p;
             }
         }
@@ -443,7 +447,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         const float mkv = sh.ms[slot_][k * NB + bin];
         const float m = live ? mkv : 0.f, mc = live ? 1.f - mkv : 0.f;
         const float wa = m * m, wb = mc * mc;
-        const c32(*zs)[NB] = sh.zs[t & 1];
+        const c32(*zs)[NB] = sh.zs[t & (2 * DISCO_ROOM_FPB - 1)];
         if constexpr (is_a) {
             c32 x[4];
 #pragma unroll
@@ -474,6 +478,40 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         }
     };
 
+    if constexpr (DISCO_ROOM_FPB == 2) {
+        // Two frames per barrier: at the top of an iteration z(t), z(t + 1) are published and frames t + 2, t + 3 are in LDS; the
+        // iteration issues t + 4, t + 5 (into the slots of t - 2, t - 1), forms and stores z(t + 2), z(t + 3), folds t and t + 1 and
+        // waits for everything it issued.  Half the barriers, loop overhead and waits per frame; a load has two form_z + two folds to land.
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue(t0 + i, i);
+        vm_wait(0);
+        __syncthreads();                                // frames t0 ... t0 + 3 and the taps are in place
+        form_z(t0, 0);
+        store_z(t0);
+        if (t0 + 1 < t1) {
+            form_z(t0 + 1, 1);
+            store_z(t0 + 1);
+        }
+        __syncthreads();
+        int s0 = 0;
+        for (int t = t0; t < t1; t += 2) {
+            issue(t + 4, (s0 + 4) % D);
+            issue(t + 5, (s0 + 5) % D);
+            if (t + 2 < t1) {
+                form_z(t + 2, (s0 + 2) % D);
+                store_z(t + 2);
+            }
+            if (t + 3 < t1) {
+                form_z(t + 3, (s0 + 3) % D);
+                store_z(t + 3);
+            }
+            fold(t, s0);
+            if (t + 1 < t1) fold(t + 1, (s0 + 1) % D);
+            vm_wait(0);
+            __syncthreads();
+            s0 = (s0 + 2) % D;
+        }
+    } else {
     constexpr int AH = DISCO_ROOM_AHEAD;                // frames a load is issued ahead of its fold
 #pragma unroll
     for (int i = 0; i < AH; ++i) issue(t0 + i, i);
@@ -493,6 +531,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         if (t + 1 < t1) store_z(t + 1);                 // after the counted wait: the stores never stand between an issue and its wait
         __syncthreads();
         s0 = (s0 + 1) % D;
+    }
     }
     vm_wait(0);                                         // no LDS-DMA may outlive the workgroup's LDS allocation
     if (live) {
