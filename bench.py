@@ -695,6 +695,15 @@ def main(argv=None):
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE {world}: start with --gpus {world}, or plainly (no torchrun) to self-launch')
 
+    # The ONE JSON line is the only thing this process may put on stdout: libraries print banners there (RCCL its version block, from C
+    # stdio, flushed at exit -- i.e. AFTER the line).  The original stdout is kept for the line; descriptor 1 becomes stderr for everybody else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + '\n').encode())
+
     if args.selftest_launch:
         dist = dd.init('gloo', rank, world)
         value, dt = dd.whole_job_throughput(1000.0 * (rank + 1), 0.5 + 0.1 * rank, world)
@@ -703,7 +712,7 @@ def main(argv=None):
         rows = gather_rank_rows(rank, world, local_rank, 10 * rank, rooms, 1e-6 * (rank + 1), dist, 'cpu', gloo=True)
         ps = merge_parity({'rooms': rooms, 'per_room': {r: 1e-6 * (rank + 1) for r in rooms}, 'worst_rel': 1e-6 * (rank + 1)}, rows, 1e-4)
         if rank == 0:
-            print(json.dumps({'selftest': 'launch', 'n_gpus': world, 'value': value, 'seconds': dt, 'parity_sample': ps}), flush=True)
+            emit({'selftest': 'launch', 'n_gpus': world, 'value': value, 'seconds': dt, 'parity_sample': ps})
         dist.barrier()
         dist.destroy_process_group()
         return 0
@@ -799,7 +808,7 @@ def main(argv=None):
             line['exchange'] = head['exchange']
         if args.extra_names:
             line['configs'] = extras
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.barrier()                    # leave together
         dist.destroy_process_group()
