@@ -49,7 +49,7 @@ def test_emu_step2_reuse_gpu_shapes(make_engine, R, K, M):
     print(pc.check_step2_reuse(make_engine, R=R, K=K, M=M, L=3072))
 
 
-@pytest.mark.parametrize('K,M,world', [(4, 4, 2), (4, 2, 4), (6, 2, 3)])
+@pytest.mark.parametrize('K,M,world', [(4, 4, 2), (4, 2, 4), (6, 2, 3), (6, 4, 3), (2, 8, 2)])      # the last two: P > 8 with M = 4 / 8 (k_apply_mq on a shard of the nodes)
 def test_emu_node_sharded_gpu_shapes(make_engine, K, M, world):
     print(pc.check_node_sharded(make_engine, R=1, K=K, M=M, L=4096, world=world))
 
