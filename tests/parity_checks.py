@@ -917,7 +917,8 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
     # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route,
     # 't16': the ring on 16-bin tiles (option "room_tile16"; the shapes with K a multiple of 4 -- elsewhere the option changes nothing)
     engines = {}
-    for mode, cov, dma, t16 in (('1', 1, 1, 0), ('reg', 1, 0, 0), ('0', 0, 1, 0), ('t16', 1, 1, 1)):
+    modes = (('1', 1, 1, 0), ('reg', 1, 0, 0), ('0', 0, 1, 0)) + ((('t16', 1, 1, 1),) if K % 4 == 0 else ())
+    for mode, cov, dma, t16 in modes:
         e = eng if mode == '1' else make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
         if mode != '1' and tuning is not None:
             e.set_tuning(*tuning)
@@ -937,10 +938,10 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
         out_e, z_e, yf_e = e.tango_enhance(y, mm)
         res[mode] = (out_i.numpy(), yf_i.numpy(), out_e.numpy(), z_e.numpy(), yf_e.numpy())
     errs = {}
-    for name, a, b, c_, d_ in zip(('out_iter', 'yf_iter', 'out', 'z_y', 'yf'), res['1'], res['0'], res['reg'], res['t16']):
-        errs[name + '_vs_staged'] = max(relerr(a[r, k], b[r, k]) for r in range(R) for k in range(K))
-        errs[name + '_reg_vs_staged'] = max(relerr(c_[r, k], b[r, k]) for r in range(R) for k in range(K))
-        errs[name + '_t16_vs_staged'] = max(relerr(d_[r, k], b[r, k]) for r in range(R) for k in range(K))
+    for q, name in enumerate(('out_iter', 'yf_iter', 'out', 'z_y', 'yf')):
+        for mode in res:
+            if mode != '0':
+                errs[f'{name}_{mode}_vs_staged'] = max(relerr(res[mode][q][r, k], res['0'][q][r, k]) for r in range(R) for k in range(K))
     assert max(errs.values()) < 2e-5, errs
     for r in range(R):
         for it_, (o_idx, yf_idx) in ((iters, (0, 1)), (1, (2, 4))):
