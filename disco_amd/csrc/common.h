@@ -107,6 +107,31 @@ __device__ __forceinline__ float quad_xor_add(float x) {
     } while (0)
 #define DISCO_LDS_WAR() __builtin_amdgcn_wave_barrier()
 
+// Stores of data this pass will not read again and that is far larger than any cache (the spectra X: 20 GB per C3 step, the masks, the
+// output samples): DISCO_X_NT = 1 marks the stores of X non-temporal (global_store ... nt) -- 7.10 -> 6.88 ms per C3 launch of k_stft_cov,
+// same-box pairs (profiles/r03_y_*); DISCO_OUT_NT does the same for the mask and output-sample stores.
+#ifndef DISCO_X_NT
+#define DISCO_X_NT 1
+#endif
+#ifndef DISCO_OUT_NT
+#define DISCO_OUT_NT 0
+#endif
+__device__ __forceinline__ void store_stream16(float4* p, const float4& v) {
+#if defined(__clang__) && DISCO_X_NT
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f_{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_stream4(float* p, const float v) {
+#if defined(__clang__) && DISCO_OUT_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // The wave index as a PROVABLY wave-uniform value: anything derived from threadIdx is divergent to hipcc, which
 // then wraps every access guarded by a per-wave condition in exec-mask branches (one per load).
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

@@ -289,11 +289,11 @@ __device__ __forceinline__ void ola_emit_pair(const c32* v, float* carry, const 
             float* o = og + (long long)seg * H + lane;
             if ((long long)(seg + 1) * H <= L) {
 #pragma unroll
-                for (int e = 0; e < EH; ++e) o[64 * e] = val[e];
+                for (int e = 0; e < EH; ++e) store_stream4(&o[64 * e], val[e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < EH; ++e)
-                    if ((long long)seg * H + lane + 64 * e < L) o[64 * e] = val[e];
+                    if ((long long)seg * H + lane + 64 * e < L) store_stream4(&o[64 * e], val[e]);
             }
         }
     }

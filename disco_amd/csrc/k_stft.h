@@ -243,7 +243,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, 2) void k_stft_
             float4* dst = reinterpret_cast<float4*>(Xo);
             const int shift = (int)((reinterpret_cast<unsigned long long>(dst) >> 4) & 7);      // whole 128-byte lines per wave store (see k_stft_cov)
             for (int i = tid - shift; i < F * chp; i += 64 * STFT_WAVES)
-                if (i >= 0) dst[i] = src[pairs_tile_slot_linear(i, chp)];
+                if (i >= 0) store_stream16(&dst[i], src[pairs_tile_slot_linear(i, chp)]);
         } else {
             for (int i = tid; i < F * chans; i += 64 * STFT_WAVES) {
                 const int f = i / chans, c = i % chans;
@@ -317,7 +317,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_mask_ora
         float* mo = mask + (g * T + t) * (long long)F;
 #pragma unroll
         for (int j = 0; j <= EH; ++j)
-            if (j < EH || lane == 0) mo[lane + 64 * j] = mval[j];
+            if (j < EH || lane == 0) store_stream4(&mo[lane + 64 * j], mval[j]);
     }
 }
 
@@ -553,7 +553,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
                     float4* dst = reinterpret_cast<float4*>(Xo);
                     const int shift = (int)((reinterpret_cast<unsigned long long>(dst) >> 4) & 7);
                     for (int i = tid - shift; i < F * M / 2; i += 64 * STFT_WAVES)
-                        if (i >= 0) dst[i] = src[i];
+                        if (i >= 0) store_stream16(&dst[i], src[i]);
                 }
 #pragma unroll
                 for (int b = 0; b < BPT; ++b) {
