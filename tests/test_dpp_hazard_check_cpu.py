@@ -33,6 +33,13 @@ def test_exec_write_within_five_wait_states():
     assert run('\tv_cmpx_gt_f64 vcc, v[0:1], v[2:3]\n\ts_nop 1\n' + DPP)[1] != []
 
 
+def test_branch_target_inside_the_window():
+    # the listing's predecessor is harmless, but somebody jumps to the label: the instructions after it must cover 5 wait states
+    assert run('\tv_mov_b32_e32 v20, 0\n.LBB0_3:\n\ts_nop 1\n' + DPP)[1] != []
+    assert run('\tv_mov_b32_e32 v20, 0\n.LBB0_3:\n\ts_nop 4\n' + DPP)[1] == []
+    assert run('.LBB0_3:                                ; =>This Inner Loop Header: Depth=1\n\tv_mov_b64_e32 v[40:41], 0\n\ts_nop 4\n\ts_nop 1\n' + DPP)[1] == []
+
+
 def test_chain_on_the_accumulator_is_no_hazard():
     assert run(DPP + '\n' + DPP + '\n' + DPP) == (3, [])
 

@@ -3,9 +3,9 @@
 --save-temps): for every `*_dpp` instruction
   * no VALU instruction within the previous 2 wait states writes a VGPR its DPP source (src0) reads,
   * no instruction within the previous 5 wait states writes EXEC.
-`s_nop N` counts N + 1 wait states, every other instruction 1; a label (branch target) resets nothing -- the straight-line
-predecessor is what the listing shows, and the helpers put their s_nop AFTER any join (checked: a label inside the window is
-reported as 'label in window' unless an s_nop of sufficient length follows it).
+`s_nop N` counts N + 1 wait states, every other instruction 1.  A label (branch target) inside the 5-wait-state window is
+reported as well: the predecessor that jumps there is not the one the listing shows, so the instructions after the label must
+cover the EXEC rule on their own (the helpers put their s_nop AFTER every join).
 Usage: check_dpp_hazards.py file.s [kernel-name-substring]   -> exit code 1 when a hazard is found."""
 import re
 import sys
@@ -52,7 +52,10 @@ def check(lines, name=''):
                     break
                 w, hm, wr, wex, is_label = h
                 if is_label:
-                    continue
+                    # a branch target: the other predecessor is not in the listing's order -- it may have written EXEC or the source in
+                    # its last instruction, so the wait states since the label must cover the EXEC rule on their own
+                    bad.append((ln, f'{mn}: branch target {ws} wait states earlier (a predecessor the listing does not show)'))
+                    break
                 if wex:
                     bad.append((ln, f'{mn}: EXEC written {ws} wait states earlier by {hm}'))
                     break
