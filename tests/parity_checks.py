@@ -902,7 +902,7 @@ def check_no_allocation_in_compute_calls(make_engine, K=3, M=2, L=6000, n_fft=51
     return own
 
 
-def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tuning=None, tol=1e-4):
+def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tuning=None, tol=1e-4, tile16=None):
     """k_room_cov (csrc/k_room.h: z of every node + the step-2 statistics of every node of a room from ONE pass over X, wide
     shapes P = M + K - 1 > 8) against (a) the route it replaces -- disco_apply + the split covariance kernels, selected with
     disco_set_option("room_cov", 0) -- and (b) the float64 oracle; both whole-path entry points.  The three routes run on THREE
@@ -917,7 +917,9 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
     # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route,
     # 't16': the ring on 16-bin tiles (option "room_tile16"; the shapes with K a multiple of 4 -- elsewhere the option changes nothing)
     engines = {}
-    modes = (('1', 1, 1, 0), ('reg', 1, 0, 0), ('0', 0, 1, 0)) + ((('t16', 1, 1, 1),) if K % 4 == 0 else ())
+    if tile16 is None:
+        tile16 = K % 4 == 0               # (the emulated 8 x 8 case leaves it out: a fourth engine of that size doubles the suite's longest test)
+    modes = (('1', 1, 1, 0), ('reg', 1, 0, 0), ('0', 0, 1, 0)) + ((('t16', 1, 1, 1),) if tile16 and K % 4 == 0 else ())
     for mode, cov, dma, t16 in modes:
         e = eng if mode == '1' else make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
         if mode != '1' and tuning is not None:
