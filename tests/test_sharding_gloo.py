@@ -206,6 +206,8 @@ def test_bench_self_launches_ranks():
     p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--selftest-launch'], env=env,
                        capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
+    # stdout carries the ONE JSON line and nothing else (descriptor 1 is handed to stderr for libraries: RCCL prints a version block from C stdio)
+    assert len(p.stdout.strip().splitlines()) == 1, p.stdout[-500:]
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1 and lines[0]['n_gpus'] == 2                      # one line, from rank 0, of a 2-rank job
     assert lines[0]['value'] == pytest.approx((1000.0 + 2000.0) / 0.6)     # sum of units / max of times over the ranks
