@@ -94,6 +94,9 @@ extern "C" int disco_create(disco_ctx** out, const disco_cfg* cfg) {
     }
     DevGuard dev_guard_(cfg->device);                     // the caller's current device is restored on return
     hipError_t e = dev_guard_.ok ? hipSuccess : hipErrorInvalidValue;
+    ctx->n_cu = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device);
+    if (ctx->n_cu < 1) ctx->n_cu = 1;
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_win, N * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tw, N * sizeof(c32));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_win, win.data(), N * sizeof(float), hipMemcpyHostToDevice);
@@ -137,13 +140,24 @@ bool overlap_applies(const disco_ctx* ctx) {
 int ensure_halves(disco_ctx* ctx) {
     if (!overlap_applies(ctx) || ctx->half[0]) return 0;
     const int ra = ctx->cfg.rooms / 2, rb = ctx->cfg.rooms - ra;
+    // both children or none: a failure part-way (out of memory for the second child's blocks) must not leave half[0] set and
+    // half[1] NULL -- the next call would return early on half[0] and the overlapped route would dereference the missing one
+    auto drop = [ctx](int rc, const char* msg) {
+        char keep[sizeof(ctx->err)];
+        snprintf(keep, sizeof(keep), "%s", msg);
+        for (int h = 0; h < 2; ++h) {
+            if (ctx->half[h]) disco_destroy(ctx->half[h]);
+            ctx->half[h] = nullptr;
+        }
+        return fail(ctx, rc, keep);
+    };
     for (int h = 0; h < 2; ++h) {
         disco_cfg c = ctx->cfg;
         c.rooms = h ? rb : ra;
         c.flags |= DISCO_FLAG_NO_CHILDREN | DISCO_FLAG_LAZY_SCRATCH;
         disco_ctx* ch = nullptr;
         const int rc = disco_create(&ch, &c);
-        if (rc) return fail(ctx, rc, disco_last_error(nullptr));
+        if (rc) return drop(rc, disco_last_error(nullptr));
         ch->parent = ctx;
         ch->geom_rooms = ctx->cfg.rooms;                   // the launch geometry of the whole batch
         ch->tune_runw = ctx->tune_runw;
@@ -156,7 +170,7 @@ int ensure_halves(disco_ctx* ctx) {
         ctx->half[h] = ch;
         if (!(ctx->cfg.flags & DISCO_FLAG_LAZY_SCRATCH)) {
             const int rs = reserve_scratch(ch);
-            if (rs) return fail(ctx, rs, ch->err);
+            if (rs) return drop(rs, ch->err);
         }
     }
     if (!ctx->side_stream) {
@@ -281,7 +295,8 @@ const OptionInfo* option_table() {
         {"overlap_solves", "DISCO_OVERLAP_SOLVES", 1},
         {"solve_f32", "DISCO_SOLVE_F32", 0},
         {"solve_dpp", "DISCO_SOLVE_DPP", 1},
-        {"room_tile16", "DISCO_ROOM_TILE16", 0},
+        {"room_sub", "DISCO_ROOM_SUB", 8},
+        {"cov1_sub", "DISCO_COV1_SUB", 4},
     };
     return t;
 }

@@ -49,7 +49,7 @@ int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco_c32* R
 }
 // (M, KR) shapes of the block-partitioned kernels k_cov_split / k_cov_split_lds (api_cov_split.hip)
 bool cov_split_shape(int M, int KR);
-bool launch_cov_split_shape(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const disco::CovArgs& a);
+bool launch_cov_split_shape(int M, int KR, bool skiploc, int sub, unsigned nblk, hipStream_t st, const disco::CovArgs& a);
 
 // skiploc (step 2 only, internal): the caller guarantees that `scratch` holds the step-1 partial sums of THIS X with THIS
 // mask (ctx->loc_M == M): the leading M x M block is then neither accumulated nor written, the partial sums go to `scratch2`
@@ -90,10 +90,12 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
     const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
     bool launched = false;
     if (split) {                // 9 <= P <= 16, one vector for both statistics: one block of pairs per wave
-        const int tiles = (ctx->F - 1 + 63) / 64;
+        // step-1 shapes (KR = 0): time sub-chunks across the lanes (option "cov1_sub": 4 or 8; anything else: lanes are bins only)
+        const int o = ctx->opt[DISCO_OPT_COV1_SUB], sub = (KR == 0 && (o == 4 || o == 8)) ? o : 1;
+        const int tiles = (ctx->F - 1 + 64 / sub - 1) / (64 / sub);
         const long long nblk = G * (tiles + 1) * chunks;
         if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
-        launched = launch_cov_split_shape(M, KR, skiploc, (unsigned)nblk, (hipStream_t)s, a);
+        launched = launch_cov_split_shape(M, KR, skiploc, sub, (unsigned)nblk, (hipStream_t)s, a);
     }
 #define X_(M_, KR_)                                                                                                  \
     if (!launched && M == M_ && KR == KR_) {                                                                         \

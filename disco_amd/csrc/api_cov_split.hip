@@ -10,8 +10,8 @@ bool cov_split_shape(int M, int KR) {
     return false;
 }
 
-bool launch_cov_split_shape(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {
-    return launch_cov_split_m8(M, KR, skiploc, nblk, st, a) || launch_cov_split_m4(M, KR, skiploc, nblk, st, a) ||
-           launch_cov_split_m2(M, KR, skiploc, nblk, st, a);
+bool launch_cov_split_shape(int M, int KR, bool skiploc, int sub, unsigned nblk, hipStream_t st, const CovArgs& a) {
+    return launch_cov_split_m8(M, KR, skiploc, sub, nblk, st, a) || launch_cov_split_m4(M, KR, skiploc, sub, nblk, st, a) ||
+           launch_cov_split_m2(M, KR, skiploc, sub, nblk, st, a);
 }
 }  // namespace disco_host

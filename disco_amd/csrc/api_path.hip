@@ -157,6 +157,7 @@ int reserve_scratch(disco_ctx* ctx) {
     const size_t NP = P * (P + 1) / 2;
     int chunks = std::max(cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));
     if (c.mics <= 8) chunks = std::max(chunks, stft_cov_chunks(ctx, nullptr));
+    if (c.mics + c.nodes - 1 > 8) chunks = std::max(chunks, room_chunks(ctx));
     const size_t need = G * (size_t)chunks * ctx->F * NP * sizeof(float4);
     int rc = ensure_scratch(ctx, need);
     if (!rc) rc = ensure_scratch2(ctx, need);
@@ -260,7 +261,7 @@ extern "C" int disco_tango_enhance(disco_ctx* ctx, const float* y, const float* 
     const disco_cfg& c0 = ctx->cfg;
     const bool fused_route = c0.nodes > 1 && c0.mics + c0.nodes - 1 <= 8 && !(c0.flags & DISCO_FLAG_STAGED_STEP2);
     // by default only where it was measured to pay: the fused route (C3: 19.67 -> 19.14 ms); forced (2 / 3) for every route
-    if (overlap_applies(ctx) && ctx->half[0] && (fused_route || ctx->opt[DISCO_OPT_OVERLAP_SOLVES] >= 2)) {
+    if (overlap_applies(ctx) && ctx->half[0] && ctx->half[1] && (fused_route || ctx->opt[DISCO_OPT_OVERLAP_SOLVES] >= 2)) {
         Steps st[2];
         for (int h = 0; h < 2; ++h) enhance_steps(ctx->half[h], child_args(ctx, a, h), st[h]);
         return run_pipelined(ctx, st, s);
@@ -527,7 +528,7 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     // The overlapped form on the wide shapes: with the LDS group solver it lost (C5: 46.4 ms plain, 48.0 / 48.4 ms overlapped -- the room
     // pass takes a whole CU per workgroup and the solver's LDS blocks compete with it); with the register / DPP solver (k_solve_dpp.h:
     // 15 KB of LDS per wave, float64 VALU only) it pays: 38.40 -> 37.88 ms (profiles/r03_o_C5_overlap*.json).  Default like the fused route.
-    if (overlap_applies(ctx) && ctx->half[0] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
+    if (overlap_applies(ctx) && ctx->half[0] && ctx->half[1] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
         Steps st[2];
         for (int h = 0; h < 2; ++h) iterated_steps(ctx->half[h], child_args(ctx, a, h), iters, st[h]);
         return run_pipelined(ctx, st, s);

@@ -1,6 +1,5 @@
 // libdisco_hip.so -- host side of the C ABI declared in include/disco_hip.h (gfx950 only): one-pass room covariance for the wide shapes
-#include "host.h"
-#include "k_room.h"
+#include "room_launch.h"
 
 using namespace disco;
 using namespace disco_host;
@@ -8,19 +7,7 @@ using namespace disco_host;
 // Wide shapes (P = M + K - 1 > 8), all nodes of a room on this GPU, mask_for_z = 'local', step-1 partial sums of THIS X with
 // THIS mask still in `scratch`: z of every node AND the step-2 partial sums of every node from ONE pass over X (k_room.h),
 // instead of disco_apply + cov_partials; room_cov_ok says whether the shape and the context's state qualify.
-#define DISCO_FOR_ROOM(X_) X_(8, 8) X_(8, 6) X_(8, 4) X_(8, 2) X_(4, 8) X_(4, 6)
 namespace disco_host {
-template <int M, int K>
-static void launch_room_dma(bool tile16, unsigned nblk, hipStream_t st, const RoomArgs& a) {
-    if constexpr (room_tile16_shape<M, K>()) {
-        if (tile16) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M, K, 16>), dim3(nblk), dim3(RoomGeom<M, K, 16>::NT), 0, st, a);
-            return;
-        }
-    }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M, K, 32>), dim3(nblk), dim3(RoomGeom<M, K, 32>::NT), 0, st, a);
-}
-
 bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes;
@@ -34,12 +21,24 @@ bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     return (long long)K * ctx->T * ctx->F * M <= 0x0fffffffLL;                               // 32-bit BYTE offsets inside a room (8 B per element)
 }
 
+// time sub-chunks per workgroup of the persistent pass (option "room_sub": 1, 2, 4 or 8; anything else: 8)
+static int room_sub(const disco_ctx* ctx) {
+    const int s = ctx->opt[DISCO_OPT_ROOM_SUB];
+    return (s == 1 || s == 2 || s == 4) ? s : 8;
+}
+
+// The persistent pass forms ONE partial block per node: its workgroups walk items (room, tile of 32 / SUB bins), the time axis is
+// split INSIDE the workgroup (SUB sub-chunks across the lanes).  The register-staged kernel keeps the chunked geometry.
+int room_chunks(const disco_ctx* ctx) { return ctx->opt[DISCO_OPT_ROOM_DMA] != 0 ? 1 : cov_chunks(ctx); }
+
 int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
                              int* chunks_out, disco_stream s) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes, P = M + K - 1;
     if (!w_loc || !z || !room_cov_ok(ctx, X, mask)) return fail(ctx, DISCO_E_ARG, "room covariance: shape / state does not qualify");
-    const int chunks = cov_chunks(ctx);
+    const bool dma = ctx->opt[DISCO_OPT_ROOM_DMA] != 0;
+    // the persistent LDS-DMA pass (default), or the register-staged kernel one frame ahead (DISCO_ROOM_DMA=0; k_room.h)
+    const int chunks = room_chunks(ctx);
     const long long G = (long long)c.rooms * K;
     const int NP = P * (P + 1) / 2;
     int rc = ensure_scratch2(ctx, (size_t)G * chunks * ctx->F * NP * sizeof(float4));
@@ -54,22 +53,25 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
     a.F = ctx->F;
     a.chunks = chunks;
     a.R = c.rooms;
-    // frames through an LDS-DMA ring three ahead (default), or staged through registers one ahead (DISCO_ROOM_DMA=0; k_room.h)
-    const bool dma = ctx->opt[DISCO_OPT_ROOM_DMA] != 0;
-#define X_(M_, K_)                                                                                                       \
-    if (M == M_ && K == K_) {                                                                                            \
-        const bool t16 = dma && room_tile16_shape<M_, K_>() && ctx->opt[DISCO_OPT_ROOM_TILE16] != 0;       /* 16-bin tiles (k_room.h) */ \
-        const int nb = t16 ? 16 : 32;                                                                                    \
-        a.tiles = (ctx->F + nb - 1) / nb;                                                                                \
-        const long long nblk = (long long)c.rooms * a.tiles * chunks;                                                    \
-        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch"); \
-        if (dma)                                                                                                         \
-            launch_room_dma<M_, K_>(t16, (unsigned)nblk, (hipStream_t)s, a);                                             \
-        else                                                                                                             \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);     \
-    }
-    DISCO_FOR_ROOM(X_)
+    if (dma) {
+        const int sub = room_sub(ctx), nb = 32 / sub;
+        a.tiles = (ctx->F + nb - 1) / nb;
+        const long long items = (long long)c.rooms * a.tiles;
+        if (items > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
+        const unsigned nwg = (unsigned)std::min<long long>(items, ctx->n_cu);               // one persistent workgroup per CU
+        const hipStream_t st = (hipStream_t)s;
+        const bool ok = sub == 1 ? launch_room_s1(M, K, nwg, st, a) : sub == 2 ? launch_room_s2(M, K, nwg, st, a)
+                      : sub == 4 ? launch_room_s4(M, K, nwg, st, a) : launch_room_s8(M, K, nwg, st, a);
+        if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: shape not instantiated");
+    } else {
+        a.tiles = (ctx->F + 31) / 32;
+        const long long nblk = (long long)c.rooms * a.tiles * chunks;
+        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
+#define X_(M_, K_) \
+        if (M == M_ && K == K_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);
+        DISCO_FOR_ROOM(X_)
 #undef X_
+    }
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;
     ctx->pending_P = P;

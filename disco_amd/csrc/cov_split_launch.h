@@ -7,17 +7,14 @@
 namespace disco_host {
 using namespace disco;
 
-#ifndef DISCO_COV1_LDS
-#define DISCO_COV1_LDS 0            // 1: the step-1 statistics of M = 8 staged through LDS as well (k_cov_split_lds<8, 0>).  Measured equal on the
-                                    // MI355X (C5 cov1 3.88 / 4.05 against 3.79 / 4.20 ms, profiles/r03_p_*): the per-wave fetches of k_cov_split stay
-#endif
 
+// sub: time sub-chunks across the lanes of a wave for the step-1 shapes (KR = 0; option "cov1_sub"): the grid then counts tiles of 64 / sub bins
 template <int M, int KR>
-static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {
+static void launch_cov_split(bool skiploc, int sub, unsigned nblk, hipStream_t st, const CovArgs& a) {
     // even M (every shape with remote rows, and the step-1 shape M = 8) with F - 1 a multiple of 64 (both FFT sizes of this library): frames
     // staged through LDS once per workgroup (k_cov.h; with remote rows 7.3 ms per C5 launch, the per-wave fetches of k_cov_split: 9.6 ms)
     if constexpr (M % 2 == 0) {
-        if (KR > 0 || (DISCO_COV1_LDS && (a.F - 1) % 64 == 0)) {
+        if (KR > 0) {
             const unsigned nb = DISCO_COV_XCD ? (nblk + DISCO_COV_XCD - 1) / DISCO_COV_XCD * DISCO_COV_XCD : nblk;      // see the kernel's id -> item map
             if constexpr (KR > 0) {
                 if (skiploc) {
@@ -29,7 +26,11 @@ static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const 
             return;
         }
     }
-    if constexpr (KR == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+    if constexpr (KR == 0) {
+        if (sub == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false, 4>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+        else if (sub == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false, 8>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+    }
 }
 
 
@@ -39,18 +40,18 @@ static void launch_cov_split(bool skiploc, unsigned nblk, hipStream_t st, const 
 #define DISCO_FOR_SPLIT_M4(X_) X_(4, 5) X_(4, 6) X_(4, 7) X_(4, 8) X_(4, 9) X_(4, 10) X_(4, 11) X_(4, 12)
 #define DISCO_FOR_SPLIT_M2(X_) X_(2, 7) X_(2, 8) X_(2, 9) X_(2, 10) X_(2, 11) X_(2, 12) X_(2, 13) X_(2, 14)
 
-bool launch_cov_split_m8(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a);
-bool launch_cov_split_m4(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a);
-bool launch_cov_split_m2(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a);
+bool launch_cov_split_m8(int M, int KR, bool skiploc, int sub, unsigned nblk, hipStream_t st, const CovArgs& a);
+bool launch_cov_split_m4(int M, int KR, bool skiploc, int sub, unsigned nblk, hipStream_t st, const CovArgs& a);
+bool launch_cov_split_m2(int M, int KR, bool skiploc, int sub, unsigned nblk, hipStream_t st, const CovArgs& a);
 
 #define DISCO_DEFINE_SPLIT_LAUNCHER(NAME_, TABLE_)                                                          \
-    bool NAME_(int M, int KR, bool skiploc, unsigned nblk, hipStream_t st, const CovArgs& a) {              \
+    bool NAME_(int M, int KR, bool skiploc, int sub, unsigned nblk, hipStream_t st, const CovArgs& a) {     \
         TABLE_(DISCO_SPLIT_CASE_)                                                                           \
         return false;                                                                                       \
     }
 #define DISCO_SPLIT_CASE_(M_, KR_)                        \
     if (M == M_ && KR == KR_) {                           \
-        launch_cov_split<M_, KR_>(skiploc, nblk, st, a);  \
+        launch_cov_split<M_, KR_>(skiploc, sub, nblk, st, a);  \
         return true;                                      \
     }
 }  // namespace disco_host

@@ -35,7 +35,8 @@ enum {
     DISCO_OPT_OVERLAP_SOLVES,           // "overlap_solves": whole-path calls run the batch as two halves on two streams
     DISCO_OPT_SOLVE_F32,                // "solve_f32": float32 squarings + float64 Rayleigh-quotient finish in the group solver (default 0: all float64)
     DISCO_OPT_SOLVE_DPP,                // "solve_dpp": 9 <= P <= 16 solved in registers with DPP row broadcasts (k_solve_dpp.h; 0: the LDS group solver)
-    DISCO_OPT_ROOM_TILE16,              // "room_tile16": the room pass's DMA variant on 16-bin tiles, two workgroups per CU (measured slower; default 0)
+    DISCO_OPT_ROOM_SUB,                 // "room_sub": time sub-chunks per workgroup of the persistent room pass (1, 2, 4 or 8 -> 32, 16, 8 or 4 bins per workgroup)
+    DISCO_OPT_COV1_SUB,                 // "cov1_sub": time sub-chunks across the lanes of the step-1 statistics of the wide shapes (M >= 7): 4 / 8, else 1
     DISCO_N_OPTIONS
 };
 namespace disco_host {
@@ -70,6 +71,7 @@ struct disco_ctx {
     int zblk;                        // layout of the exchanged-signal arguments Zs / Zn / Z (disco_set_z_blocks; default K = plain)
     int tune_runw, tune_cov_chunks, tune_step2_chunks, tune_pairs;   // disco_set_tuning overrides (0 = batch-size heuristic)
     int opt[DISCO_N_OPTIONS];        // disco_set_option values (DISCO_OPT_*)
+    int n_cu;                        // compute units of cfg.device (the persistent kernels start one workgroup per CU)
     int geom_rooms;                  // batch size the launch-geometry heuristics look at (cfg.rooms; a half-batch child: its parent's)
     // two half-batch children (rooms split [0, R/2) and [R/2, R)) + the second stream / events of the overlapped whole-path calls
     // (DISCO_OPT_OVERLAP_SOLVES): one half's solves run beside the other half's streaming kernels.  NULL when not in use.
@@ -204,6 +206,7 @@ RefLayout ref_layout(const disco_ctx* ctx);
 
 // launch geometry (batch-size heuristics / disco_set_tuning)
 int cov_chunks(const disco_ctx* ctx);
+int room_chunks(const disco_ctx* ctx);
 int step2_chunks(const disco_ctx* ctx, int tiles_plus_1);
 int stft_cov_chunks(const disco_ctx* ctx, int* runw_out);
 

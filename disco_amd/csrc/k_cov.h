@@ -429,21 +429,27 @@ __device__ __forceinline__ void cov_split_store(float4* o, const c32* acc_s, con
     }
 }
 
-template <int M, int KR, int X0, int X1, int Y0, int Y1, bool TRI>
+// S > 1: the tile is 64 / S bins wide and a wave's lanes are (sub-chunk sc, bin): lane (sc, b) folds frames t0 + sc, t0 + sc + S, ... of
+// the chunk -- S times shorter float32 sums per accumulator at the same register count (round 4: the step-1 statistics of the wide
+// shapes summed 157 frames each, and the 8 x 8 block they produce is the leading block of every step-2 pencil; cf. k_room.h) -- and
+// the S partial sums of an entry meet through the lane crossbar at the end, where the Nyquist tile's 64 always did.
+template <int M, int KR, int X0, int X1, int Y0, int Y1, bool TRI, int S = 1>
 __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, int c, int tile, int lane) {
     using Role = CovSplitRole<M, KR, X0, X1, Y0, Y1, TRI>;
     constexpr int P = M + KR, NP = P * (P + 1) / 2, NX = Role::NX, NY = Role::NY, NPAIR = Role::NPAIR;
+    constexpr int NBT = 64 / S;                                                  // bins per tile
+    static_assert(S == 1 || S == 2 || S == 4 || S == 8, "sub-chunks share a wave");
     if constexpr (NPAIR == 0) {
         return;
     } else {
         const int K = a.K, T = a.T, F = a.F;
-        const int nbin = F - 1, tiles = (nbin + 63) / 64;
+        const int nbin = F - 1, tiles = (nbin + NBT - 1) / NBT;
         const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
         const bool nyq = tile == tiles;
-        int f = nyq ? nbin : tile * 64 + lane;
+        int f = nyq ? nbin : tile * NBT + (lane & (NBT - 1));
         const bool live = nyq || f < nbin;
         if (f > nbin) f = nbin;
-        const int t_step = nyq ? 64 : 1, t_off = nyq ? lane : 0;
+        const int t_step = nyq ? 64 : S, t_off = nyq ? lane : lane / NBT;
         const long long r = g / a.Kl;
         const int k = a.k0 + (int)(g % a.Kl);
         const c32* xp = a.X + (g * T * (long long)F) * M;                     // wave-uniform plane pointers (scalar registers)
@@ -481,18 +487,20 @@ __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, in
             for (int i = 0; i < NY; ++i) uy[i] = ny[i];
             mcur = mnext;
         }
-        if (nyq) {          // lanes hold partial sums over disjoint frames of the same bin
+        if (nyq || S > 1) {          // lanes hold partial sums over disjoint frames of the same bin: all 64 (Nyquist tile) or the S sub-chunks
+            const int stop = nyq ? 1 : NBT;
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q)
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) {
+                    if (off < stop) break;
                     acc_s[q].x += __shfl_xor(acc_s[q].x, off);
                     acc_s[q].y += __shfl_xor(acc_s[q].y, off);
                     acc_n[q].x += __shfl_xor(acc_n[q].x, off);
                     acc_n[q].y += __shfl_xor(acc_n[q].y, off);
                 }
         }
-        if (live && (!nyq || lane == 0)) {
+        if (live && (nyq ? lane == 0 : lane < NBT)) {
             float4* o = a.part + (((g * a.chunks + c) * F) + f) * (long long)NP;
             cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
         }
@@ -524,11 +532,12 @@ __device__ __forceinline__ void cov_split_roles(const int role, Fn&& fn) {
     }
 }
 
-// grid = R*Kl * (tiles + 1) * chunks blocks of 64 * cov_split_waves() threads; Zs == Zn and mask_remote != 0 are the caller's contract
-template <int M, int KR, bool SKIPLOC>
+// grid = R*Kl * (tiles + 1) * chunks blocks of 64 * cov_split_waves() threads, tiles = ceil((F - 1) / (64 / S)); Zs == Zn and
+// mask_remote != 0 are the caller's contract
+template <int M, int KR, bool SKIPLOC, int S = 1>
 __global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_split(CovArgs a) {
     static_assert(KR > 0 || !SKIPLOC, "nothing to compute");
-    const int nbin = a.F - 1, tiles = (nbin + 63) / 64;
+    const int nbin = a.F - 1, tiles = (nbin + 64 / S - 1) / (64 / S);
     int bid = blockIdx.x;
     const int c = bid % a.chunks;
     bid /= a.chunks;
@@ -538,7 +547,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLO
     const int role = wave_id() + (KR > 0 ? 0 : 6);
     cov_split_roles<M, KR, SKIPLOC>(role, [&](auto tag) {
         using R_ = decltype(tag);
-        cov_split_wave<M, KR, R_::x0, R_::x1, R_::y0, R_::y1, R_::tri>(a, g, c, tile, lane);
+        cov_split_wave<M, KR, R_::x0, R_::x1, R_::y0, R_::y1, R_::tri, S>(a, g, c, tile, lane);
     });
 }
 

@@ -240,53 +240,78 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
     else room_cov_run<M, K, false>(a, sh);
 }
 
-// ---- the same pass with the frames fetched by LDS-DMA ---------------------------------------------------------------------------
+// ---- the same pass, frames fetched by LDS-DMA, as ONE PERSISTENT workgroup per CU with time sub-chunks across its lanes --------------
 // k_room_cov keeps ONE frame of the tile in flight per workgroup (registers: 112 of a lane's 168 are accumulators, a second
-// frame does not fit) and there is one workgroup per CU: 4.4 MB in flight over the chip (8.6 ms per C5 launch; this variant: 7.1 ms,
-// the two passes it replaces: 11.0 ms).  Here the spectra and masks go from HBM straight into an LDS ring of
-// DISCO_ROOM_DEPTH frames (global_load_lds_dwordx4 / _dword: no registers), issued DISCO_ROOM_AHEAD = 3 frames ahead:
-//   iteration t:  issue frame t + 3  ->  fold frame t  ->  wait until only that issue is outstanding (frame t + 2 has landed)
-//                 ->  form z(t + 1) from the ring (own granule + taps, cross-lane sum), publish it  ->  barrier.
+// frame does not fit) and there is one workgroup per CU.  Here the spectra and masks go from HBM straight into an LDS ring
+// (global_load_lds_dwordx4 / _dword: no registers) two iterations ahead of their use.
+//
+// Round 4 -- what changed and why.  C5's two-iteration output was 2.3e-4 from the float64 oracle because every accumulator summed
+// 157 frames sequentially in float32 (profiles/r03_c5_accumulation.txt); more frame chunks per node cured it at 1.2 GB of partial
+// sums written and read back per extra chunk and launch.  A second accumulation level does not fit the registers (112 + 112).
+// What does fit is MORE, SHORTER sums at the same register count: a workgroup now owns 32 / SUB bins and SUB CONSECUTIVE FRAMES at a
+// time -- lane = (bin, slot, sub-chunk sc), the lane folds frames t0 + SUB u + sc, u = 0, 1, ... -- so a lane's sums are SUB times
+// shorter, the bytes per barrier, the ring, the loader rounds and the arithmetic per lane are exactly what they were, and the SUB
+// partial sums of an entry meet INSIDE the wave at the end (v_permlane32_swap / v_permlane16_swap: the two halves swap one register
+// each and add, so every level also halves the entries a lane is left to store).  SUB = 8 sums 20 frames per accumulator where
+// round 3 summed 157, and ONE partial block per node reaches HBM instead of two.
+// Shorter items would pay the per-workgroup prologue / epilogue (about 20 us of a 250 us item in round 3: dispatch, taps, ring fill,
+// first z, 28 uncoalesced 16-byte stores per lane) four to eight times as often, so the workgroup is PERSISTENT: it walks items
+// blockIdx.x, blockIdx.x + gridDim.x, ... (an item: a room's tile, all its frames) and the ring never drains -- the loads of the next item's first frames (and its taps, into
+// the other tap buffer) are issued while the current item's last frames are folded, the sums of the finished item are reduced and
+// stored under the first iteration of the next.
+//
+// Per iteration (two groups of SUB frames):
+//   issue   groups of the iteration after next  ->  ring slots (s0 + 4, s0 + 5) % 6       [+ the next item's taps when it begins]
+//   [reduce + store + clear the sums of the item whose last groups were folded in the previous iteration]
+//   form    z of the next iteration's groups from the ring (own granule + taps, cross-lane sum), publish in LDS, store to HBM
+//   fold    this iteration's two groups
+//   s_waitcnt vmcnt(0); barrier
 // An LDS-DMA wave-load writes 64 lanes x 16 B to consecutive LDS bytes, so a lane's LDS position is fixed and the granule it
-// FETCHES is chosen instead: position (bin, lp') holds granule lp = lp' ^ swz(bin) -- an XOR swizzle that keeps the 16-byte
-// reads of the covariance lanes (same granule, 16 consecutive bins) on distinct banks without padding.
-// The waits are counted by hand (the instructions are inline asm: hipcc's own LDS-DMA tracking would wait for vmcnt(0) before every
-// LDS read, the ring index being a run-time value): after the wait of iteration t at most the loads of frame t + 3 are
-// outstanding; VMEM operations return in order, the z stores of the previous iteration are older than that issue.  The kernel
-// must not spill (a scratch access in the loop would shift the count): build.py checks the resource usage.
-#ifndef DISCO_ROOM_AHEAD
-#define DISCO_ROOM_AHEAD 3              // frames between a frame's LDS-DMA issue and its fold.  3 = one iteration between an issue and the wait
-                                        // for it; 4 / 5 (two / three iterations, 16 KB of LDS each) measured 14.12 / 14.19 ms against 14.08 ms per
-                                        // C5 step (profiles/r03_n_*): the pass is not waiting for its loads
-#endif
-#ifndef DISCO_ROOM_FPB
-#define DISCO_ROOM_FPB 2                // frames per barrier.  2: six ring slots, two frames issued / formed / folded per iteration, one wait for
-                                        // both -- 13.4 against 14.0 ms per C5 step for 1 (profiles/r03_t_*), bit-identical sums
-#endif
+// FETCHES is chosen instead: position (sc, node, bin, lp') holds granule lp = lp' ^ swz(bin, sc) -- an XOR swizzle that keeps the
+// 16-byte reads of the covariance lanes on distinct banks without padding.  The waits are written by hand (the loads are inline
+// asm: hipcc's own LDS-DMA tracking would wait for vmcnt(0) before every LDS read, the ring index being a run-time value); every
+// iteration waits for everything it issued, so nothing depends on the order in which loads and stores retire.  The kernel must
+// not spill: build.py checks the resource usage.
 #ifndef DISCO_ROOM_DEPTH
-#define DISCO_ROOM_DEPTH (DISCO_ROOM_FPB == 2 ? 6 : DISCO_ROOM_AHEAD + 1)
+#define DISCO_ROOM_DEPTH 6              // ring slots: two groups per iteration, issued two iterations ahead
 #endif
 
-// Shapes for which the DMA variant also exists on 16-bin tiles (option "room_tile16").  Measured SLOWER on the MI355X -- 16.8 against
-// 14.05 ms per C5 step (profiles/r03_s_*): the pass is bound by what a frame costs a workgroup whatever its width (barrier, LDS-DMA
-// issue, z formation), not by phase-locked waves.  Kept selectable, and tested, as the record of it.
-template <int M, int K>
-constexpr bool room_tile16_shape() { return K % 4 == 0; }
+template <int M, int K, int SUB_>
+struct RoomGeomS {
+    static_assert(SUB_ == 1 || SUB_ == 2 || SUB_ == 4 || SUB_ == 8, "sub-chunks share a wave");
+    static_assert(M % 4 == 0 && K % 2 == 0 && K >= 2 && K <= 8, "4-mic slots, two slots per wave, <= 28 pairs per slot");
+    static constexpr int SUB = SUB_, NB = 32 / SUB_;    // frames per group, bins per workgroup
+    static constexpr int KR = K - 1, P = M + KR, NP = P * (P + 1) / 2;
+    static constexpr int NA = M / 4;                    // A slots per node
+    static constexpr int WA = K * NA / 2, WB = K / 2;   // waves of A slots, waves of B slots (two slots per wave)
+    static constexpr int NT = 64 * (WA + WB);
+    static constexpr int MH = M / 2;                    // 16-byte granules (two mics) per bin
+    static constexpr int NROW = K * NB * MH;            // granules of one frame of the tile
+    static constexpr int NITEMS = SUB * NROW;           // ... of a group of SUB frames: 32 K MH whatever SUB is
+    static constexpr int NL = (NITEMS + NT - 1) / NT;   // loader rounds
+    static_assert(NITEMS % 64 == 0 && (NITEMS - (NL - 1) * NT) % 64 == 0, "whole waves in every loader round");
+    static constexpr int NMASK = SUB * K * NB;          // mask values of a group: 32 K
+    static constexpr int NMW = NMASK / 64;              // ... in wave-loads
+    static_assert(NMASK % 64 == 0 && NMW <= WA + WB, "one mask wave-load per wave");
+    static constexpr int NTAPP = (NROW + 63) / 64 * 64; // tap granules of an item, padded to whole wave-loads
+    static constexpr int BPR = 16 / MH;                 // bins per 256-byte bank row of granules
+    static constexpr int LH = SUB >= 4 ? 2 : (SUB == 2 ? 1 : 0);      // halving levels of the final reduction (lane bits 5, 4)
+};
 
-template <int M, int K, int NB_>
-struct alignas(16) RoomRing {
-    using Gm = RoomGeom<M, K, NB_>;
+template <int M, int K, int SUB>
+struct alignas(16) RoomRingS {
+    using Gm = RoomGeomS<M, K, SUB>;
     float4 xs[DISCO_ROOM_DEPTH][Gm::NITEMS];           // granules, linear in the loader's item index
-    float ms[DISCO_ROOM_DEPTH][K * Gm::NB];
-    c32 zs[2 * DISCO_ROOM_FPB][K][Gm::NB];
-    c32 wt[K][Gm::NB][M];
+    float4 wt[2][Gm::NTAPP];                           // the step-1 filters of the current and of the next item, as granules
+    float ms[DISCO_ROOM_DEPTH][Gm::NMW][64 + 8];       // one padded row per wave-load (the SUB sub-chunks of a wave read different rows)
+    c32 zs[4][SUB][K + 1][Gm::NB];                     // z of four groups in flight; the + 1 row keeps the sub-chunks of a wave off each other's banks
 };
 
 // 64 lanes x 16 (4) bytes, lane i from gbase + off[i] (gbase wave-uniform: an SGPR pair, off a 32-bit byte offset: no per-lane
 // 64-bit address arithmetic), to the LDS bytes [lds_wave, lds_wave + 1024 (256)) in lane order; lds_wave is wave-uniform.
 // M0 (the LDS-DMA destination base) is compiler-reserved: saved, written and restored inside the one statement that reads it;
 // the nops cover "SALU writes an SGPR -> VMEM reads it as base" (5 wait states) for a base the compiler has just formed.
-// hipcc neither counts these loads nor waits for them (vm_wait below does).
+// hipcc neither counts these loads nor waits for them (vm_wait_all below does).
 __device__ __forceinline__ void lds_dma16(const void* gbase, unsigned off, void* lds_wave, int lane) {
 #if defined(__clang__)
     (void)lane;
@@ -313,90 +338,127 @@ __device__ __forceinline__ void lds_dma4(const void* gbase, unsigned off, void* 
     reinterpret_cast<float*>(lds_wave)[lane] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gbase) + off);
 #endif
 }
-// at most N vector-memory operations of this wave still outstanding (N <= 9 here)
-__device__ __forceinline__ void vm_wait(int n) {
+// every vector-memory operation of this wave has completed (LDS-DMA loads have landed, stores are out)
+__device__ __forceinline__ void vm_wait_all() {
 #if defined(__clang__)
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    }
-#else
-    (void)n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 
-template <int M, int K, int NB_, bool IS_A>
-__device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, K, NB_>& sh) {
-    using Gm = RoomGeom<M, K, NB_>;
-    constexpr int KR = Gm::KR, P = Gm::P, NP = Gm::NP, NB = Gm::NB, NA = Gm::NA, WA = Gm::WA, NT = Gm::NT, MH = Gm::MH;
-    constexpr int NITEMS = Gm::NITEMS, NL = Gm::NL, D = DISCO_ROOM_DEPTH;
-    constexpr int BPR = 16 / MH;                       // bins per 256-byte bank row of granules
-    static_assert(DISCO_ROOM_FPB == 2 ? D == 6 : (D == DISCO_ROOM_AHEAD + 1 && (DISCO_ROOM_AHEAD - 2) * (NL + 1) <= 9), "AHEAD frames ahead; vm_wait knows 0..9");
-    const int T = a.T, F = a.F;
-    long long item = blockIdx.x;
-    const int c = (int)(item % a.chunks);
-    item /= a.chunks;
-    const int tile = (int)(item % a.tiles);
-    const long long room = item / a.tiles;
-    const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
-    const int f0 = tile * NB;
-    const int tid = threadIdx.x, wid = wave_id(), lane = tid & 63;
-    const int bin = lane & (NB - 1), sub = lane / NB;
-    const bool live = f0 + bin < F;
+// 2 x 2 transpose between two registers and lane bit BIT, then the sum: lanes with the bit clear are left with a + a' (a' = the partner
+// lane's a), lanes with it set with b + b'.  One swap + one add per PAIR of registers, and the survivors are split between the halves.
+template <int BIT>
+__device__ __forceinline__ float lane_swap_add(float a, float b, int lane) {
+#if defined(__clang__)
+    (void)lane;
+    static_assert(BIT == 32 || BIT == 16, "permlane swaps");
+    if constexpr (BIT == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#else
+    const float pa = __shfl_xor(a, BIT), pb = __shfl_xor(b, BIT);
+    return (lane & BIT) ? pb + b : a + pa;
+#endif
+}
+// entries [0, N) of (es, en) -> [0, N / 2): entry e meets entry e + N / 2; lanes with the bit set keep the upper half's totals
+template <int BIT, int N>
+__device__ __forceinline__ void room_halve(c32* es, c32* en, int lane) {
+    static_assert(N % 2 == 0, "pairs of entries");
+#pragma unroll
+    for (int e = 0; e < N / 2; ++e) {
+        es[e].x = lane_swap_add<BIT>(es[e].x, es[e + N / 2].x, lane);
+        es[e].y = lane_swap_add<BIT>(es[e].y, es[e + N / 2].y, lane);
+        en[e].x = lane_swap_add<BIT>(en[e].x, en[e + N / 2].x, lane);
+        en[e].y = lane_swap_add<BIT>(en[e].y, en[e + N / 2].y, lane);
+    }
+}
 
-    const c32* Xr = a.X + (room * K * T) * (long long)F * M;
-    c32* Zr = a.z + (room * K * T) * (long long)F;
-    const float* Mr = a.mask + (room * K * T) * (long long)F;
-    // loader lane: LDS position it = tid + r * NT  <->  node lk, bin lbin, granule lp = lp' ^ swz(lbin); bins beyond F - 1 fetch (and
-    // later re-write) bin F - 1: every load and store is issued by every lane, the counts the waits rely on are exact
-    unsigned lxo[NL];
-    int lwt[NL], lzs[NL], lzo[NL];                      // taps in wt (c32 units), z slot in zs (-1: not this lane's), z offset in the room's z block
+template <int M, int K, int SUB, bool IS_A>
+__device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M, K, SUB>& sh) {
+    using Gm = RoomGeomS<M, K, SUB>;
+    constexpr int KR = Gm::KR, P = Gm::P, NP = Gm::NP, NB = Gm::NB, NA = Gm::NA, WA = Gm::WA, NT = Gm::NT, MH = Gm::MH;
+    constexpr int NROW = Gm::NROW, NITEMS = Gm::NITEMS, NL = Gm::NL, D = DISCO_ROOM_DEPTH, BPR = Gm::BPR, LH = Gm::LH;
+    constexpr int LOGM = M == 8 ? 3 : 2;
+    static_assert(D == 6, "two groups per iteration, two iterations ahead");
+    static_assert(M == 8 || M == 4, "byte offsets of z are derived from those of X by a shift");
+    const int T = a.T, F = a.F;
+    const unsigned FM8 = (unsigned)(F * M * 8);
+    const int tid = threadIdx.x, wid = wave_id(), lane = tid & 63;
+    const int bin = lane & (NB - 1), sub = (lane / NB) & 1, sc = lane / (2 * NB);
+    // An item is (room, tile of NB bins), all T frames: item I = room * tiles + tile.  (Frame chunks across workgroups are not needed
+    // here: SUB sub-chunks live inside the workgroup, and rooms x tiles fills the chip for every batch but toy ones.)
+    const int n_items = (int)(a.R * a.tiles);
+    const int J = (T + 2 * SUB - 1) / (2 * SUB);         // iterations per item: two groups of SUB frames each
+
+    // ---- loader lane: LDS position it = tid + r * NT  <->  sub-chunk lsc, node lk, bin lbin, granule lp = lp' ^ swz(lbin, lsc).
+    // Bins beyond F - 1 fetch (and later re-write) bin F - 1, frames beyond T - 1 frame T - 1: every load and store is issued by every
+    // lane of a whole wave, and what the surplus lanes write is the value that is there already.
+    // Per round three registers: lxa = byte offset of the granule inside its room for bin 0 of the tile and frame 0 of the group
+    // ((node, granule) part), lpk = lbin | lsc << 8 | (lp' == 0) << 16, lwt = the lane's tap granule in wt.
+    unsigned lxa[NL];
+    int lpk[NL], lwt[NL];
     bool lact[NL];
-    int nload = 0;
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
         const int it = tid + r * NT;
         lact[r] = wid * 64 + r * NT < NITEMS;          // whole waves: a scalar condition
-        nload += lact[r] ? 1 : 0;
         const int it_ = lact[r] ? it : 0;
-        const int lk = it_ / (NB * MH), rem = it_ % (NB * MH), lbin = rem / MH, lp = (rem % MH) ^ ((lbin / BPR) % MH);
-        const int lf = min(f0 + lbin, F - 1);
-        lxo[r] = (unsigned)((((lk * T) * F + lf) * M + 2 * lp) * 8);           // bytes; + t * F * M * 8
-        lwt[r] = (lk * NB + lbin) * M + 2 * lp;
-        lzs[r] = (rem % MH == 0) ? lk * NB + lbin : -1;
-        lzo[r] = (lk * T) * F + lf;                                              // + t * F; bins beyond F - 1 repeat bin F - 1's value
-        if (lact[r]) {
-            const float4 wq = *reinterpret_cast<const float4*>(a.w + ((room * K + lk) * F + lf) * (long long)M + 2 * lp);
-            *reinterpret_cast<float4*>(&sh.wt[0][0][0] + (lk * NB + lbin) * M + 2 * lp) = wq;
-        }
+        const int lsc = it_ / NROW, rem = it_ % NROW, lk = rem / (NB * MH), lbin = (rem / MH) % NB, lpp = rem % MH;
+        const int lp = lpp ^ ((lbin / BPR + lsc) % MH);
+        lxa[r] = (unsigned)(((lk * T) * F * M + 2 * lp) * 8);
+        lpk[r] = lbin | lsc << 8 | (lpp == 0 ? 1 << 16 : 0);
+        lwt[r] = (lk * NB + lbin) * MH + (lp ^ ((lbin / BPR) % MH));
     }
-    const bool mact = wid * 64 < K * NB;               // whole waves
-    nload += mact ? 1 : 0;
-    const unsigned mo = (unsigned)((((mact ? tid / NB : 0) * T) * F + min(f0 + tid % NB, F - 1)) * 4);
+    const bool mact = wid < Gm::NMW;                   // wave w fetches mask row w of a group: value (msc, mk, mb) = tid
+    const unsigned mxa = (unsigned)((((tid / NB) % K) * T) * F * 4);
 
-    auto issue = [&](int t, int slot_) {
-        t = t < t1 ? t : t1 - 1;
+    // group u of the item (room, f0) into ring slot `slot_`
+    auto issue = [&](int room, int f0, int u, int slot_) {
+        const int tb = u * SUB, tbc = tb < T ? tb : T - 1, nv1 = T - 1 - tbc;         // sub-chunks beyond nv1 repeat frame T - 1
+        const int bmax = F - 1 - f0;                                                  // bins beyond bmax repeat bin F - 1
+        const c32* gx = a.X + (((long long)room * K * T + tbc) * F + f0) * M;
 #pragma unroll
         for (int r = 0; r < NL; ++r)
-            if (lact[r]) lds_dma16(Xr + (long long)t * F * M, lxo[r], &sh.xs[slot_][wid * 64 + r * NT], lane);       // the frame's base is scalar
-        if (mact) lds_dma4(Mr + (long long)t * F, mo, &sh.ms[slot_][wid * 64], lane);
+            if (lact[r]) {
+                const unsigned off = lxa[r] + (unsigned)min(lpk[r] & 255, bmax) * (unsigned)(M * 8) + (unsigned)min((lpk[r] >> 8) & 255, nv1) * FM8;
+                lds_dma16(gx, off, &sh.xs[slot_][wid * 64 + r * NT], lane);
+            }
+        if (mact) {
+            const float* gm = a.mask + ((long long)room * K * T + tbc) * F + f0;
+            const unsigned off = mxa + (unsigned)min(tid % NB, bmax) * 4u + (unsigned)min(tid / (K * NB), nv1) * (unsigned)(F * 4);
+            lds_dma4(gm, off, &sh.ms[slot_][wid][0], lane);
+        }
     };
-    // z(t) = w^H x of every (node, bin) of the tile from ring slot `slot_`: a lane's own granule and taps, then the MH lanes of the bin
-    c32 zreg[NL];                                       // z of the frame just formed, on its way to HBM (stored after the counted wait)
-    auto form_z = [&](int t, int slot_) {
+    // the item's step-1 filters: tap granules at positions [0, NROW) of the item order (sub-chunk 0's swizzle), whole waves
+    auto issue_taps = [&](int room, int f0, int buf) {
+        const c32* gw = a.w + ((long long)room * K * F + f0) * M;
+        const int bmax = F - 1 - f0;
+        int tid_ = tid;                                  // opaque: the offsets are formed here, once per item, not carried through the loop
+#if defined(__clang__)
+        asm volatile("" : "+v"(tid_));
+#endif
+#pragma unroll
+        for (int r = 0; r < (Gm::NTAPP + NT - 1) / NT; ++r)
+            if (wid * 64 + r * NT < Gm::NTAPP) {
+                const int tit = min(tid_ + r * NT, NROW - 1), tk = tit / (NB * MH), tbin = (tit / MH) % NB, tp = (tit % MH) ^ ((tbin / BPR) % MH);
+                lds_dma16(gw, (unsigned)(((tk * F + min(tbin, bmax)) * M + 2 * tp) * 8), &sh.wt[buf][wid * 64 + r * NT], lane);
+            }
+    };
+    // z of group u = w^H x of every (frame, node, bin) of the group from ring slot `slot_`: a lane's own granule and taps, then the
+    // MH lanes of the bin; published in zs[zb] and stored
+    auto form_z = [&](int room, int f0, int u, int slot_, int zb, int buf) {
+        const int tb = u * SUB, tbc = tb < T ? tb : T - 1, nv1 = T - 1 - tbc;
+        const int bmax = F - 1 - f0;
+        char* gz = reinterpret_cast<char*>(a.z + ((long long)room * K * T + tbc) * F + f0);
 #pragma unroll
         for (int r = 0; r < NL; ++r) {
             if (lact[r]) {
                 const float4 q = sh.xs[slot_][tid + r * NT];
-                const float4 wq = *reinterpret_cast<const float4*>(&sh.wt[0][0][0] + lwt[r]);
+                const float4 wq = sh.wt[buf][lwt[r]];
                 c32 p = cfma_conj(make_float2(wq.x, wq.y), make_float2(q.x, q.y), make_float2(0.f, 0.f));
                 p = cfma_conj(make_float2(wq.z, wq.w), make_float2(q.z, q.w), p);
                 static_assert(MH == 2 || MH == 4, "the lanes of a bin are (part of) a quad");
@@ -406,29 +468,26 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
                     p.x = quad_xor_add<2>(p.x);
                     p.y = quad_xor_add<2>(p.y);
                 }
-                if (lzs[r] >= 0) (&sh.zs[t & (2 * DISCO_ROOM_FPB - 1)][0][0])[lzs[r]] = p;
-                zreg[r] = p;
+                if (lpk[r] >> 16) {
+                    const int lbin = lpk[r] & 255, lsc = (lpk[r] >> 8) & 255;
+                    // the node's place: lxa = (lk T F M + 2 lp) 8 with 2 lp < M  =>  (lxa >> log2 M) & ~7 = lk T F 8 (bytes of z), and
+                    // lwt / (NB MH) = lk (the z rows of a sub-chunk are padded to K + 1)
+                    (&sh.zs[zb][0][0][0])[(lsc * (K + 1) + lwt[r] / (NB * MH)) * NB + lbin] = p;
+                    *reinterpret_cast<c32*>(gz + ((lxa[r] >> LOGM) & ~7u) + (unsigned)((min(lbin, bmax) + min(lsc, nv1) * F) * 8)) = p;
+                }
             }
         }
     };
-    auto store_z = [&](int t) {
-#pragma unroll
-        for (int r = 0; r < NL; ++r)
-            if (lact[r] && lzs[r] >= 0) Zr[lzo[r] + t * F] = zreg[r];
-    };
 
     // ---- the lane's slot
-    // slot = SPW * (wave within its role) + sub.  A: k = slot / NA, h = slot % NA; B: k = slot.  kw = the wave's first node (a
-    // SCALAR), dk = k - kw in {0, 1} (always 0 when the two halves of a wave share a node, NA even): the remote row jj of a lane
-    // is node jj + (jj >= kw + dk), which differs between the halves only for jj == kw -- every other LDS offset of a remote
+    // slot = 2 * (wave within its role) + sub.  A: k = slot / NA, h = slot % NA; B: k = slot.  kw = the wave's first node (a
+    // SCALAR), dk = k - kw in {0, 1} (always 0 when the two slots of a wave share a node, NA even): the remote row jj of a lane
+    // is node jj + (jj >= kw + dk), which differs between the slots only for jj == kw -- every other LDS offset of a remote
     // row is a scalar instead of a per-lane select.
-    // With SPW slots per wave: slot = SPW * (wave within its role) + sub; the wave's nodes are kw ... kw + DKMAX and only the remote
-    // rows jj in [kw, kw + DKMAX) take a per-lane select.
     constexpr bool is_a = IS_A;
-    constexpr int SPW = Gm::SPW;
-    constexpr int DKMAX = IS_A ? (SPW - 1) / NA : SPW - 1;
+    constexpr int DKMAX = IS_A ? 1 / NA : 1;
     const int wr = is_a ? wid : wid - WA;
-    const int kw = is_a ? (SPW * wr) / NA : SPW * wr;
+    const int kw = is_a ? (2 * wr) / NA : 2 * wr;
     const int dk = is_a ? sub / NA : sub;
     const int k = kw + dk;
     const int h = is_a ? sub % NA : 0;
@@ -437,22 +496,24 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         if (DKMAX > 0 && jj >= kw && jj < kw + DKMAX) j = jj + (jj >= k ? 1 : 0);
         return j;
     };
-    const int swz = (bin / BPR) % MH;
+    const int swz = (bin / BPR + sc) % MH;
+    const int fim = (sc * K + k) * NB + bin;             // the lane's (sub-chunk, node, bin) in the item order of a group
     constexpr int NACC = IS_A ? 4 * KR : KR * (KR + 1) / 2;
     c32 acc_s[NACC], acc_n[NACC];
 #pragma unroll
     for (int q = 0; q < NACC; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
 
-    auto fold = [&](int t, int slot_) {
-        const float mkv = sh.ms[slot_][k * NB + bin];
-        const float m = live ? mkv : 0.f, mc = live ? 1.f - mkv : 0.f;
+    auto fold = [&](int f0, int u, int slot_, int zb) {
+        const float mkv = sh.ms[slot_][fim / 64][fim % 64];
+        const bool ok = f0 + bin < F && u * SUB + sc < T;
+        const float m = ok ? mkv : 0.f, mc = ok ? 1.f - mkv : 0.f;
         const float wa = m * m, wb = mc * mc;
-        const c32(*zs)[NB] = sh.zs[t & (2 * DISCO_ROOM_FPB - 1)];
+        const c32(*zs)[NB] = sh.zs[zb][sc];
         if constexpr (is_a) {
             c32 x[4];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const float4 q = sh.xs[slot_][(k * NB + bin) * MH + ((2 * h + p) ^ swz)];
+                const float4 q = sh.xs[slot_][fim * MH + ((2 * h + p) ^ swz)];
                 x[2 * p] = make_float2(q.x, q.y);
                 x[2 * p + 1] = make_float2(q.z, q.w);
             }
@@ -478,88 +539,129 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRing<M, 
         }
     };
 
-    if constexpr (DISCO_ROOM_FPB == 2) {
-        // Two frames per barrier: at the top of an iteration z(t), z(t + 1) are published and frames t + 2, t + 3 are in LDS; the
-        // iteration issues t + 4, t + 5 (into the slots of t - 2, t - 1), forms and stores z(t + 2), z(t + 3), folds t and t + 1 and
-        // waits for everything it issued.  Half the barriers, loop overhead and waits per frame; a load has two form_z + two folds to land.
+    // The SUB partial sums of every entry meet inside the wave: lane bit 5, then bit 4, by swap-and-add (every level leaves a lane
+    // half of its entries: the upper half's totals go to the lanes with the bit set), a third sub-chunk bit (SUB = 8, lane bit 3) by a plain
+    // add.  A lane then stores whole 16-byte entries -- for A slots one row of KR contiguous ones -- and clears its sums.
+    // Entries are numbered q = i KR + jj (A: rows 4 h + i against the remote columns) / the upper triangle of the remote block
+    // row by row (B): in both cases consecutive q of a row are consecutive in the packed triangle, and for B so is the whole run.
+    auto finish = [&](int room, int f0) {
+        constexpr int NACCP = (NACC + (1 << LH) - 1) >> LH << LH, EPL = NACCP >> LH;
+        c32 es[NACCP], en[NACCP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue(t0 + i, i);
-        vm_wait(0);
-        __syncthreads();                                // frames t0 ... t0 + 3 and the taps are in place
-        form_z(t0, 0);
-        store_z(t0);
-        if (t0 + 1 < t1) {
-            form_z(t0 + 1, 1);
-            store_z(t0 + 1);
+        for (int q = 0; q < NACCP; ++q) {
+            es[q] = q < NACC ? acc_s[q] : make_float2(0.f, 0.f);
+            en[q] = q < NACC ? acc_n[q] : make_float2(0.f, 0.f);
         }
-        __syncthreads();
-        int s0 = 0;
-        for (int t = t0; t < t1; t += 2) {
-            issue(t + 4, (s0 + 4) % D);
-            issue(t + 5, (s0 + 5) % D);
-            if (t + 2 < t1) {
-                form_z(t + 2, (s0 + 2) % D);
-                store_z(t + 2);
+        if constexpr (LH >= 1) room_halve<32, NACCP>(es, en, lane);
+        if constexpr (LH >= 2) room_halve<16, NACCP / 2>(es, en, lane);
+        if constexpr (SUB == 8) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                es[e].x += __shfl_xor(es[e].x, 8);
+                es[e].y += __shfl_xor(es[e].y, 8);
+                en[e].x += __shfl_xor(en[e].x, 8);
+                en[e].y += __shfl_xor(en[e].y, 8);
             }
-            if (t + 3 < t1) {
-                form_z(t + 3, (s0 + 3) % D);
-                store_z(t + 3);
-            }
-            fold(t, s0);
-            if (t + 1 < t1) fold(t + 1, (s0 + 1) % D);
-            vm_wait(0);
-            __syncthreads();
-            s0 = (s0 + 2) % D;
         }
-    } else {
-    constexpr int AH = DISCO_ROOM_AHEAD;                // frames a load is issued ahead of its fold
+        // Where the lane's entries go is recomputed here from an OPAQUE copy of the thread index: derived once before the loop, these
+        // values would be carried through it in registers the fold needs (hipcc hoists them out and then spills them).
+        int tid_ = tid;
+#if defined(__clang__)
+        asm volatile("" : "+v"(tid_));
+#endif
+        const int lane_ = tid_ & 63, bin_ = lane_ & (NB - 1), sub_ = (lane_ / NB) & 1;
+        const int k_ = is_a ? (2 * wr + sub_) / NA : 2 * wr + sub_, h_ = is_a ? sub_ % NA : 0;
+        const int g = LH == 2 ? ((lane_ >> 5) & 1) * 2 + ((lane_ >> 4) & 1) : (LH == 1 ? (lane_ >> 5) & 1 : 0);
+        const bool writer = f0 + bin_ < F && (SUB != 8 || (lane_ & 8) == 0);
+        if (writer) {
+            float4* o = a.part + (((long long)room * K + k_) * F + f0 + bin_) * (long long)NP;
 #pragma unroll
-    for (int i = 0; i < AH; ++i) issue(t0 + i, i);
-    vm_wait((AH - 2) * nload);                          // frames t0 and t0 + 1 have landed (this wave's part)
-    __syncthreads();                                    // ... and everybody else's; the taps are in place
-    form_z(t0, 0);
-    store_z(t0);
-    __syncthreads();
-    int s0 = 0;                                         // ring slot of frame t
-    for (int t = t0; t < t1; ++t) {
-        issue(t + AH, (s0 + AH) % D);                   // the slot frame t - 1 was folded from (D = AH + 1)
-        if (t + 1 < t1) form_z(t + 1, (s0 + 1) % D);    // frame t + 1 landed (and was published) an iteration ago; into the OTHER z buffer
-        fold(t, s0);
-        vm_wait((AH - 2) * nload);                      // only the last AH - 2 issues may still be in flight: frame t + 2 is in LDS (the z stores
-                                                        // between them are younger than frame t + 2 either way: whether or not stores retire in
-                                                        // order with loads, AH - 2 issues' worth of outstanding operations cannot include it)
-        if (t + 1 < t1) store_z(t + 1);                 // after the counted wait: the stores never stand between an issue and its wait
-        __syncthreads();
-        s0 = (s0 + 1) % D;
-    }
-    }
-    vm_wait(0);                                         // no LDS-DMA may outlive the workgroup's LDS allocation
-    if (live) {
-        float4* o = a.part + ((((room * K + k) * a.chunks + c) * F) + f0 + bin) * (long long)NP;
-        if constexpr (is_a) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = 0; jj < KR; ++jj) {
-                    const int q = i * KR + jj;
-                    o[tri_index<P>(4 * h + i, M + jj)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+            for (int e = 0; e < EPL; ++e) {
+                const int q = g * EPL + e;
+                if constexpr (is_a) {
+                    const int r = 4 * h_ + q / KR, jj = q % KR;           // row of the node's own mic, remote column
+                    o[r * P - (r * (r - 1)) / 2 + (M - r) + jj] = make_float4(es[e].x, es[e].y, en[e].x, en[e].y);
+                } else {
+                    if (q < NACC) o[tri_index<P>(M, M) + q] = make_float4(es[e].x, es[e].y, en[e].x, en[e].y);
                 }
-        } else {
-            int q = 0;
-#pragma unroll
-            for (int i = 0; i < KR; ++i)
-#pragma unroll
-                for (int j = i; j < KR; ++j, ++q)
-                    o[tri_index<P>(M + i, M + j)] = make_float4(acc_s[q].x, acc_s[q].y, acc_n[q].x, acc_n[q].y);
+            }
         }
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc_s[q] = acc_n[q] = make_float2(0.f, 0.f);
+    };
+
+    // ---- the pipeline over this workgroup's items blockIdx.x, + gridDim.x, ...  Three positions, one iteration apart: (Ii, ji) is
+    // issued, (If, jf) formed, (Id, jd) folded; room / first bin of each are cached.  All of it is wave-uniform.
+    int Ii = blockIdx.x, ji = 0, ni = 0;                // item, iteration inside it, ordinal of the item (its tap buffer is n & 1)
+    if (Ii >= n_items) return;                          // (the launcher never starts more workgroups than items)
+    int ri = Ii / a.tiles, fi = (Ii % a.tiles) * NB;
+    int rf = ri, ff = fi, jf = 0, nf = 0;
+    int rd = ri, fd = fi, jd = 0;
+    bool vi = true, vf = true;                          // position still inside the workgroup's items
+    auto advance_issue = [&]() {
+        if (++ji == J) {
+            Ii += gridDim.x;
+            vi = Ii < n_items;
+            if (vi) {
+                ri = Ii / a.tiles;
+                fi = (Ii % a.tiles) * NB;
+                ji = 0;
+                ++ni;
+            }
+        }
+    };
+    // prologue: the first item's taps, the first two iterations' groups
+    issue_taps(ri, fi, 0);
+    issue(ri, fi, 0, 0);
+    issue(ri, fi, 1, 1);
+    advance_issue();
+    rf = ri, ff = fi, jf = ji, nf = ni, vf = vi;        // the form position of the first loop iteration is what is issued second
+    if (vi) {
+        if (ji == 0) issue_taps(ri, fi, ni & 1);
+        issue(ri, fi, 2 * ji, 2);
+        issue(ri, fi, 2 * ji + 1, 3);
+        advance_issue();
     }
+    vm_wait_all();
+    __syncthreads();                                    // groups 0 ... 3 and the taps are in place
+    form_z(rd, fd, 0, 0, 0, 0);
+    form_z(rd, fd, 1, 1, 1, 0);
+    __syncthreads();
+    int s0 = 0, zb0 = 0;                                // ring slot / z buffer of the fold position's first group
+    int rp = rd, fp = fd;                               // the item whose last groups were folded in the previous iteration (pending)
+    bool pending = false;
+    while (true) {
+        if (vi) {
+            if (ji == 0) issue_taps(ri, fi, ni & 1);    // (the form position left that buffer's item an iteration ago)
+            issue(ri, fi, 2 * ji, (s0 + 4) % D);
+            issue(ri, fi, 2 * ji + 1, (s0 + 5) % D);
+        }
+        if (pending) finish(rp, fp);
+        if (vf) {
+            form_z(rf, ff, 2 * jf, (s0 + 2) % D, zb0 ^ 2, nf & 1);
+            form_z(rf, ff, 2 * jf + 1, (s0 + 3) % D, (zb0 ^ 2) + 1, nf & 1);
+        }
+        fold(fd, 2 * jd, s0, zb0);
+        fold(fd, 2 * jd + 1, (s0 + 1) % D, zb0 + 1);
+        pending = jd == J - 1;
+        rp = rd, fp = fd;
+        vm_wait_all();
+        __syncthreads();
+        if (!vf) break;                                 // the fold position was this workgroup's last iteration
+        s0 = (s0 + 2) % D;
+        zb0 ^= 2;
+        rd = rf, fd = ff, jd = jf;
+        rf = ri, ff = fi, jf = ji, nf = ni, vf = vi;
+        if (vi) advance_issue();
+    }
+    finish(rp, fp);
 }
 
-template <int M, int K, int NB_>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K, NB_>::NT), DISCO_ROOM_WPE) void k_room_cov_dma(RoomArgs a) {
-    __shared__ RoomRing<M, K, NB_> sh;
-    if (wave_id() < RoomGeom<M, K, NB_>::WA) room_cov_dma_run<M, K, NB_, true>(a, sh);
-    else room_cov_dma_run<M, K, NB_, false>(a, sh);
+template <int M, int K, int SUB>
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeomS<M, K, SUB>::NT), DISCO_ROOM_WPE) void k_room_cov_dma(RoomArgs a) {
+    __shared__ RoomRingS<M, K, SUB> sh;
+    if (wave_id() < RoomGeomS<M, K, SUB>::WA) room_cov_dma_run<M, K, SUB, true>(a, sh);
+    else room_cov_dma_run<M, K, SUB, false>(a, sh);
 }
 
 }  // namespace disco

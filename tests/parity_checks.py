@@ -902,10 +902,10 @@ def check_no_allocation_in_compute_calls(make_engine, K=3, M=2, L=6000, n_fft=51
     return own
 
 
-def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tuning=None, tol=1e-4, tile16=None):
+def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tuning=None, tol=1e-4, subs=(4,)):
     """k_room_cov (csrc/k_room.h: z of every node + the step-2 statistics of every node of a room from ONE pass over X, wide
     shapes P = M + K - 1 > 8) against (a) the route it replaces -- disco_apply + the split covariance kernels, selected with
-    disco_set_option("room_cov", 0) -- and (b) the float64 oracle; both whole-path entry points.  The three routes run on THREE
+    disco_set_option("room_cov", 0) -- and (b) the float64 oracle; both whole-path entry points.  The routes run on SEVERAL
     contexts alive at the same time (options are per context, not process-global), and the stage names say which route ran."""
     from disco_amd import synth
     y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
@@ -914,22 +914,21 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
         eng.set_tuning(*tuning)
     m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F)
     res = {}
-    # '1': the default (frames through the LDS-DMA ring), 'reg': the register-staged variant, '0': the staged route,
-    # 't16': the ring on 16-bin tiles (option "room_tile16"; the shapes with K a multiple of 4 -- elsewhere the option changes nothing)
+    # '1': the default (persistent pass on the LDS-DMA ring, 8 time sub-chunks per workgroup), 'reg': the register-staged kernel,
+    # '0': the staged route, 's<n>': the persistent pass with n sub-chunks (option "room_sub": 32 / n bins per workgroup)
     engines = {}
-    if tile16 is None:
-        tile16 = K % 4 == 0               # (the emulated 8 x 8 case leaves it out: a fourth engine of that size doubles the suite's longest test)
-    modes = (('1', 1, 1, 0), ('reg', 1, 0, 0), ('0', 0, 1, 0)) + ((('t16', 1, 1, 1),) if tile16 and K % 4 == 0 else ())
-    for mode, cov, dma, t16 in modes:
+    modes = (('1', 1, 1, 8), ('reg', 1, 0, 8), ('0', 0, 1, 8)) + tuple((f's{n_}', 1, 1, n_) for n_ in subs)
+    for mode, cov, dma, nsub in modes:
         e = eng if mode == '1' else make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
         if mode != '1' and tuning is not None:
             e.set_tuning(*tuning)
         e.set_option('room_cov', cov)
         e.set_option('room_dma', dma)
-        e.set_option('room_tile16', t16)
+        e.set_option('room_sub', nsub)
         engines[mode] = e
     m_np = m.numpy()
-    want_stage = {'1': 'room_cov2', 'reg': 'room_cov2_reg', '0': 'cov2', 't16': 'room_cov2'}
+    want_stage = {'1': 'room_cov2', 'reg': 'room_cov2_reg', '0': 'cov2'}
+    want_stage.update({f's{n_}': 'room_cov2' for n_ in subs})
     for mode, e in engines.items():
         mm = m if e is eng else m_np
         e.stage_timing(True)
