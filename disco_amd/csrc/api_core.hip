@@ -317,6 +317,14 @@ extern "C" int disco_set_option(disco_ctx* ctx, const char* key, int value) {
     if (i == DISCO_OPT_OVERLAP_SOLVES) return disco_host::ensure_halves(ctx);     // (may allocate: this is not a compute call)
     for (int h = 0; h < 2; ++h)
         if (ctx->half[h]) ctx->half[h]->opt[i] = value;
+    // a route may ask for larger partial-sum blocks than the one sized so far (e.g. "room_dma" 0: chunked sums): size them HERE, so
+    // that the next compute call still allocates nothing (this is not a compute call)
+    if (!(ctx->cfg.flags & DISCO_FLAG_LAZY_SCRATCH)) {
+        int rc = disco_host::reserve_scratch(ctx);
+        for (int h = 0; h < 2 && !rc; ++h)
+            if (ctx->half[h] && (rc = disco_host::reserve_scratch(ctx->half[h]))) return fail(ctx, rc, ctx->half[h]->err);
+        return rc;
+    }
     return 0;
 }
 

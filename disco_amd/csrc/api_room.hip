@@ -21,10 +21,10 @@ bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     return (long long)K * ctx->T * ctx->F * M <= 0x0fffffffLL;                               // 32-bit BYTE offsets inside a room (8 B per element)
 }
 
-// time sub-chunks per workgroup of the persistent pass (option "room_sub": 1, 2, 4 or 8; anything else: 8)
+// time sub-chunks per workgroup of the persistent pass (option "room_sub": 2, 4 or 8; anything else: 8)
 static int room_sub(const disco_ctx* ctx) {
     const int s = ctx->opt[DISCO_OPT_ROOM_SUB];
-    return (s == 1 || s == 2 || s == 4) ? s : 8;
+    return (s == 2 || s == 4) ? s : 8;
 }
 
 // The persistent pass forms ONE partial block per node: its workgroups walk items (room, tile of 32 / SUB bins), the time axis is
@@ -60,7 +60,7 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
         if (items > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
         const unsigned nwg = (unsigned)std::min<long long>(items, ctx->n_cu);               // one persistent workgroup per CU
         const hipStream_t st = (hipStream_t)s;
-        const bool ok = sub == 1 ? launch_room_s1(M, K, nwg, st, a) : sub == 2 ? launch_room_s2(M, K, nwg, st, a)
+        const bool ok = sub == 2 ? launch_room_s2(M, K, nwg, st, a)
                       : sub == 4 ? launch_room_s4(M, K, nwg, st, a) : launch_room_s8(M, K, nwg, st, a);
         if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: shape not instantiated");
     } else {

@@ -278,7 +278,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 
 template <int M, int K, int SUB_>
 struct RoomGeomS {
-    static_assert(SUB_ == 1 || SUB_ == 2 || SUB_ == 4 || SUB_ == 8, "sub-chunks share a wave");
+    static_assert(SUB_ == 2 || SUB_ == 4 || SUB_ == 8, "sub-chunks share a wave");
     static_assert(M % 4 == 0 && K % 2 == 0 && K >= 2 && K <= 8, "4-mic slots, two slots per wave, <= 28 pairs per slot");
     static constexpr int SUB = SUB_, NB = 32 / SUB_;    // frames per group, bins per workgroup
     static constexpr int KR = K - 1, P = M + KR, NP = P * (P + 1) / 2;

@@ -1,0 +1,98 @@
+"""C5 (200 rooms x 8 x 8, 1024-pt, 2 iterations) on ONE batch under several kernel routes: ms per step, stage times, and the error of sampled
+rooms against the float64 oracle (computed once, in worker processes, while the GPU runs the variants).  Test / measurement tooling.
+Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [variants=room_sub:cov1_sub:cov_chunks,...] [sample=0,100,199]"""
+import json
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+
+
+def oracle_room(args):
+    import numpy as np
+    yr, sr, nr, n_fft, iters = args
+    from oracle import stft_oracle as so, tango_oracle as to
+    s = np.zeros_like(yr); n = np.zeros_like(yr)
+    s[:, 0] = sr; n[:, 0] = nr
+    o = to.offline_tango_vec(yr, s, n, vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh', extra_iters=iters - 1)
+    return [so.istft(o['yf'][k], yr.shape[-1], n_fft, n_fft // 2, work_dtype=np.float64) for k in range(yr.shape[0])]
+
+
+def main():
+    import numpy as np
+    import torch
+    from disco_amd import synth
+    from disco_amd.engine import Engine
+    out_path = sys.argv[1]
+    kv = dict(a.split('=') for a in sys.argv[2:])
+    R = int(kv.get('rooms', 200))
+    K, M, N, L, iters = int(kv.get('nodes', 8)), int(kv.get('mics', 8)), int(kv.get('n_fft', 1024)), 160000, int(kv.get('iters', 2))
+    variants = [tuple(int(x) for x in v.split(':')) for v in kv.get('variants', '8:4:0,4:4:0,2:4:0,1:4:0,8:1:0,8:8:0').split(',')]
+    sample = [int(x) for x in kv.get('sample', '0,100,199').split(',') if int(x) < R]
+    steps = int(kv.get('steps', 8))
+    dev = torch.device('cuda:0')
+    eng = Engine(rooms=R, nodes=K, mics=M, length=L, n_fft=N, device=0)
+    y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, L, first_room=0, device=dev, ref_only_sn=True)
+    pool = ProcessPoolExecutor(max_workers=len(sample))
+    futs = {r: pool.submit(oracle_room, (y[r].cpu().numpy(), s_ref[r].cpu().numpy(), n_ref[r].cpu().numpy(), N, iters)) for r in sample}
+    T, F = eng.T, eng.F
+    mask = torch.empty((R, K, T, F), dtype=torch.float32, device=dev)
+    out = torch.empty((R, K, L), dtype=torch.float32, device=dev)
+    ws = torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
+    lib = eng.lib
+
+    def step():
+        eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), R * K, mask.data_ptr(), None))
+        if iters > 1:
+            eng._chk(lib.disco_tango_enhance_iterated(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), iters, out.data_ptr(), None, None,
+                                                      ws.data_ptr(), ws.numel(), None))
+        else:
+            eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
+    res = {'rooms': R, 'shape': [K, M, N], 'iters': iters, 'steps': steps, 'variants': {}}
+    got = {}
+    for rs, cs, ch in variants:
+        name = f'room_sub={rs},cov1_sub={cs},cov_chunks={ch}'
+        eng.set_option('room_sub', rs)
+        eng.set_option('cov1_sub', cs)
+        eng.set_tuning(0, ch, 0, 0)
+        if eng.workspace_bytes() > ws.numel():
+            ws = torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        ov = eng.get_option('overlap_solves')
+        eng.set_option('overlap_solves', 0)
+        step(); torch.cuda.synchronize()
+        reps = []
+        for _ in range(3):
+            eng.stage_timing(True)
+            step()
+            reps.append(eng.stage_report())
+        eng.stage_timing(False)
+        eng.set_option('overlap_solves', ov)
+        stages = {nm: round(sorted(r_[nm][0] for r_ in reps)[1], 3) for nm in reps[0]}
+        step(); torch.cuda.synchronize()
+        got[name] = {r: out[r].cpu().numpy() for r in sample}
+        res['variants'][name] = {'ms_per_step': round(ms, 3), 'stages_ms': stages}
+        print(name, round(ms, 3), stages, flush=True)
+        json.dump(res, open(out_path, 'w'), indent=1)
+    for r in sample:
+        ref = futs[r].result(timeout=1500)
+        for name in got:
+            e = max(float(np.linalg.norm(got[name][r][k] - ref[k]) / np.linalg.norm(ref[k])) for k in range(K))
+            res['variants'][name].setdefault('rel_err', {})[str(r)] = e
+        json.dump(res, open(out_path, 'w'), indent=1)
+    for name, v in res['variants'].items():
+        print(name, v['ms_per_step'], {k_: '%.2e' % e for k_, e in v['rel_err'].items()}, flush=True)
+
+
+if __name__ == '__main__':
+    main()
