@@ -16,9 +16,12 @@ OBJ = os.path.join(HERE, 'lib', 'obj')
 # -fno-slp-vectorize: hipcc's SLP pass fuses adjacent f32 ops into v_pk_*_f32, which issue slower than the scalar
 # pair on gfx950 (guide: "packed f32 VALU ... an anti-lever"); measured -0.9 ms on k_stft_cov, -0.6 ms on k_step2_cov_fused
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-fPIC']
-# kernels that count their vector-memory queue by hand (csrc/k_room.h): a compiler spill inside their loops would shift that
-# count -- a build in which one of them uses scratch is refused
-NO_SPILL = ('k_room_cov_dma', 'k_gevd_mwf_r1_dpp')
+# scratch (bytes per lane) a kernel may use; a build that exceeds it is refused.  k_gevd_mwf_r1_dpp: none (a spill between its inline-asm
+# DPP statements would break the hazard spacing the build checks).  k_room_cov_dma (csrc/k_room.h): its LDS-DMA loads are inline asm, but
+# every wait is a full `s_waitcnt vmcnt(0)` (round 4: no hand-counted queue depth any more), so a scratch access cannot break it; 168
+# registers at 3 waves / SIMD leave hipcc a few words short in the A-role loop of some shapes (the loader's per-lane constants: <= 5 reloads
+# per iteration) -- tolerated up to 64 bytes, anything larger means the accumulators went to scratch and is refused.
+SCRATCH_LIMIT = {'k_room_cov_dma': 64, 'k_gevd_mwf_r1_dpp': 0}
 # units whose kernels read other lanes' registers through DPP inside inline asm (csrc/dpp64.h): hipcc cannot see those reads, so
 # the two DPP hazards (a VALU write of the source within 2 wait states, an EXEC write within 5) are checked on the device
 # assembly of the unit (tools/check_dpp_hazards.py) and a build with a hazard is refused
@@ -112,10 +115,10 @@ def build_hip(force=False, verbose=True, jobs=None):
         if rc != 0:
             sys.stderr.write(remarks[-8000:])
             raise RuntimeError(f'hipcc failed ({rc}) on {obj}')
-        spilled = [k for part in NO_SPILL for k in scratch_users(remarks, part)]
+        spilled = [k for part, limit in SCRATCH_LIMIT.items() for k in scratch_users(remarks, part, limit)]
         if spilled:
             os.remove(obj)
-            raise RuntimeError(f'kernels that must not spill use scratch: {spilled}')
+            raise RuntimeError(f'kernels over their scratch allowance: {spilled}')
         objs.append(obj)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
     if verbose:
@@ -124,15 +127,16 @@ def build_hip(force=False, verbose=True, jobs=None):
     return OUT
 
 
-def scratch_users(remarks, name_part):
-    """Names of kernels containing `name_part` whose 'ScratchSize [bytes/lane]' remark is not 0."""
+def scratch_users(remarks, name_part, limit=0):
+    """Names (with the size) of kernels containing `name_part` whose 'ScratchSize [bytes/lane]' remark exceeds `limit`."""
     bad, cur = [], None
     for line in remarks.splitlines():
         if 'Function Name:' in line:
             cur = line.split('Function Name:')[1].split('[')[0].strip()
         elif 'ScratchSize [bytes/lane]:' in line and cur and name_part in cur:
-            if int(line.split('ScratchSize [bytes/lane]:')[1].split('[')[0].strip()) != 0:
-                bad.append(cur)
+            n = int(line.split('ScratchSize [bytes/lane]:')[1].split('[')[0].strip())
+            if n > limit:
+                bad.append(f'{cur} ({n} B)')
     return bad
 
 

@@ -65,9 +65,13 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
     const int chunks = cov_chunks(ctx);
     const long long G = (long long)c.rooms * ctx->Kl;
     const int NP = P * (P + 1) / 2;
-    const size_t need = (size_t)G * chunks * ctx->F * NP * sizeof(float4);
     const bool same = (Zs == Zn);
     const bool split = (KR == 0 || (P > 8 && same && mask_remote && (ctx->F - 1) % 64 == 0)) && cov_split_shape(M, KR);
+    // step-1 shapes of the split kernels (KR = 0, M >= 7): time sub-chunks across the lanes (option "cov1_sub": 4 or 8; anything else:
+    // lanes are bins only); every frame chunk then leaves a (hi, lo) PAIR of partial blocks (k_cov.h)
+    const int o_sub = ctx->opt[DISCO_OPT_COV1_SUB], sub = (split && KR == 0 && (o_sub == 4 || o_sub == 8)) ? o_sub : 1;
+    const int blocks = sub > 1 ? 2 * chunks : chunks;
+    const size_t need = (size_t)G * blocks * ctx->F * NP * sizeof(float4);
     skiploc = skiploc && split && KR > 0 && ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask;
     int rc = 0;
     rc = skiploc ? ensure_scratch2(ctx, need) : ensure_scratch(ctx, need);
@@ -90,8 +94,6 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
     const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
     bool launched = false;
     if (split) {                // 9 <= P <= 16, one vector for both statistics: one block of pairs per wave
-        // step-1 shapes (KR = 0): time sub-chunks across the lanes (option "cov1_sub": 4 or 8; anything else: lanes are bins only)
-        const int o = ctx->opt[DISCO_OPT_COV1_SUB], sub = (KR == 0 && (o == 4 || o == 8)) ? o : 1;
         const int tiles = (ctx->F - 1 + 64 / sub - 1) / (64 / sub);
         const long long nblk = G * (tiles + 1) * chunks;
         if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
@@ -123,15 +125,15 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_big<false>), dim3((unsigned)nblk), dim3(64 * CB_S), 0, (hipStream_t)s, a, M, KR);
     }
-    *chunks_out = chunks;
-    ctx->pending_chunks = chunks;
+    *chunks_out = blocks;
+    ctx->pending_chunks = blocks;
     ctx->pending_P = P;
     ctx->pending_skiploc = skiploc ? 1 : 0;
     if (!skiploc) {
         // `scratch` now holds THIS call's partial sums: step-1 ones (P == M, all nodes here) can be re-used by a step 2
         // on the same mask, anything else invalidates what k_stft_cov / an earlier step-1 call left
         ctx->loc_M = (KR == 0 && !sharded(ctx)) ? M : 0;
-        ctx->loc_chunks = chunks;
+        ctx->loc_chunks = blocks;
         ctx->loc_X = X;
         ctx->loc_mask = mask;
     }

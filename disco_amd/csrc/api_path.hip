@@ -155,7 +155,7 @@ int reserve_scratch(disco_ctx* ctx) {
     const size_t G = (size_t)c.rooms * ctx->Kl;
     const size_t P = (size_t)std::min(c.mics + c.nodes - 1, 16);
     const size_t NP = P * (P + 1) / 2;
-    int chunks = std::max(cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));
+    int chunks = std::max(2 * cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));        // (2 x: the (hi, lo) pairs of the sub-chunked kernels)
     if (c.mics <= 8) chunks = std::max(chunks, stft_cov_chunks(ctx, nullptr));
     if (c.mics + c.nodes - 1 > 8) chunks = std::max(chunks, room_chunks(ctx));
     const size_t need = G * (size_t)chunks * ctx->F * NP * sizeof(float4);

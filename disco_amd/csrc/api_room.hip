@@ -21,15 +21,21 @@ bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     return (long long)K * ctx->T * ctx->F * M <= 0x0fffffffLL;                               // 32-bit BYTE offsets inside a room (8 B per element)
 }
 
-// time sub-chunks per workgroup of the persistent pass (option "room_sub": 2, 4 or 8; anything else: 8)
+// time sub-chunks per workgroup of the persistent pass (option "room_sub": 4 or 8; anything else: 8)
 static int room_sub(const disco_ctx* ctx) {
     const int s = ctx->opt[DISCO_OPT_ROOM_SUB];
-    return (s == 2 || s == 4) ? s : 8;
+    return s == 4 ? 4 : 8;
 }
 
-// The persistent pass forms ONE partial block per node: its workgroups walk items (room, tile of 32 / SUB bins), the time axis is
-// split INSIDE the workgroup (SUB sub-chunks across the lanes).  The register-staged kernel keeps the chunked geometry.
-int room_chunks(const disco_ctx* ctx) { return ctx->opt[DISCO_OPT_ROOM_DMA] != 0 ? 1 : cov_chunks(ctx); }
+// Partial blocks per node of the persistent pass: its workgroups walk items (room, tile of 32 / SUB bins, all frames) and hand their
+// sums over NF times per item (option "room_flush"), each time as a (hi, lo) PAIR of blocks -- the float32 totals of the SUB sub-chunks
+// and what the additions between them rounded away.  The register-staged kernel keeps the chunked geometry.
+int room_chunks(const disco_ctx* ctx) {
+    if (ctx->opt[DISCO_OPT_ROOM_DMA] == 0) return cov_chunks(ctx);
+    const int J = (ctx->T + 2 * room_sub(ctx) - 1) / (2 * room_sub(ctx));            // iterations per item
+    const int nf = std::max(1, std::min(std::min(ctx->opt[DISCO_OPT_ROOM_FLUSH], 4), J));
+    return 2 * nf;
+}
 
 int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
                              int* chunks_out, disco_stream s) {
@@ -60,8 +66,7 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
         if (items > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
         const unsigned nwg = (unsigned)std::min<long long>(items, ctx->n_cu);               // one persistent workgroup per CU
         const hipStream_t st = (hipStream_t)s;
-        const bool ok = sub == 2 ? launch_room_s2(M, K, nwg, st, a)
-                      : sub == 4 ? launch_room_s4(M, K, nwg, st, a) : launch_room_s8(M, K, nwg, st, a);
+        const bool ok = sub == 4 ? launch_room_s4(M, K, nwg, st, a) : launch_room_s8(M, K, nwg, st, a);
         if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: shape not instantiated");
     } else {
         a.tiles = (ctx->F + 31) / 32;

@@ -35,7 +35,8 @@ enum {
     DISCO_OPT_OVERLAP_SOLVES,           // "overlap_solves": whole-path calls run the batch as two halves on two streams
     DISCO_OPT_SOLVE_F32,                // "solve_f32": float32 squarings + float64 Rayleigh-quotient finish in the group solver (default 0: all float64)
     DISCO_OPT_SOLVE_DPP,                // "solve_dpp": 9 <= P <= 16 solved in registers with DPP row broadcasts (k_solve_dpp.h; 0: the LDS group solver)
-    DISCO_OPT_ROOM_SUB,                 // "room_sub": time sub-chunks per workgroup of the persistent room pass (2, 4 or 8 -> 16, 8 or 4 bins per workgroup)
+    DISCO_OPT_ROOM_SUB,                 // "room_sub": time sub-chunks per workgroup of the persistent room pass (4 or 8 -> 8 or 4 bins per workgroup)
+    DISCO_OPT_ROOM_FLUSH,               // "room_flush": hand-overs of the sums per item of the persistent room pass (1 ... 4): 2 x that many partial blocks per node
     DISCO_OPT_COV1_SUB,                 // "cov1_sub": time sub-chunks across the lanes of the step-1 statistics of the wide shapes (M >= 7): 4 / 8, else 1
     DISCO_N_OPTIONS
 };

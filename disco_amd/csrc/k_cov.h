@@ -429,6 +429,19 @@ __device__ __forceinline__ void cov_split_store(float4* o, const c32* acc_s, con
     }
 }
 
+// hi <- fl(hi + hi'), lo <- lo + lo' + the rounding error of that addition (Knuth's two_sum), hi' / lo' = the values of lane ^ off
+__device__ __forceinline__ void cov_two_sum_xor(float& hi, float& lo, const int off) {
+    const float b = __shfl_xor(hi, off), lb = __shfl_xor(lo, off);
+    float s = hi + b;
+    const float bb = s - hi;
+    float e = (hi - (s - bb)) + (b - bb);
+#if defined(__clang__)
+    asm volatile("" : "+v"(s), "+v"(e));
+#endif
+    hi = s;
+    lo = (lo + lb) + e;
+}
+
 // S > 1: the tile is 64 / S bins wide and a wave's lanes are (sub-chunk sc, bin): lane (sc, b) folds frames t0 + sc, t0 + sc + S, ... of
 // the chunk -- S times shorter float32 sums per accumulator at the same register count (round 4: the step-1 statistics of the wide
 // shapes summed 157 frames each, and the 8 x 8 block they produce is the leading block of every step-2 pencil; cf. k_room.h) -- and
@@ -487,22 +500,45 @@ __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, in
             for (int i = 0; i < NY; ++i) uy[i] = ny[i];
             mcur = mnext;
         }
-        if (nyq || S > 1) {          // lanes hold partial sums over disjoint frames of the same bin: all 64 (Nyquist tile) or the S sub-chunks
+        if constexpr (S > 1) {
+            // lanes hold partial sums over disjoint frames of the same bin -- all 64 (Nyquist tile) or the S sub-chunks.  They meet through
+            // the lane crossbar by two_sum: the float32 total AND what its additions rounded away, stored as TWO partial blocks (2 c, 2 c + 1
+            // of 2 * chunks) which the solvers add in float64 (cf. k_room.h: a float32 rounding of the total alone costs the worst C5 room 4e-5)
             const int stop = nyq ? 1 : NBT;
+            c32 lo_s[NPAIR], lo_n[NPAIR];
 #pragma unroll
-            for (int q = 0; q < NPAIR; ++q)
+            for (int q = 0; q < NPAIR; ++q) {
+                lo_s[q] = lo_n[q] = make_float2(0.f, 0.f);
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) {
                     if (off < stop) break;
-                    acc_s[q].x += __shfl_xor(acc_s[q].x, off);
-                    acc_s[q].y += __shfl_xor(acc_s[q].y, off);
-                    acc_n[q].x += __shfl_xor(acc_n[q].x, off);
-                    acc_n[q].y += __shfl_xor(acc_n[q].y, off);
+                    cov_two_sum_xor(acc_s[q].x, lo_s[q].x, off);
+                    cov_two_sum_xor(acc_s[q].y, lo_s[q].y, off);
+                    cov_two_sum_xor(acc_n[q].x, lo_n[q].x, off);
+                    cov_two_sum_xor(acc_n[q].y, lo_n[q].y, off);
                 }
-        }
-        if (live && (nyq ? lane == 0 : lane < NBT)) {
-            float4* o = a.part + (((g * a.chunks + c) * F) + f) * (long long)NP;
-            cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
+            }
+            if (live && (nyq ? lane == 0 : lane < NBT)) {
+                float4* o = a.part + (((g * (2 * a.chunks) + 2 * c) * F) + f) * (long long)NP;
+                cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
+                cov_split_store<P, X0, Y0, TRI, NX, NY>(o + (long long)F * NP, lo_s, lo_n);
+            }
+        } else {
+            if (nyq) {          // lanes hold partial sums over disjoint frames of the same bin
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        acc_s[q].x += __shfl_xor(acc_s[q].x, off);
+                        acc_s[q].y += __shfl_xor(acc_s[q].y, off);
+                        acc_n[q].x += __shfl_xor(acc_n[q].x, off);
+                        acc_n[q].y += __shfl_xor(acc_n[q].y, off);
+                    }
+            }
+            if (live && (!nyq || lane == 0)) {
+                float4* o = a.part + (((g * a.chunks + c) * F) + f) * (long long)NP;
+                cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
+            }
         }
     }
 }

@@ -10,7 +10,6 @@ using namespace disco;
 // (M, K) shapes of the one-pass room covariance (wide shapes: P = M + K - 1 > 8)
 #define DISCO_FOR_ROOM(X_) X_(8, 8) X_(8, 6) X_(8, 4) X_(8, 2) X_(4, 8) X_(4, 6)
 
-bool launch_room_s2(int M, int K, unsigned nwg, hipStream_t st, const RoomArgs& a);
 bool launch_room_s4(int M, int K, unsigned nwg, hipStream_t st, const RoomArgs& a);
 bool launch_room_s8(int M, int K, unsigned nwg, hipStream_t st, const RoomArgs& a);
 
@@ -24,7 +23,6 @@ bool launch_room_s8(int M, int K, unsigned nwg, hipStream_t st, const RoomArgs& 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov_dma<M_, K_, SUB_>), dim3(nwg), dim3(RoomGeomS<M_, K_, SUB_>::NT), 0, st, a); \
         return true;                                                                                                        \
     }
-#define DISCO_ROOM_CASE_2(M_, K_) DISCO_ROOM_CASE_(M_, K_, 2)
 #define DISCO_ROOM_CASE_4(M_, K_) DISCO_ROOM_CASE_(M_, K_, 4)
 #define DISCO_ROOM_CASE_8(M_, K_) DISCO_ROOM_CASE_(M_, K_, 8)
 }  // namespace disco_host

@@ -51,8 +51,8 @@ def test_kernel_sources_have_no_cuda_or_portability_shims():
 
 
 def test_build_refuses_spilling_lds_dma_kernels():
-    """disco_amd/build.py: k_room_cov_dma counts its vector-memory queue by hand, so a build in which it uses scratch is refused;
-    the parser of hipcc's resource-usage remarks is what decides."""
+    """disco_amd/build.py: a build in which a kernel exceeds its scratch allowance (k_gevd_mwf_r1_dpp: none; k_room_cov_dma: 64 bytes per
+    lane) is refused; the parser of hipcc's resource-usage remarks is what decides."""
     from disco_amd import build
     remarks = '''
 k_room.h:504:1: remark: Function Name: _ZN5disco14k_room_cov_dmaILi8ELi8EEEvNS_8RoomArgsE [-Rpass-analysis=kernel-resource-usage]
@@ -63,5 +63,6 @@ k_room.h:504:1: remark:     ScratchSize [bytes/lane]: 36 [-Rpass-analysis=kernel
 k_stft.h:427:1: remark: Function Name: _ZN5disco10k_stft_covILi512ELi4ELb1EEEvPKf [-Rpass-analysis=kernel-resource-usage]
 k_stft.h:427:1: remark:     ScratchSize [bytes/lane]: 20 [-Rpass-analysis=kernel-resource-usage]
 '''
-    assert build.scratch_users(remarks, 'k_room_cov_dma') == ['_ZN5disco14k_room_cov_dmaILi4ELi8EEEvNS_8RoomArgsE']
+    assert build.scratch_users(remarks, 'k_room_cov_dma') == ['_ZN5disco14k_room_cov_dmaILi4ELi8EEEvNS_8RoomArgsE (36 B)']
+    assert build.scratch_users(remarks, 'k_room_cov_dma', 64) == []
     assert build.scratch_users(remarks.replace(' 36 ', ' 0 '), 'k_room_cov_dma') == []

@@ -1,6 +1,6 @@
 """C5 (200 rooms x 8 x 8, 1024-pt, 2 iterations) on ONE batch under several kernel routes: ms per step, stage times, and the error of sampled
 rooms against the float64 oracle (computed once, in worker processes, while the GPU runs the variants).  Test / measurement tooling.
-Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [variants=room_sub:cov1_sub:cov_chunks,...] [sample=0,100,199]"""
+Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [variants=room_sub:cov1_sub:cov_chunks:room_flush,...] [sample=0,100,199]"""
 import json
 import os
 import sys
@@ -30,7 +30,7 @@ def main():
     kv = dict(a.split('=') for a in sys.argv[2:])
     R = int(kv.get('rooms', 200))
     K, M, N, L, iters = int(kv.get('nodes', 8)), int(kv.get('mics', 8)), int(kv.get('n_fft', 1024)), 160000, int(kv.get('iters', 2))
-    variants = [tuple(int(x) for x in v.split(':')) for v in kv.get('variants', '8:4:0,4:4:0,2:4:0,1:4:0,8:1:0,8:8:0').split(',')]
+    variants = [tuple(int(x) for x in v.split(':')) for v in kv.get('variants', '8:4:0:2,8:4:0:1,4:4:0:2').split(',')]
     sample = [int(x) for x in kv.get('sample', '0,100,199').split(',') if int(x) < R]
     steps = int(kv.get('steps', 8))
     dev = torch.device('cuda:0')
@@ -53,9 +53,10 @@ def main():
             eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None))
     res = {'rooms': R, 'shape': [K, M, N], 'iters': iters, 'steps': steps, 'variants': {}}
     got = {}
-    for rs, cs, ch in variants:
-        name = f'room_sub={rs},cov1_sub={cs},cov_chunks={ch}'
+    for rs, cs, ch, nf in variants:
+        name = f'room_sub={rs},cov1_sub={cs},cov_chunks={ch},room_flush={nf}'
         eng.set_option('room_sub', rs)
+        eng.set_option('room_flush', nf)
         eng.set_option('cov1_sub', cs)
         eng.set_tuning(0, ch, 0, 0)
         if eng.workspace_bytes() > ws.numel():
