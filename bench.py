@@ -38,12 +38,11 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# parity bar of the DANSE-style ITERATED scheme (C5).  The reference is strictly two-step (tango.py:1-7): there is no reference output
-# for a second iteration, the float64 oracle defines it ("no reference parity").  Measured:
-# float32 accumulation of the 313-frame, 15 x 15 covariances is what separates the HIP path from that oracle -- the oracle itself with
-# sequential float32 accumulation is 1.0-2.2e-4 away from the all-float64 one on the worst of three sampled rooms, 8e-6 ... 2.4e-5
-# on the others; with 8 covariance chunks per node instead of 2 the HIP path is at 4e-5.  The two-step workloads keep 1e-4.
-ITER_TOL = 3.0e-4
+# Parity bar of every workload: 1e-4 (BASELINE.json north_star), two-step and iterated alike.  (Round 3 held the DANSE-style ITERATED
+# scheme, C5, to 3e-4: its float32 sums over 157 frames left room 199 at 2.3e-4.  Round 4 shortened the sums -- time sub-chunks across
+# the lanes of the room pass, float64 step-1 statistics -- and the relaxed bar is gone.)
+PARITY_TOL = 1.0e-4
+HBM_ACHIEVABLE = 6.3e12    # /opt/skills/guides/MI355X_MICROARCH.md: what a streaming kernel reaches; a stage "moving" more than that has a wrong byte model
 HBM_PEAK = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
 BF16_MATRIX_PEAK = 2.5e15   # same guide: dense bf16 MFMA peak (the headline figures with 2:1 sparsity are never used)
 F32_MATRIX_PEAK = 157.3e12  # same guide: f32-input MFMA = the f32 vector rate (what a float32 library GEMM / convolution can reach)
@@ -86,7 +85,7 @@ def kernel_alg_bytes(M, K, F, H):
         'cov2': M * F * 8 + F * 4 + (K - 1) * F * 8,          # X + mask + remote z in
         'room_cov2': M * F * 8 + F * 4 + F * 8,               # X + mask in, z out (all nodes of a room in one workgroup: remote z's stay on chip)
         'room_cov2_reg': M * F * 8 + F * 4 + F * 8,
-        'apply2': M * F * 8 + (K - 1) * F * 8 + F * 8,        # X + remote z in, yf out
+        'apply2': M * F * 8 + F * 8 + F * 8,                  # X + z in (every z row once per room: the K - 1 readers of a row share it on chip / in L2), yf out
         'step2_cov': M * F * 8 + F * 4,                       # X + mask in (z stays on chip)
         'step2_apply': M * F * 8 + F * 8,                     # X in, yf out
         'step2_apply_istft': M * F * 8 + H * 4,               # X in, hop samples out (yf stays on chip)
@@ -492,7 +491,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
 
     # ---- sampled rooms of the last timed step -> the oracle workers (every rank, its own rooms)
     ticket = {'name': name, 'jobs': [], 'rooms_global': [first_room + r for r in sample_rooms], 'first_room': first_room,
-              'tol': 1e-4 if iters == 1 else ITER_TOL, 'finite': finite}
+              'tol': PARITY_TOL, 'finite': finite}
     if want_parity:
         pool = env['pool']
         for r in sample_rooms:
@@ -549,12 +548,18 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                    'ms_min': round(ms_list[0], 4), 'ms_max': round(ms_list[-1], 4)}
             if nm in kab:
                 ent['alg_bytes'] = kab[nm] * rooms_done * K * T        # per step (all launches of the stage)
+                if nm in ('room_cov2', 'room_cov2_reg') and iters > 1:
+                    # only the LAST pass of an iterated run stores z (nobody reads an earlier one): 8 F per node-frame once per step
+                    ent['alg_bytes'] -= (rooms_done - R) * K * T * F * 8
                 ent['GBps'] = round(ent['alg_bytes'] / (per_step * 1e-3) / 1e9, 1)
             if nm in ('crnn_z', 'crnn_w'):
                 from disco_amd.dnn.crnn import flops_per_frame
                 ent['flops'] = flops_per_frame(1 if nm == 'crnn_z' else K) * rooms_done * K * T
                 ent['TFLOPs'] = round(ent['flops'] / (per_step * 1e-3) / 1e12, 2)
             stages[nm] = ent
+        # sanity of the byte models: no stage may "move" its algorithmic bytes faster than the achievable HBM rate
+        sanity = [f'{nm}: {ent["GBps"]} GB/s of algorithmic bytes exceeds the achievable HBM rate ({HBM_ACHIEVABLE / 1e9:.0f} GB/s): byte model wrong'
+                  for nm, ent in stages.items() if ent.get('GBps', 0.0) > HBM_ACHIEVABLE / 1e9]
         pipeline_b = b_alg(M, K, F, H, iters)
         pipeline = {'B_alg_per_node_frame': pipeline_b, 'achieved_GBps': round(units_per_step * steps / dt_local * pipeline_b / 1e9, 1),
                     'frac': round(units_per_step * steps / dt_local * pipeline_b / HBM_PEAK, 4)}
@@ -598,6 +603,13 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                                     'fraction says how far they are from the streaming bound of their inputs')
             if traffic_note:
                 roofline['traffic_note'] = traffic_note
+            elif traffic is not None and traffic < 0.9 * launch_bytes:
+                sanity.append(f'{dom}: counter traffic {traffic:.3e} B per launch is below 0.9 x the algorithmic bytes {launch_bytes:.3e}: byte model or counters wrong')
+            if dom in ('stft_cov1', 'stft'):
+                roofline['byte_model_note'] = ('the byte model of this kernel includes the store of the spectra X (8 M F per node-frame), which SURVEY 8(d) '
+                                               'treats as avoidable (STFT recomputed, not stored); the 8(d)-faithful figure is `pipeline`')
+        if sanity:
+            roofline = dict(roofline or {}, sanity_errors=sanity)
 
     exchange = None
     if node_sharded:
@@ -813,8 +825,16 @@ def main(argv=None):
         dist.barrier()                    # leave together
         dist.destroy_process_group()
     for nm, worst in failures + soft_failures:
-        print(f'PARITY FAILURE ({nm}): worst relative error over all ranks {worst:.3e} >= 1e-4', file=sys.stderr)
-    return 3 if failures else 0
+        print(f'PARITY FAILURE ({nm}): worst relative error over all ranks {worst:.3e} >= {PARITY_TOL:.1e}', file=sys.stderr)
+    sanity = [(nm, e) for nm, r_ in [(head_name, head)] + [(n_, x_) for n_, x_ in extras.items() if 'error' not in x_]
+              for e in ((r_.get('roofline') or {}).get('sanity_errors') or [])] if rank == 0 else []
+    for nm, e in sanity:
+        print(f'SANITY FAILURE ({nm}): {e}', file=sys.stderr)
+    # exit code: 3 = the headline failed its parity bar (or a sanity check of its byte models), 4 = an attached workload did; the line is
+    # printed either way
+    if failures or any(nm == head_name for nm, _ in sanity):
+        return 3
+    return 4 if (soft_failures or sanity) else 0
 
 
 if __name__ == '__main__':

@@ -296,8 +296,7 @@ const OptionInfo* option_table() {
         {"solve_f32", "DISCO_SOLVE_F32", 0},
         {"solve_dpp", "DISCO_SOLVE_DPP", 1},
         {"room_sub", "DISCO_ROOM_SUB", 8},
-        {"room_flush", "DISCO_ROOM_FLUSH", 2},
-        {"cov1_sub", "DISCO_COV1_SUB", 4},
+        {"cov1_mode", "DISCO_COV1_MODE", 64},
     };
     return t;
 }

@@ -62,15 +62,20 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
     if (KR != 0 && KR != c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: P must be M or M + K - 1");
     if (KR > 0 && (!Zs || !Zn)) return fail(ctx, DISCO_E_ARG, "disco_cov_masked: Zs/Zn required when P > M");
     if (P > CB_PMAX || M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: P > 16 or M > 8");
-    const int chunks = cov_chunks(ctx);
+    int chunks = cov_chunks(ctx);
     const long long G = (long long)c.rooms * ctx->Kl;
     const int NP = P * (P + 1) / 2;
     const bool same = (Zs == Zn);
     const bool split = (KR == 0 || (P > 8 && same && mask_remote && (ctx->F - 1) % 64 == 0)) && cov_split_shape(M, KR);
-    // step-1 shapes of the split kernels (KR = 0, M >= 7): time sub-chunks across the lanes (option "cov1_sub": 4 or 8; anything else:
-    // lanes are bins only); every frame chunk then leaves a (hi, lo) PAIR of partial blocks (k_cov.h)
-    const int o_sub = ctx->opt[DISCO_OPT_COV1_SUB], sub = (split && KR == 0 && (o_sub == 4 || o_sub == 8)) ? o_sub : 1;
-    const int blocks = sub > 1 ? 2 * chunks : chunks;
+    // step-1 shapes of the split kernels (KR = 0, M >= 7; option "cov1_mode"): 64 (default) = float64 accumulators, every frame chunk
+    // leaves a (hi, lo) PAIR of partial blocks; 4 / 8 = float32 with that many time sub-chunks across the lanes; else float32, lanes = bins
+    const int o_mode = ctx->opt[DISCO_OPT_COV1_MODE], sub = (split && KR == 0 && (o_mode == 4 || o_mode == 8 || o_mode == 64)) ? o_mode : 1;
+    // (the float64 kernel starts (tiles + 1) workgroups of 4 waves per node and chunk: one chunk as soon as that fills the chip)
+    if (sub == 64 && ctx->tune_cov_chunks == 0) {
+        const long long wgs = (long long)ctx->geom_rooms * ctx->Kl * ((ctx->F - 1 + 63) / 64 + 1);
+        chunks = (int)std::max<long long>(1, std::min<long long>(std::min(8, ctx->T), (8LL * ctx->n_cu + wgs - 1) / wgs));
+    }
+    const int blocks = sub == 64 ? 2 * chunks : chunks;
     const size_t need = (size_t)G * blocks * ctx->F * NP * sizeof(float4);
     skiploc = skiploc && split && KR > 0 && ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask;
     int rc = 0;
@@ -94,7 +99,7 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
     const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
     bool launched = false;
     if (split) {                // 9 <= P <= 16, one vector for both statistics: one block of pairs per wave
-        const int tiles = (ctx->F - 1 + 64 / sub - 1) / (64 / sub);
+        const int nbt = (sub == 4 || sub == 8) ? 64 / sub : 64, tiles = (ctx->F - 1 + nbt - 1) / nbt;
         const long long nblk = G * (tiles + 1) * chunks;
         if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
         launched = launch_cov_split_shape(M, KR, skiploc, sub, (unsigned)nblk, (hipStream_t)s, a);

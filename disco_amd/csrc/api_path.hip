@@ -155,7 +155,7 @@ int reserve_scratch(disco_ctx* ctx) {
     const size_t G = (size_t)c.rooms * ctx->Kl;
     const size_t P = (size_t)std::min(c.mics + c.nodes - 1, 16);
     const size_t NP = P * (P + 1) / 2;
-    int chunks = std::max(2 * cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));        // (2 x: the (hi, lo) pairs of the sub-chunked kernels)
+    int chunks = std::max(2 * cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));        // (2 x: the (hi, lo) pairs of k_cov_loc_f64)
     if (c.mics <= 8) chunks = std::max(chunks, stft_cov_chunks(ctx, nullptr));
     if (c.mics + c.nodes - 1 > 8) chunks = std::max(chunks, room_chunks(ctx));
     const size_t need = G * (size_t)chunks * ctx->F * NP * sizeof(float4);
@@ -491,10 +491,11 @@ static void iterated_steps(disco_ctx* ctx, const PathArgs& a, int iters, Steps& 
         // compression with the current w_loc (step 1's, then the local part of the previous iteration's filter) and the step-2
         // statistics: ONE pass over X for every node of a room where the shape allows it (k_room_cov), else the filter pass
         // followed by the covariance pass that reads X again and the K - 1 remote z's
+        const bool last_pass = it + 1 == iters;          // only the last pass's z is read again (by the filter pass; it is what z_y returns)
         st.push_back({nullptr, false, [=](disco_stream s) {
             int ch = 1, rc;
             if (same_mask && room_cov_ok(ctx, X, mask_w))
-                return STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w_loc, z, &ch, s));
+                return STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w_loc, z, &ch, s, last_pass));
             if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
             return STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &ch, s,
                                                       same_mask && c.nodes > 1));

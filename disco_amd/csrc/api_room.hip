@@ -27,18 +27,12 @@ static int room_sub(const disco_ctx* ctx) {
     return s == 4 ? 4 : 8;
 }
 
-// Partial blocks per node of the persistent pass: its workgroups walk items (room, tile of 32 / SUB bins, all frames) and hand their
-// sums over NF times per item (option "room_flush"), each time as a (hi, lo) PAIR of blocks -- the float32 totals of the SUB sub-chunks
-// and what the additions between them rounded away.  The register-staged kernel keeps the chunked geometry.
-int room_chunks(const disco_ctx* ctx) {
-    if (ctx->opt[DISCO_OPT_ROOM_DMA] == 0) return cov_chunks(ctx);
-    const int J = (ctx->T + 2 * room_sub(ctx) - 1) / (2 * room_sub(ctx));            // iterations per item
-    const int nf = std::max(1, std::min(std::min(ctx->opt[DISCO_OPT_ROOM_FLUSH], 4), J));
-    return 2 * nf;
-}
+// The persistent pass forms ONE partial block per node: its workgroups walk items (room, tile of 32 / SUB bins, all frames), the time
+// axis is split INSIDE the workgroup (SUB sub-chunks across the lanes).  The register-staged kernel keeps the chunked geometry.
+int room_chunks(const disco_ctx* ctx) { return ctx->opt[DISCO_OPT_ROOM_DMA] != 0 ? 1 : cov_chunks(ctx); }
 
 int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
-                             int* chunks_out, disco_stream s) {
+                             int* chunks_out, disco_stream s, bool store_z) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes, P = M + K - 1;
     if (!w_loc || !z || !room_cov_ok(ctx, X, mask)) return fail(ctx, DISCO_E_ARG, "room covariance: shape / state does not qualify");
@@ -59,6 +53,7 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
     a.F = ctx->F;
     a.chunks = chunks;
     a.R = c.rooms;
+    a.store_z = store_z ? 1 : 0;
     if (dma) {
         const int sub = room_sub(ctx), nb = 32 / sub;
         a.tiles = (ctx->F + nb - 1) / nb;

@@ -36,8 +36,7 @@ enum {
     DISCO_OPT_SOLVE_F32,                // "solve_f32": float32 squarings + float64 Rayleigh-quotient finish in the group solver (default 0: all float64)
     DISCO_OPT_SOLVE_DPP,                // "solve_dpp": 9 <= P <= 16 solved in registers with DPP row broadcasts (k_solve_dpp.h; 0: the LDS group solver)
     DISCO_OPT_ROOM_SUB,                 // "room_sub": time sub-chunks per workgroup of the persistent room pass (4 or 8 -> 8 or 4 bins per workgroup)
-    DISCO_OPT_ROOM_FLUSH,               // "room_flush": hand-overs of the sums per item of the persistent room pass (1 ... 4): 2 x that many partial blocks per node
-    DISCO_OPT_COV1_SUB,                 // "cov1_sub": time sub-chunks across the lanes of the step-1 statistics of the wide shapes (M >= 7): 4 / 8, else 1
+    DISCO_OPT_COV1_MODE,                // "cov1_mode": step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (default), 4 / 8 = float32 with time sub-chunks across the lanes, else float32
     DISCO_N_OPTIONS
 };
 namespace disco_host {
@@ -226,7 +225,7 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
                  int* chunks_out, disco_stream s, bool skiploc = false);
 bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask);
 int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z, int* chunks_out,
-                      disco_stream s);
+                      disco_stream s, bool store_z = true);
 int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s,
                       bool store = true);
 int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc, disco_c32* z_out, int* chunks_out,

@@ -429,19 +429,6 @@ __device__ __forceinline__ void cov_split_store(float4* o, const c32* acc_s, con
     }
 }
 
-// hi <- fl(hi + hi'), lo <- lo + lo' + the rounding error of that addition (Knuth's two_sum), hi' / lo' = the values of lane ^ off
-__device__ __forceinline__ void cov_two_sum_xor(float& hi, float& lo, const int off) {
-    const float b = __shfl_xor(hi, off), lb = __shfl_xor(lo, off);
-    float s = hi + b;
-    const float bb = s - hi;
-    float e = (hi - (s - bb)) + (b - bb);
-#if defined(__clang__)
-    asm volatile("" : "+v"(s), "+v"(e));
-#endif
-    hi = s;
-    lo = (lo + lb) + e;
-}
-
 // S > 1: the tile is 64 / S bins wide and a wave's lanes are (sub-chunk sc, bin): lane (sc, b) folds frames t0 + sc, t0 + sc + S, ... of
 // the chunk -- S times shorter float32 sums per accumulator at the same register count (round 4: the step-1 statistics of the wide
 // shapes summed 157 frames each, and the 8 x 8 block they produce is the leading block of every step-2 pencil; cf. k_room.h) -- and
@@ -500,46 +487,157 @@ __device__ __forceinline__ void cov_split_wave(const CovArgs& a, long long g, in
             for (int i = 0; i < NY; ++i) uy[i] = ny[i];
             mcur = mnext;
         }
-        if constexpr (S > 1) {
-            // lanes hold partial sums over disjoint frames of the same bin -- all 64 (Nyquist tile) or the S sub-chunks.  They meet through
-            // the lane crossbar by two_sum: the float32 total AND what its additions rounded away, stored as TWO partial blocks (2 c, 2 c + 1
-            // of 2 * chunks) which the solvers add in float64 (cf. k_room.h: a float32 rounding of the total alone costs the worst C5 room 4e-5)
+        if (nyq || S > 1) {          // lanes hold partial sums over disjoint frames of the same bin: all 64 (Nyquist tile) or the S sub-chunks
             const int stop = nyq ? 1 : NBT;
-            c32 lo_s[NPAIR], lo_n[NPAIR];
 #pragma unroll
-            for (int q = 0; q < NPAIR; ++q) {
-                lo_s[q] = lo_n[q] = make_float2(0.f, 0.f);
+            for (int q = 0; q < NPAIR; ++q)
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) {
                     if (off < stop) break;
-                    cov_two_sum_xor(acc_s[q].x, lo_s[q].x, off);
-                    cov_two_sum_xor(acc_s[q].y, lo_s[q].y, off);
-                    cov_two_sum_xor(acc_n[q].x, lo_n[q].x, off);
-                    cov_two_sum_xor(acc_n[q].y, lo_n[q].y, off);
+                    acc_s[q].x += __shfl_xor(acc_s[q].x, off);
+                    acc_s[q].y += __shfl_xor(acc_s[q].y, off);
+                    acc_n[q].x += __shfl_xor(acc_n[q].x, off);
+                    acc_n[q].y += __shfl_xor(acc_n[q].y, off);
                 }
-            }
-            if (live && (nyq ? lane == 0 : lane < NBT)) {
-                float4* o = a.part + (((g * (2 * a.chunks) + 2 * c) * F) + f) * (long long)NP;
-                cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
-                cov_split_store<P, X0, Y0, TRI, NX, NY>(o + (long long)F * NP, lo_s, lo_n);
-            }
-        } else {
-            if (nyq) {          // lanes hold partial sums over disjoint frames of the same bin
-#pragma unroll
-                for (int q = 0; q < NPAIR; ++q)
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        acc_s[q].x += __shfl_xor(acc_s[q].x, off);
-                        acc_s[q].y += __shfl_xor(acc_s[q].y, off);
-                        acc_n[q].x += __shfl_xor(acc_n[q].x, off);
-                        acc_n[q].y += __shfl_xor(acc_n[q].y, off);
-                    }
-            }
-            if (live && (!nyq || lane == 0)) {
-                float4* o = a.part + (((g * a.chunks + c) * F) + f) * (long long)NP;
-                cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
-            }
         }
+        if (live && (nyq ? lane == 0 : lane < NBT)) {
+            float4* o = a.part + (((g * a.chunks + c) * F) + f) * (long long)NP;
+            cov_split_store<P, X0, Y0, TRI, NX, NY>(o, acc_s, acc_n);
+        }
+    }
+}
+
+// ---- step-1 statistics of the wide shapes in FLOAT64 (round 4) -----------------------------------------------------------------------
+// The M x M statistics of step 1 feed three solves of a two-iteration run -- the local filters, and the leading block of both step-2
+// pencils -- and on C5 their float32 summation was what the output's distance from the float64 oracle followed: with the lanes-are-bins
+// kernel above room 199 came out at 1.2e-4, with 4 / 8 time sub-chunks per wave at 9e-5 / 3-5e-5, whatever the step-2 pass did
+// (profiles/r04_a_*, r04_b_*).  The pass is HBM-bound with arithmetic to spare (36 entries per bin and frame), so here the sums are simply
+// formed in float64: the products u_i conj(u_j) stay float32 (their rounding errors are independent and average out over the frames), the
+// weights m^2, (1 - m)^2 and the accumulation are float64 -- 2 conversions + 4 v_fma_f64 per entry where the float32 form has 2 packed
+// fmas.  The M(M+1)/2 entries are dealt to FOUR waves (tri(A0), tri(A1), A0 x B0, A0 x B1 with A0 = [0, MA), A1 = [MA, M), B0 | B1 = A1:
+// 32 float64 accumulators per lane at M = 8, four waves per SIMD stay resident), the total leaves as a (hi, lo) PAIR of float32 partial
+// blocks (2 c, 2 c + 1 of 2 * chunks) which every solver adds in float64 -- so nothing is rounded to float32 on the way to the solve.
+template <int M, int X0, int X1, int Y0, int Y1, bool TRI>
+__device__ __forceinline__ void cov_loc_f64_wave(const CovArgs& a, long long g, int c, int tile, int lane) {
+    using Role = CovSplitRole<M, 0, X0, X1, Y0, Y1, TRI>;
+    constexpr int P = M, NP = P * (P + 1) / 2, NX = Role::NX, NY = Role::NY, NPAIR = Role::NPAIR;
+    if constexpr (NPAIR == 0) {
+        return;
+    } else {
+        const int T = a.T, F = a.F;
+        const int nbin = F - 1, tiles = (nbin + 63) / 64;
+        const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
+        const bool nyq = tile == tiles;                                      // the Nyquist bin: lanes are frames
+        int f = nyq ? nbin : tile * 64 + lane;
+        const bool live = nyq || f < nbin;
+        if (f > nbin) f = nbin;
+        const int t_step = nyq ? 64 : 1, t_off = nyq ? lane : 0;
+        const c32* xp = a.X + (g * T * (long long)F) * M;                    // wave-uniform plane pointers (scalar registers)
+        const float* mp = a.mask + g * T * (long long)F;
+        const c32* const zp[1] = {nullptr};
+        double sr[NPAIR], si[NPAIR], nr[NPAIR], ni[NPAIR];                   // Rss / Rnn entry q, real and imaginary part (imaginary parts of diagonal entries stay unused)
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) sr[q] = si[q] = nr[q] = ni[q] = 0.0;
+        c32 ux[NX > 0 ? NX : 1], uy[NY > 0 ? NY : 1], nx[NX > 0 ? NX : 1], ny[NY > 0 ? NY : 1];
+        float mcur, mnext;
+        auto fetch = [&](int tu, c32* px, c32* py, float& m_) {
+            int t_ = tu + t_off;
+            t_ = t_ < t1 ? t_ : t1 - 1;
+            const int tfm = t_ * F + f;                                      // (frame, bin) offset inside the node's plane
+            m_ = mp[tfm];
+            cov_split_fetch<M, 0, X0, X1>(px, xp, zp, tfm);
+            cov_split_fetch<M, 0, Y0, Y1>(py, xp, zp, tfm);
+        };
+        auto pair = [&](const c32 u, const c32 v, const double wa, const double wb, int q) {
+            const c32 p = cmul_aconjb(u, v);
+            const double pr = (double)p.x, pi = (double)p.y;
+            sr[q] = fma(wa, pr, sr[q]);
+            nr[q] = fma(wb, pr, nr[q]);
+            si[q] = fma(wa, pi, si[q]);
+            ni[q] = fma(wb, pi, ni[q]);
+        };
+        auto diag = [&](const c32 u, const double wa, const double wb, int q) {
+            const double pr = (double)fmaf(u.x, u.x, u.y * u.y);
+            sr[q] = fma(wa, pr, sr[q]);
+            nr[q] = fma(wb, pr, nr[q]);
+        };
+        fetch(t0, ux, uy, mcur);
+        for (int tu = t0; tu < t1; tu += t_step) {
+            fetch(tu + t_step, nx, ny, mnext);                               // harmless clamp at the end of the chunk
+            const bool ok = live && (tu + t_off) < t1;
+            const double m = ok ? (double)mcur : 0.0, mc = ok ? 1.0 - (double)mcur : 0.0;
+            const double wa = m * m, wb = mc * mc;
+            int q = 0;                                                       // (the order of cov_split_accumulate / cov_split_store)
+            if constexpr (TRI) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = i; j < NX; ++j, ++q) {
+                        if (j == i) diag(ux[i], wa, wb, q);
+                        else pair(ux[i], ux[j], wa, wb, q);
+                    }
+#pragma unroll
+                for (int i = 0; i < NY; ++i)
+#pragma unroll
+                    for (int j = i; j < NY; ++j, ++q) {
+                        if (j == i) diag(uy[i], wa, wb, q);
+                        else pair(uy[i], uy[j], wa, wb, q);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j < NY; ++j, ++q) pair(ux[i], uy[j], wa, wb, q);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) ux[i] = nx[i];
+#pragma unroll
+            for (int i = 0; i < NY; ++i) uy[i] = ny[i];
+            mcur = mnext;
+        }
+        if (nyq) {          // lanes hold partial sums over disjoint frames of the same bin
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    sr[q] += __shfl_xor(sr[q], off);
+                    si[q] += __shfl_xor(si[q], off);
+                    nr[q] += __shfl_xor(nr[q], off);
+                    ni[q] += __shfl_xor(ni[q], off);
+                }
+        }
+        if (live && (!nyq || lane == 0)) {
+            c32 hs[NPAIR], hn[NPAIR], ls[NPAIR], ln[NPAIR];
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+                hs[q] = make_float2((float)sr[q], (float)si[q]);
+                hn[q] = make_float2((float)nr[q], (float)ni[q]);
+                ls[q] = make_float2((float)(sr[q] - (double)hs[q].x), (float)(si[q] - (double)hs[q].y));
+                ln[q] = make_float2((float)(nr[q] - (double)hn[q].x), (float)(ni[q] - (double)hn[q].y));
+            }
+            float4* o = a.part + (((g * (2 * a.chunks) + 2 * c) * F) + f) * (long long)NP;
+            cov_split_store<P, X0, Y0, TRI, NX, NY>(o, hs, hn);
+            cov_split_store<P, X0, Y0, TRI, NX, NY>(o + (long long)F * NP, ls, ln);
+        }
+    }
+}
+
+// grid = R*Kl * (tiles + 1) * chunks blocks of 4 waves, tiles = ceil((F - 1) / 64); partial blocks: 2 * chunks
+template <int M>
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(256) void k_cov_loc_f64(CovArgs a) {
+    constexpr int MA = (M + 1) / 2, MB = MA + (M - MA + 1) / 2;
+    const int nbin = a.F - 1, tiles = (nbin + 63) / 64;
+    int bid = blockIdx.x;
+    const int c = bid % a.chunks;
+    bid /= a.chunks;
+    const int tile = bid % (tiles + 1);
+    const long long g = bid / (tiles + 1);
+    const int lane = threadIdx.x & 63;
+    switch (wave_id()) {
+        case 0: cov_loc_f64_wave<M, 0, MA, MA, MA, true>(a, g, c, tile, lane); break;          // tri(A0)
+        case 1: cov_loc_f64_wave<M, MA, M, M, M, true>(a, g, c, tile, lane); break;            // tri(A1)
+        case 2: cov_loc_f64_wave<M, 0, MA, MA, MB, false>(a, g, c, tile, lane); break;         // A0 x B0
+        default: cov_loc_f64_wave<M, 0, MA, MB, M, false>(a, g, c, tile, lane); break;         // A0 x B1
     }
 }
 

@@ -69,6 +69,7 @@ struct RoomArgs {
     float4* part;        // [R*K][chunks][F][NP]
     int T, F, chunks, tiles;
     long long R;
+    int store_z;         // 0: z is only formed on chip (an iteration whose z nobody reads: the next pass re-compresses with new filters)
 };
 
 // IS_A: the role of the calling WAVE (slots A or B).  The whole stage loop is instantiated per role -- a role branch inside one
@@ -149,7 +150,7 @@ __device__ __forceinline__ void room_cov_run(const RoomArgs& a, RoomStage<M, K>*
                         p.y += __shfl_xor(p.y, off);
                     }
                     if (lzs[r] >= 0) (&st.zs[s_][0][0])[lzs[r]] = p;
-                    if (lzo[r] >= 0 && t < t1) Zr[lzo[r] + t * F] = p;
+                    if (lzo[r] >= 0 && t < t1 && a.store_z) Zr[lzo[r] + t * F] = p;
                 }
             }
             if (mact) st.ms[s_][mk][mb] = lm[s_];
@@ -278,7 +279,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 
 template <int M, int K, int SUB_>
 struct RoomGeomS {
-    static_assert(SUB_ == 4 || SUB_ == 8, "sub-chunks share a wave: lane bits 5, 4 (and 3)");
+    static_assert(SUB_ == 2 || SUB_ == 4 || SUB_ == 8, "sub-chunks share a wave");
     static_assert(M % 4 == 0 && K % 2 == 0 && K >= 2 && K <= 8, "4-mic slots, two slots per wave, <= 28 pairs per slot");
     static constexpr int SUB = SUB_, NB = 32 / SUB_;    // frames per group, bins per workgroup
     static constexpr int KR = K - 1, P = M + KR, NP = P * (P + 1) / 2;
@@ -295,7 +296,7 @@ struct RoomGeomS {
     static_assert(NMASK % 64 == 0 && NMW <= WA + WB, "one mask wave-load per wave");
     static constexpr int NTAPP = (NROW + 63) / 64 * 64; // tap granules of an item, padded to whole wave-loads
     static constexpr int BPR = 16 / MH;                 // bins per 256-byte bank row of granules
-    static constexpr int LH = 2;                         // halving levels of the final reduction (lane bits 5, 4)
+    static constexpr int LH = SUB >= 4 ? 2 : (SUB == 2 ? 1 : 0);      // halving levels of the final reduction (lane bits 5, 4)
 };
 
 template <int M, int K, int SUB>
@@ -345,62 +346,35 @@ __device__ __forceinline__ void vm_wait_all() {
 #endif
 }
 
-// 2 x 2 transpose between two registers and lane bit BIT: lanes with the bit clear are left with (a, a') -- a' = the partner lane's a --,
-// lanes with it set with (b', b).  One swap per PAIR of registers, and the two sums that follow are split between the halves.
+// 2 x 2 transpose between two registers and lane bit BIT, then the sum: lanes with the bit clear are left with a + a' (a' = the partner
+// lane's a), lanes with it set with b + b'.  One swap + one add per PAIR of registers, and the survivors are split between the halves.
 template <int BIT>
-__device__ __forceinline__ void lane_swap(float& a, float& b, int lane) {
+__device__ __forceinline__ float lane_swap_add(float a, float b, int lane) {
 #if defined(__clang__)
     (void)lane;
     static_assert(BIT == 32 || BIT == 16, "permlane swaps");
     if constexpr (BIT == 32) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        a = __uint_as_float(r[0]);
-        b = __uint_as_float(r[1]);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
     } else {
         const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        a = __uint_as_float(r[0]);
-        b = __uint_as_float(r[1]);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #else
     const float pa = __shfl_xor(a, BIT), pb = __shfl_xor(b, BIT);
-    if (lane & BIT) a = pb;
-    else b = pa;
+    return (lane & BIT) ? pb + b : a + pa;
 #endif
 }
-// s = fl(a + b) and the rounding error of that addition, exactly (Knuth): a + b = s + e
-__device__ __forceinline__ void two_sum(float a, float b, float& s, float& e) {
-    s = a + b;
-    const float bb = s - a;
-    e = (a - (s - bb)) + (b - bb);
-#if defined(__clang__)
-    asm volatile("" : "+v"(s), "+v"(e));               // (keeps the compiler from re-associating the error term away)
-#endif
-}
-// One level of the reduction over the sub-chunks: entries [0, N) -> [0, N / 2), entry e meets entry e + N / 2 of the partner lane
-// (lanes with the bit set keep the upper half's totals).  hi carries the float32 sums, lo what their additions rounded away.
-template <int BIT, int N, bool HAVE_LO>
-__device__ __forceinline__ void room_halve(float (*hi)[4], float (*lo)[4], int lane) {
+// entries [0, N) of (es, en) -> [0, N / 2): entry e meets entry e + N / 2; lanes with the bit set keep the upper half's totals
+template <int BIT, int N>
+__device__ __forceinline__ void room_halve(c32* es, c32* en, int lane) {
     static_assert(N % 2 == 0, "pairs of entries");
-    // the two statistics one after the other (components 0, 1: Rss; 2, 3: Rnn), with a fence between: hipcc otherwise interleaves all
-    // pairs for latency and needs more registers than the sums themselves take
 #pragma unroll
-    for (int c0 = 0; c0 < 4; c0 += 2) {
-#pragma unroll
-        for (int e = 0; e < N / 2; ++e)
-#pragma unroll
-            for (int c = c0; c < c0 + 2; ++c) {
-                float a = hi[e][c], b = hi[e + N / 2][c], err;
-                lane_swap<BIT>(a, b, lane);
-                two_sum(a, b, hi[e][c], err);
-                if constexpr (HAVE_LO) {
-                    float la = lo[e][c], lb = lo[e + N / 2][c];
-                    lane_swap<BIT>(la, lb, lane);
-                    lo[e][c] = (la + lb) + err;
-                } else {
-                    lo[e][c] = err;
-                }
-            }
-        DISCO_SCHED_FENCE();
+    for (int e = 0; e < N / 2; ++e) {
+        es[e].x = lane_swap_add<BIT>(es[e].x, es[e + N / 2].x, lane);
+        es[e].y = lane_swap_add<BIT>(es[e].y, es[e + N / 2].y, lane);
+        en[e].x = lane_swap_add<BIT>(en[e].x, en[e + N / 2].x, lane);
+        en[e].y = lane_swap_add<BIT>(en[e].y, en[e + N / 2].y, lane);
     }
 }
 
@@ -500,7 +474,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
                     // the node's place: lxa = (lk T F M + 2 lp) 8 with 2 lp < M  =>  (lxa >> log2 M) & ~7 = lk T F 8 (bytes of z), and
                     // lwt / (NB MH) = lk (the z rows of a sub-chunk are padded to K + 1)
                     (&sh.zs[zb][0][0][0])[(lsc * (K + 1) + lwt[r] / (NB * MH)) * NB + lbin] = p;
-                    *reinterpret_cast<c32*>(gz + ((lxa[r] >> LOGM) & ~7u) + (unsigned)((min(lbin, bmax) + min(lsc, nv1) * F) * 8)) = p;
+                    if (a.store_z) *reinterpret_cast<c32*>(gz + ((lxa[r] >> LOGM) & ~7u) + (unsigned)((min(lbin, bmax) + min(lsc, nv1) * F) * 8)) = p;
                 }
             }
         }
@@ -568,34 +542,27 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
 
     // The SUB partial sums of every entry meet inside the wave: lane bit 5, then bit 4, by swap-and-add (every level leaves a lane
     // half of its entries: the upper half's totals go to the lanes with the bit set), a third sub-chunk bit (SUB = 8, lane bit 3) by a plain
-    // add.  Every addition of the tree is a two_sum: what it rounds away is carried in a second word, and the pair (hi, lo) goes to TWO
-    // partial blocks, 2 blk and 2 blk + 1 -- the solvers add the blocks of an entry in float64, so the sub-chunk totals meet without a
-    // float32 rounding at full magnitude (which alone costs the worst C5 room 4e-5: profiles/r04_c5_accumulation.txt, "x").
-    // A lane then stores whole 16-byte entries -- for A slots one row of KR contiguous ones -- and clears its sums.
+    // add.  A lane then stores whole 16-byte entries -- for A slots one row of KR contiguous ones -- and clears its sums.
     // Entries are numbered q = i KR + jj (A: rows 4 h + i against the remote columns) / the upper triangle of the remote block
     // row by row (B): in both cases consecutive q of a row are consecutive in the packed triangle, and for B so is the whole run.
-    auto finish = [&](int room, int f0, int blk) {
+    auto finish = [&](int room, int f0) {
         constexpr int NACCP = (NACC + (1 << LH) - 1) >> LH << LH, EPL = NACCP >> LH;
-        float hi[NACCP][4], lo[NACCP / 2][4];
+        c32 es[NACCP], en[NACCP];
 #pragma unroll
         for (int q = 0; q < NACCP; ++q) {
-            hi[q][0] = q < NACC ? acc_s[q].x : 0.f;
-            hi[q][1] = q < NACC ? acc_s[q].y : 0.f;
-            hi[q][2] = q < NACC ? acc_n[q].x : 0.f;
-            hi[q][3] = q < NACC ? acc_n[q].y : 0.f;
+            es[q] = q < NACC ? acc_s[q] : make_float2(0.f, 0.f);
+            en[q] = q < NACC ? acc_n[q] : make_float2(0.f, 0.f);
         }
-        room_halve<32, NACCP, false>(hi, lo, lane);
-        room_halve<16, NACCP / 2, true>(hi, lo, lane);
+        if constexpr (LH >= 1) room_halve<32, NACCP>(es, en, lane);
+        if constexpr (LH >= 2) room_halve<16, NACCP / 2>(es, en, lane);
         if constexpr (SUB == 8) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float err;
-                    const float other = __shfl_xor(hi[e][c], 8), lother = __shfl_xor(lo[e][c], 8);
-                    two_sum(hi[e][c], other, hi[e][c], err);
-                    lo[e][c] = (lo[e][c] + lother) + err;
-                }
+            for (int e = 0; e < EPL; ++e) {
+                es[e].x += __shfl_xor(es[e].x, 8);
+                es[e].y += __shfl_xor(es[e].y, 8);
+                en[e].x += __shfl_xor(en[e].x, 8);
+                en[e].y += __shfl_xor(en[e].y, 8);
+            }
         }
         // Where the lane's entries go is recomputed here from an OPAQUE copy of the thread index: derived once before the loop, these
         // values would be carried through it in registers the fold needs (hipcc hoists them out and then spills them).
@@ -605,24 +572,18 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
 #endif
         const int lane_ = tid_ & 63, bin_ = lane_ & (NB - 1), sub_ = (lane_ / NB) & 1;
         const int k_ = is_a ? (2 * wr + sub_) / NA : 2 * wr + sub_, h_ = is_a ? sub_ % NA : 0;
-        const int g = ((lane_ >> 5) & 1) * 2 + ((lane_ >> 4) & 1);
+        const int g = LH == 2 ? ((lane_ >> 5) & 1) * 2 + ((lane_ >> 4) & 1) : (LH == 1 ? (lane_ >> 5) & 1 : 0);
         const bool writer = f0 + bin_ < F && (SUB != 8 || (lane_ & 8) == 0);
         if (writer) {
-            float4* o = a.part + ((((long long)room * K + k_) * a.chunks + 2 * blk) * F + f0 + bin_) * (long long)NP;
-            float4* ol = o + (long long)F * NP;
+            float4* o = a.part + (((long long)room * K + k_) * F + f0 + bin_) * (long long)NP;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int q = g * EPL + e;
-                int at = -1;
                 if constexpr (is_a) {
                     const int r = 4 * h_ + q / KR, jj = q % KR;           // row of the node's own mic, remote column
-                    at = r * P - (r * (r - 1)) / 2 + (M - r) + jj;
+                    o[r * P - (r * (r - 1)) / 2 + (M - r) + jj] = make_float4(es[e].x, es[e].y, en[e].x, en[e].y);
                 } else {
-                    if (q < NACC) at = tri_index<P>(M, M) + q;
-                }
-                if (at >= 0) {
-                    o[at] = make_float4(hi[e][0], hi[e][1], hi[e][2], hi[e][3]);
-                    ol[at] = make_float4(lo[e][0], lo[e][1], lo[e][2], lo[e][3]);
+                    if (q < NACC) o[tri_index<P>(M, M) + q] = make_float4(es[e].x, es[e].y, en[e].x, en[e].y);
                 }
             }
         }
@@ -668,11 +629,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
     form_z(rd, fd, 1, 1, 1, 0);
     __syncthreads();
     int s0 = 0, zb0 = 0;                                // ring slot / z buffer of the fold position's first group
-    // The sums are handed over NF = a.chunks / 2 times per item (after iterations ceil(J (f + 1) / NF) - 1): shorter float32 sums again,
-    // at one more pair of partial blocks per hand-over.
-    const int NF = a.chunks / 2;
-    int fl = 0, jnext = (J + NF - 1) / NF - 1;          // the hand-over in progress, the iteration that completes it
-    int rp = rd, fp = fd, bp = 0;                       // the (item, hand-over) whose last groups were folded in the previous iteration (pending)
+    int rp = rd, fp = fd;                               // the item whose last groups were folded in the previous iteration (pending)
     bool pending = false;
     while (true) {
         if (vi) {
@@ -680,20 +637,15 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
             issue(ri, fi, 2 * ji, (s0 + 4) % D);
             issue(ri, fi, 2 * ji + 1, (s0 + 5) % D);
         }
-        if (pending) finish(rp, fp, bp);
+        if (pending) finish(rp, fp);
         if (vf) {
             form_z(rf, ff, 2 * jf, (s0 + 2) % D, zb0 ^ 2, nf & 1);
             form_z(rf, ff, 2 * jf + 1, (s0 + 3) % D, (zb0 ^ 2) + 1, nf & 1);
         }
         fold(fd, 2 * jd, s0, zb0);
         fold(fd, 2 * jd + 1, (s0 + 1) % D, zb0 + 1);
-        pending = jd == jnext;
-        rp = rd, fp = fd, bp = fl;
-        if (pending) {
-            ++fl;
-            jnext = (int)(((long long)J * (fl + 1) + NF - 1) / NF) - 1;
-            if (jd == J - 1) fl = 0, jnext = (J + NF - 1) / NF - 1;
-        }
+        pending = jd == J - 1;
+        rp = rd, fp = fd;
         vm_wait_all();
         __syncthreads();
         if (!vf) break;                                 // the fold position was this workgroup's last iteration
@@ -703,7 +655,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
         rf = ri, ff = fi, jf = ji, nf = ni, vf = vi;
         if (vi) advance_issue();
     }
-    finish(rp, fp, bp);
+    finish(rp, fp);
 }
 
 template <int M, int K, int SUB>

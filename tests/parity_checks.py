@@ -578,6 +578,42 @@ def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-
     return errs
 
 
+def check_c5_full_length(make_engine, rooms=(0, 100, 199), K=8, M=8, n_fft=1024, L=160000, iters=2, tol=1e-4):
+    """BASELINE.json configs[4] at its real shape and length -- 8 nodes x 8 mics, 1024-point STFT, 10 s, two step-2 iterations -- on the
+    rooms bench.py samples from its 200-room batch (first, middle, last), against the float64 oracle at the north star's 1e-4.  The
+    launch geometry is pinned to the one the 200-room batch takes (one frame chunk in the step-1 statistics; the room pass has none), so
+    that every room goes through exactly the arithmetic it goes through in the bench.  The oracles run in worker processes while the
+    GPU computes.  (The iterated scheme is an extension: the reference is strictly two-step, tango.py:1-7; the oracle defines it.)"""
+    from concurrent.futures import ProcessPoolExecutor
+    from disco_amd import synth
+    data = [synth.make_room_numpy(r, K=K, M=M, L=L)[:3] for r in rooms]
+    y = np.stack([d[0] for d in data])
+    s = np.stack([d[1] for d in data])
+    n = np.stack([d[2] for d in data])
+    R = len(rooms)
+    with ProcessPoolExecutor(max_workers=R) as pool:
+        futs = [pool.submit(_c5_oracle_room, y[i], s[i, :, 0], n[i, :, 0], n_fft, iters) for i in range(R)]
+        eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+        eng.set_tuning(0, 1, 0, 0)
+        m = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F)
+        out = eng.tango_enhance_iterated(y, m, iters=iters)[0].numpy()
+        errs = {}
+        for i, r in enumerate(rooms):
+            ref = futs[i].result(timeout=1500)
+            errs[r] = max(relerr(out[i, k], ref[k]) for k in range(K))
+    assert max(errs.values()) < tol, errs
+    return errs
+
+
+def _c5_oracle_room(yr, s_ref, n_ref, n_fft, iters):
+    s = np.zeros_like(yr)
+    n = np.zeros_like(yr)
+    s[:, 0] = s_ref                                       # the masks only look at the reference microphone (tango.py:338-342)
+    n[:, 0] = n_ref
+    o = to.offline_tango_vec(yr, s, n, vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh', extra_iters=iters - 1)
+    return [so.istft(o['yf'][k], yr.shape[-1], n_fft, n_fft // 2, work_dtype=np.float64) for k in range(yr.shape[0])]
+
+
 def check_iterated_outputs(make_engine, K, M, L, n_fft, iters, tol=1e-4):
     """disco_tango_enhance_iterated: STFT-domain AND time-domain outputs against the oracle's restatement of the same
     definition (offline_tango_vec(extra_iters=...)); iters = 1 must be the plain two-step path."""

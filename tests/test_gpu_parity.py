@@ -214,6 +214,12 @@ def test_iterated_danse_extension(make_engine, K, M, L, n_fft, iters):
     print(pc.check_iterated_outputs(make_engine, K, M, L, n_fft, iters))
 
 
+def test_c5_full_length_rooms(make_engine):
+    """BASELINE.json configs[4] at full shape and length (8 x 8, 1024-point, L = 160000, 2 iterations), rooms 0 / 100 / 199 of the
+    bench's batch, 1e-4 against the float64 oracle."""
+    print(pc.check_c5_full_length(make_engine))
+
+
 @pytest.mark.parametrize('scene', ['k2m2', 'k4m4'])
 def test_tango_vs_reference_golden(make_engine, golden_dir, scene):
     """HIP path against outputs of the REFERENCE'S OWN offline_tango on the short scenes (tests/golden/tango_ref_*.npz, 17-25

@@ -1,6 +1,6 @@
 """C5 (200 rooms x 8 x 8, 1024-pt, 2 iterations) on ONE batch under several kernel routes: ms per step, stage times, and the error of sampled
 rooms against the float64 oracle (computed once, in worker processes, while the GPU runs the variants).  Test / measurement tooling.
-Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [variants=room_sub:cov1_sub:cov_chunks:room_flush,...] [sample=0,100,199]"""
+Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [variants=room_sub:cov1_mode:cov_chunks:unused,...] [sample=0,100,199]"""
 import json
 import os
 import sys
@@ -54,10 +54,9 @@ def main():
     res = {'rooms': R, 'shape': [K, M, N], 'iters': iters, 'steps': steps, 'variants': {}}
     got = {}
     for rs, cs, ch, nf in variants:
-        name = f'room_sub={rs},cov1_sub={cs},cov_chunks={ch},room_flush={nf}'
+        name = f'room_sub={rs},cov1_mode={cs},cov_chunks={ch}'
         eng.set_option('room_sub', rs)
-        eng.set_option('room_flush', nf)
-        eng.set_option('cov1_sub', cs)
+        eng.set_option('cov1_mode', cs)
         eng.set_tuning(0, ch, 0, 0)
         if eng.workspace_bytes() > ws.numel():
             ws = torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)
