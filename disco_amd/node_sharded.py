@@ -99,7 +99,14 @@ def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, g
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         # concatenated-along-dim-0 form: the one every backend (RCCL, gloo) accepts
-        dist.all_gather_into_tensor(torch.view_as_real(parts).view(W * R, Kl, eng.T, eng.F, 2), torch.view_as_real(z), group=group)
+        if z.is_cuda and dist.get_backend(group) == 'gloo':
+            # functional tests of the N-rank data flow on a box with ONE GPU (bench.py --dist-backend gloo --single-device): gloo gathers
+            # host tensors only, so this path -- never the measured one -- stages the blocks through the host
+            host = torch.empty((W * R, Kl, eng.T, eng.F, 2), dtype=torch.float32)
+            dist.all_gather_into_tensor(host, torch.view_as_real(z).cpu(), group=group)
+            torch.view_as_real(parts).view(W * R, Kl, eng.T, eng.F, 2).copy_(host)
+        else:
+            dist.all_gather_into_tensor(torch.view_as_real(parts).view(W * R, Kl, eng.T, eng.F, 2), torch.view_as_real(z), group=group)
         if timed:
             e1.record()
             gather_events.append((e0, e1))

@@ -1085,9 +1085,76 @@ def check_reference_scene_per_bin(make_engine, golden_dir, idx, staged=False, ma
             if (~ok[k]).any():
                 res['ref_excluded'] = max(res['ref_excluded'], float(e_ref[~ok[k]].max()))
             res['ref_kept_signal'] = max(res['ref_kept_signal'], relerr(got[ok[k]], ref[ok[k]]))       # all kept bins as one signal
+            res['ref_whole_signal'] = max(res.get('ref_whole_signal', 0.0), relerr(got, ref))            # ALL bins, kept or not, as one signal
     assert res['ref_kept'] < tol_bin and res['ref_kept_signal'] < tol, res
     assert res['f64_kept'] < tol and res['f64_signal'] < tol and res['f64_worst_bin'] < 2e-3, res
+    # backstop on everything at once: the whole signal, excluded bins included, against the reference's own output.  Documented bound
+    # 5e-3: on the excluded bins of these 201-frame scenes the REFERENCE is up to 2e-2 per bin from the exact solution of its own
+    # algorithm (make_golden_scenes.py prints it), which is 1-3e-3 of a whole signal; the full-length scenes
+    # (check_baseline_shape_reference) have no excluded bins and are held to 1e-4 on the whole signal.
+    assert res['ref_whole_signal'] < 5e-3, res
     return res
+
+
+def _load_baseline_shapes_module(golden_dir):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('make_golden_baseline_shapes', os.path.join(golden_dir, 'make_golden_baseline_shapes.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def baseline_shape_inputs(golden_dir, name):
+    """Inputs of one BASELINE-shaped scene of tests/golden/tango_ref_baseline_shapes.npz ('c3': 4 x 4, 'c2': 1 x 4; L = 160 000), regenerated
+    from the bench's room generator and checked against the SHA-256 the fixture carries -> (g, y, s, n) with [node](M, L) lists."""
+    import os
+    mb, ms = _load_baseline_shapes_module(golden_dir), _load_scenes_module(golden_dir)
+    g = np.load(os.path.join(golden_dir, 'tango_ref_baseline_shapes.npz'))
+    y, s, n = mb.inputs(name)
+    assert ms.checksum(y, s, n) == str(g[f'{name}_sha']), 'the regenerated inputs differ from the ones the reference was run on'
+    return g, y, s, n
+
+
+def check_baseline_shape_reference(make_engine, golden_dir, name, staged=False, tol=1e-4, tol_bin=2e-4):
+    """The HIP path against the REFERENCE'S OWN offline_tango (tango.py:252-457) at BASELINE.json's shape and length: one room of C3
+    (4 nodes x 4 mics, L = 160 000, T = 626) or of C2 (1 node x 4 mics), the bench's own synthetic room (make_golden_baseline_shapes.py).
+    With 626 frames NO (node, bin) is beyond the sensitivity cut of make_golden_scenes.py (the 201-frame scenes lose 16-49 %), so the
+    comparison is on everything: z_y and yf of every node as WHOLE SIGNALS within 1e-4 of the reference's output, every single bin
+    within 2e-4 (the reference's own complex64 rounding is part of a per-bin figure), and the same against the float64 restatement.
+    Returns the numbers, among them the excluded share (asserted 0) and the whole-signal error against the reference."""
+    ms = _load_scenes_module(golden_dir)
+    g, y, s, n = baseline_shape_inputs(golden_dir, name)
+    K, M, L = int(g[f'{name}_K']), int(g[f'{name}_M']), int(g['L'])
+    y, s, n = np.stack(y)[None], np.stack(s)[None], np.stack(n)[None]
+    eng = make_engine(rooms=1, nodes=K, mics=M, length=L, staged_step2=staged)
+    m = eng.mask_oracle(s[0, :, 0], n[0, :, 0]).reshape(1, K, eng.T, eng.F)
+    out, z, yf = eng.tango_enhance(y, m)
+    z, yf = z.numpy()[0], yf.numpy()[0]
+    ok = ms.kappa(g[f'{name}_cond1'], g[f'{name}_gap1'], g[f'{name}_cond2'], g[f'{name}_gap2']) <= float(g['kappa_cut'])
+    res = {'excluded_share': float((~ok).mean()), 'ref_signal': 0.0, 'ref_worst_bin': 0.0, 'f64_signal': 0.0, 'f64_worst_bin': 0.0}
+    assert res['excluded_share'] == 0.0, res
+    o = to.offline_tango_vec(y[0], s[0], n[0], vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+    for k in range(K):
+        for nm, got in (('z_y', z[k].T), ('yf', yf[k].T)):
+            ref = g[f'{name}_{nm}{k}']
+            res['ref_signal'] = max(res['ref_signal'], relerr(got, ref))
+            res['ref_worst_bin'] = max(res['ref_worst_bin'], float(_per_bin_err(got, ref).max()))
+            res['f64_signal'] = max(res['f64_signal'], relerr(got, o[nm][k]))
+            res['f64_worst_bin'] = max(res['f64_worst_bin'], float(_per_bin_err(got, o[nm][k]).max()))
+    assert res['ref_signal'] < tol and res['ref_worst_bin'] < tol_bin and res['f64_signal'] < tol and res['f64_worst_bin'] < tol_bin, res
+    return res
+
+
+def check_baseline_shape_surface(offline_tango, golden_dir, name, tol=1e-4):
+    """The Python call surface (`offline_tango`, the reference's own signature) on a BASELINE-shaped room: the nine outputs' z_y and yf
+    as whole signals within 1e-4 of the REFERENCE'S OWN output, no oracle in between, nothing excluded."""
+    g, y, s, n = baseline_shape_inputs(golden_dir, name)
+    K = int(g[f'{name}_K'])
+    res = offline_tango(y, s, n, vads=['irm1', 'irm1'], mods=[None, None])
+    worst = max(relerr(np.asarray(res[i][k]), g[f'{name}_{nm}{k}']) for k in range(K) for i, nm in ((0, 'yf'), (3, 'z_y')))
+    assert worst < tol, worst
+    return worst
 
 
 def check_short_reference_scene_per_bin(make_engine, golden_dir, scene, kappa_cut=2e3, tol=1e-4, tol_bin=2e-4):

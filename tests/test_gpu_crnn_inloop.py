@@ -98,3 +98,32 @@ def test_offline_tango_with_crnn_masks(two_models):
         assert max(np.abs(ref_mw[k].T - mw[k]).max() for k in range(K)) < 2e-3
     else:
         assert all(np.array_equal(mw[k], mz[k]) for k in range(K))
+
+
+@pytest.mark.parametrize('tag,n_ch', [('sc', 1), ('mc', 4)])
+@pytest.mark.parametrize('ftp,nt', [('mid', None), ('last', None), ('mid', 'scale_to_unit_norm'), ('mid', 'scale_to_1'), ('last', 'center_and_scale')])
+def test_predict_masks_on_gpu_vs_reference_fixture(golden_dir, tag, n_ch, ftp, nt):
+    """predict_masks on the MI355X -- the path with the HIP helpers disco_crnn_windows / disco_gru_gates / disco_maxpool_last4 active --
+    DIRECTLY against the outputs of the reference's own model / prepare_data / reshape_mask (dnn/models/crnn.py:55-63,
+    speech_enhancement/utils.py:69-138; tests/golden/crnn_ref.npz, crnn_variants_ref.npz): one link, no CPU evaluation in between
+    (VERDICT round 3, item 5 of "what's missing").  2e-5 on masks in [0, 1]: float32 GEMMs / convolutions of another library."""
+    import os
+    import torch
+    from disco_amd.dnn.crnn import build_crnn
+    gold = np.load(os.path.join(golden_dir, 'crnn_ref.npz'))
+    var = np.load(os.path.join(golden_dir, 'crnn_variants_ref.npz'))
+    sd = {k[len(tag) + 4:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(f'{tag}_sd_')}
+    dev = torch.device('cuda', 0)
+    model = build_crnn(n_ch=n_ch, state_dict=sd).to(dev).eval()
+    chans = [np.abs(gold[f'{tag}_Y'])]
+    if n_ch > 1:
+        chans += [np.abs(z) for z in gold[f'{tag}_Z']]
+    mag = torch.from_numpy(np.stack(chans)[None].transpose(0, 1, 3, 2).copy()).to(dev)          # (1, n_ch, T, F)
+    mask = model.predict_masks(mag, frame_to_pred=ftp, norm_type=nt)
+    assert mask.is_cuda
+    mask = mask.cpu().numpy()[0]
+    ref = gold[f'{tag}_mask'] if (ftp == 'mid' and nt is None) else var[f'{tag}_{ftp}_{nt}']    # (F, T)
+    assert mask.shape == ref.T.shape
+    err = float(np.abs(mask - ref.T).max())
+    assert err < 2e-5, err
+    print(tag, ftp, nt, 'max |mask - reference|', err)

@@ -237,6 +237,14 @@ def test_reference_run_scenes_per_bin(make_engine, golden_dir, idx, staged):
     print(pc.check_reference_scene_per_bin(make_engine, golden_dir, idx, staged=staged))
 
 
+@pytest.mark.parametrize('name,staged', [('c3', False), ('c3', True), ('c2', False)])
+def test_baseline_shapes_vs_reference(make_engine, golden_dir, name, staged):
+    """BASELINE.json's own shapes at full length (4 x 4 and 1 x 4, L = 160 000, 626 frames) run through the REFERENCE'S offline_tango
+    (tests/golden/make_golden_baseline_shapes.py): fused and staged routes, whole signals at 1e-4 against the reference, every bin at
+    2e-4, no bin excluded."""
+    print(name, 'staged' if staged else 'fused', pc.check_baseline_shape_reference(make_engine, golden_dir, name, staged=staged))
+
+
 def test_full_size_properties(make_engine):
     """Size-independent properties at the benchmark's per-room size, many rooms: (i) linearity of the filter stage
     -- apply(X, w) is linear in X; (ii) iSTFT(STFT(x)) == x; (iii) the MWF output is invariant to a common

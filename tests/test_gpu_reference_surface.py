@@ -201,3 +201,12 @@ def test_reference_run_scenes_per_bin_1e4(golden_dir, idx):
     from disco_amd.speech_enhancement.tango import offline_tango
     import parity_checks as pc
     print(pc.check_reference_surface_scene_per_bin(offline_tango, golden_dir, idx))
+
+
+@pytest.mark.parametrize('name', ('c3', 'c2'))
+def test_baseline_shapes_surface_vs_reference(golden_dir, name):
+    """offline_tango (the reference's signature) on a C3-shaped and a C2-shaped room at full length against the REFERENCE'S OWN outputs
+    (tests/golden/tango_ref_baseline_shapes.npz): whole signals at 1e-4, nothing excluded."""
+    from disco_amd.speech_enhancement.tango import offline_tango
+    import parity_checks as pc
+    print(name, pc.check_baseline_shape_surface(offline_tango, golden_dir, name))

@@ -80,3 +80,30 @@ def test_bench_two_ranks_bookkeeping_on_one_gpu():
         assert len(v['seconds_per_rank']) == 2 and v['parity_sample']['ok'] and len(v['parity_sample']['ranks']) == 2, nm
         units = 2 * v['config']['rooms_per_gpu'] * v['config']['nodes'] * v['config']['frames'] * v['steps']
         assert abs(v['value'] - units / max(v['seconds_per_rank'])) < 1e-6 * v['value'], nm
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('shard', ['rooms', 'nodes'])
+def test_bench_eight_ranks_bookkeeping_on_one_gpu(shard):
+    """The 8-rank job the driver's scaling run starts, on a box with ONE GPU: eight self-launched ranks, all computing on cuda:0, the
+    collectives over gloo (`--dist-backend gloo --single-device`; functional, not a measurement -- RCCL with more than one rank has never
+    run in this project).
+      rooms: every rank owns its own 2 rooms (first_room = 2 rank) and checks a room of its OWN batch; the line carries eight parity rows.
+      nodes: 8 nodes, ONE per rank (the exchange DISCO's algorithm performs): every step-2 pass all-gathers z over the eight ranks and
+             consumes it rank-major ([W][R][1][T][F], disco_set_z_blocks); every rank checks its node against the oracle of the WHOLE room."""
+    common = ['--gpus', '8', '--dist-backend', 'gloo', '--single-device', '--rooms', '2', '--length', '24000', '--steps', '1', '--warmup', '1',
+              '--extras', 'none', '--no-cpu-baseline']
+    if shard == 'rooms':
+        d = _run_bench(common, timeout=1400)
+        ps = d['parity_sample']
+        assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and len(ps['ranks']) == 8
+        assert [r['first_room'] for r in ps['ranks']] == [2 * r for r in range(8)]
+        for r in ps['ranks']:
+            assert all(2 * r['rank'] <= x < 2 * r['rank'] + 2 for x in r['rooms_checked']), r
+    else:
+        d = _run_bench(common + ['--shard', 'nodes', '--nodes', '8', '--mics', '2'], timeout=1400)
+        ps = d['parity_sample']
+        assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and len(ps['ranks']) == 8
+        assert d['exchange']['gathers_per_step'] == 1 and d['exchange']['bytes_per_peer_link_per_gather'] == 2 * 1 * d['config']['frames'] * 257 * 8
+        assert '1 per rank' in d['config']['parallelism']
+    assert ps['ok'] and ps['worst_rel_all_ranks'] < 1e-4, ps

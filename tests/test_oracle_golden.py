@@ -183,3 +183,24 @@ def test_ivad_oracle_matches_reference(golden_dir):
     for i, nm in enumerate(names):
         for k in range(K):
             assert np.array_equal(np.asarray(lit[i][k]), g[f'{nm}{k}']), (nm, k)
+
+
+def test_literal_port_is_bit_identical_at_baseline_shape(golden_dir):
+    """The literal port against the reference's own offline_tango on a C2-shaped room at FULL length (1 node x 4 mics, 626 frames;
+    tests/golden/make_golden_baseline_shapes.py): bit for bit, as on the short scenes."""
+    import parity_checks as pc
+    g, y, s, n = pc.baseline_shape_inputs(golden_dir, 'c2')
+    res = to.offline_tango_literal(y, s, n, vads=['irm1', 'irm1'])
+    assert np.array_equal(res[0][0], g['c2_yf0']) and np.array_equal(res[3][0], g['c2_z_y0'])
+
+
+def test_vectorised_oracle_at_baseline_shape(golden_dir):
+    """The float64 restatement against the reference's own output on a C3-shaped room at full length (4 x 4, 626 frames): with that
+    many frames the reference's complex64 arithmetic resolves its own algorithm to 2e-6 on the whole signal -- the float64 oracle the GPU
+    tests use IS the reference at this shape, to that accuracy."""
+    import parity_checks as pc
+    g, y, s, n = pc.baseline_shape_inputs(golden_dir, 'c3')
+    o = to.offline_tango_vec(y, s, n, vads=['irm1', 'irm1'], precision='f64', solver='eigh')
+    worst = max(relerr(o[nm][k], g[f'c3_{nm}{k}']) for k in range(4) for nm in ('yf', 'z_y'))
+    assert worst < 1e-5, worst
+    print('float64 restatement vs reference, C3 shape, whole signals:', worst)
