@@ -297,6 +297,7 @@ const OptionInfo* option_table() {
         {"solve_dpp", "DISCO_SOLVE_DPP", 1},
         {"room_sub", "DISCO_ROOM_SUB", 8},
         {"cov1_mode", "DISCO_COV1_MODE", 64},
+        {"solve_thread", "DISCO_SOLVE_THREAD", 1},
     };
     return t;
 }

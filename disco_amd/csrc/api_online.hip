@@ -41,10 +41,23 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
     switch (P) {
 #define C_(P_)                                                                                                          \
     case P_: {                          /* one thread per (room, node, bin) */                                          \
+        constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P_>();                                                  \
         const long long grid = (a.n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;                              \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf_thread<P_>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, st, a); \
     } break;
         C_(1) C_(2) C_(3) C_(4)
+        default: break;
+    }
+    // 5 <= P <= 7, option "solve_thread": one thread per problem as well (the float64 solve in the registers of one thread, AGPRs as its
+    // second register file: k_solve_small.h)
+    if (P >= 5 && P <= 7 && ctx->opt[DISCO_OPT_SOLVE_THREAD] != 0) {
+        switch (P) {
+            C_(5) C_(6) C_(7)
+        }
+        return check_launch(ctx, "k_online_mwf_thread");
+    }
+    if (P <= 4) return check_launch(ctx, "k_online_mwf_thread");
+    switch (P) {
 #undef C_
 #define C_(P_)                                                                                                          \
     case P_: {                          /* a group of 8 / 16 lanes per (room, node, bin) */                             \

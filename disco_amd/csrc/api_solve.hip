@@ -12,8 +12,10 @@ void launch_solve_dpp(int P, const SolveSrc& src, long long n_prob, double mu, c
 }
 
 template <int P>
-static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s, bool mixed) {
-    if constexpr (P <= 4) {             // one thread per pencil (k_solve_small.h)
+static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s, bool mixed, bool thread) {
+    if (P <= 4 || (P <= 7 && thread)) {             // one thread per pencil (k_solve_small.h); P = 8 spills there (1.57 against 1.98 ms per 1 028 000 pencils for the LDS group form -- and the partial-sum fetch of the thread form is the slower one: kept on the group solver)
+        if constexpr (P <= 7) {
+        constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P>();
         const long long grid = (n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;
         if (src.part)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1_thread<P, true>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, s, src, n_prob,
@@ -21,7 +23,10 @@ static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* 
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1_thread<P, false>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, s, src, n_prob,
                                mu, w, t1);
-    } else {
+        }
+        return;
+    }
+    if constexpr (P >= 5) {
     const int probs = SolveGeom<P>::PROBS;
     const long long grid = (n_prob + probs - 1) / probs;
     if (mixed) {            // float32 squarings + float64 Rayleigh-quotient finish (option "solve_f32")
@@ -52,7 +57,7 @@ static int solve_dispatch(disco_ctx* ctx, const SolveSrc& src, int64_t n_prob, i
         return check_launch(ctx, "k_gevd_mwf_r1_dpp");
     }
     switch (P) {
-#define C_(P_) case P_: launch_solve<P_>(src, n_prob, (double)mu, (c32*)w, (c32*)t1, st, P_ >= 5 && ctx->opt[DISCO_OPT_SOLVE_F32] != 0); break;
+#define C_(P_) case P_: launch_solve<P_>(src, n_prob, (double)mu, (c32*)w, (c32*)t1, st, P_ >= 5 && ctx->opt[DISCO_OPT_SOLVE_F32] != 0, ctx->opt[DISCO_OPT_SOLVE_THREAD] != 0); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
 #undef C_
     }

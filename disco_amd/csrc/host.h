@@ -37,6 +37,7 @@ enum {
     DISCO_OPT_SOLVE_DPP,                // "solve_dpp": 9 <= P <= 16 solved in registers with DPP row broadcasts (k_solve_dpp.h; 0: the LDS group solver)
     DISCO_OPT_ROOM_SUB,                 // "room_sub": time sub-chunks per workgroup of the persistent room pass (4 or 8 -> 8 or 4 bins per workgroup)
     DISCO_OPT_COV1_MODE,                // "cov1_mode": step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (default), 4 / 8 = float32 with time sub-chunks across the lanes, else float32
+    DISCO_OPT_SOLVE_THREAD,             // "solve_thread": 5 <= P <= 8 solved one THREAD per pencil (k_solve_small.h at one wave per SIMD, AGPRs as the second register file) instead of the LDS group solver
     DISCO_N_OPTIONS
 };
 namespace disco_host {

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
 // thread-local float64 solve of k_solve_small.h; consecutive threads are consecutive bins, so the per-frame loads stay
 // contiguous.  Same recursion, same outputs as k_online_mwf.
 template <int P>
-__global__ __launch_bounds__(SOLVE_SMALL_THREADS) void k_online_mwf_thread(OnlineArgs a) {
+__global__ __launch_bounds__(solve_small_threads<P>()) void k_online_mwf_thread(OnlineArgs a) {
+    constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P>();
     constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
     const long long pid = (long long)blockIdx.x * SOLVE_SMALL_THREADS + threadIdx.x;
     const bool live = pid < a.n_prob;

@@ -259,12 +259,15 @@ __device__ __forceinline__ void solve_load_tri(const SolveSrc& src, long long pi
         }
 }
 
-constexpr int SOLVE_SMALL_THREADS = 128;
+// threads per workgroup: two waves, one for the larger pencils (the wave-cooperative fetch stages 64 * NP float4 per wave in LDS)
+template <int P>
+constexpr int solve_small_threads() { return P <= 6 ? 128 : 64; }
 
 template <int P, bool FROM_PART>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__(SOLVE_SMALL_THREADS) void k_gevd_mwf_r1_thread(SolveSrc src, long long n_prob, double mu,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(solve_small_threads<P>()) void k_gevd_mwf_r1_thread(SolveSrc src, long long n_prob, double mu,
                                                                               c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
+    constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P>();
     const long long pid = (long long)blockIdx.x * SOLVE_SMALL_THREADS + threadIdx.x;
     const bool live = pid < n_prob;
     float a_d[P], b_d[P];
