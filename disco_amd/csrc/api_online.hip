@@ -7,10 +7,15 @@ using namespace disco_host;
 
 // ---- online / adaptive mode ------------------------------------------------------------------------------
 
-extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const float* mask, int P,
-                                float lambda_cor, float mu, int update_every, float init_diag, disco_c32* out,
-                                disco_c32* w_last, disco_stream s) {
-    DISCO_ENTER(ctx);
+// frames: the walk of this call (see OnlineArgs): T frames, planes of Tx (X, from frame tx0) / Tm (Z, mask, out) frames; state / init / phase:
+// the resumable recursion of the streaming form (NULL / 0 / 0: a whole clip from Rss = 0, Rnn = init_diag I)
+struct OnlineWalk {
+    int T, Tx, tx0, Tm;
+    c32* state;
+    int init, phase;
+};
+static int online_mwf_walk(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const float* mask, int P, float lambda_cor, float mu,
+                           int update_every, float init_diag, disco_c32* out, disco_c32* w_last, const OnlineWalk& wk, disco_stream s) {
     const disco_cfg& c = ctx->cfg;
     if (!X || !mask || !out) return fail(ctx, DISCO_E_ARG, "disco_online_mwf: null argument");
     if (P != c.mics && P != c.mics + c.nodes - 1) return fail(ctx, DISCO_E_ARG, "disco_online_mwf: P must be mics or mics + nodes - 1");
@@ -27,7 +32,13 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
     a.K = c.nodes;
     a.Kl = ctx->Kl;
     a.k0 = ctx->k0;
-    a.T = ctx->T;
+    a.T = wk.T;
+    a.Tx = wk.Tx;
+    a.tx0 = wk.tx0;
+    a.Tm = wk.Tm;
+    a.state = wk.state;
+    a.init = wk.init;
+    a.phase = wk.phase;
     a.F = ctx->F;
     a.M = c.mics;
     a.update_every = update_every;
@@ -71,6 +82,14 @@ extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_
     return check_launch(ctx, "k_online_mwf");
 }
 
+extern "C" int disco_online_mwf(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const float* mask, int P,
+                                float lambda_cor, float mu, int update_every, float init_diag, disco_c32* out,
+                                disco_c32* w_last, disco_stream s) {
+    DISCO_ENTER(ctx);
+    const OnlineWalk wk{ctx->T, ctx->T, 0, ctx->T, nullptr, 0, 0};
+    return online_mwf_walk(ctx, X, Z, mask, P, lambda_cor, mu, update_every, init_diag, out, w_last, wk, s);
+}
+
 extern "C" int disco_tango_online(disco_ctx* ctx, const float* y, const float* mask_z, const float* mask_w, float lambda_cor,
                                   int update_every, float init_diag, float* out, disco_c32* z_y, disco_c32* yf,
                                   void* workspace, size_t workspace_bytes, disco_stream s) {
@@ -90,8 +109,124 @@ extern "C" int disco_tango_online(disco_ctx* ctx, const float* y, const float* m
     if ((rc = STAGE(ctx, s, "online1", disco_online_mwf(ctx, X, nullptr, mask_z, c.mics, lambda_cor, c.mu, update_every, init_diag, z, nullptr, s)))) return rc;
     if (c.nodes == 1 && mask_w == mask_z) {             // nothing to append: step 2 would repeat step 1
         if (yf) HIPCHK(ctx, hipMemcpyAsync(yf, z, (size_t)G * ctx->T * ctx->F * sizeof(c32), hipMemcpyDeviceToDevice, (hipStream_t)s));
-        return disco_istft(ctx, z, G, out, s);
+        return istft_any(ctx, z, G, out, c.length, ctx->T, s, true);
     }
     if ((rc = STAGE(ctx, s, "online2", disco_online_mwf(ctx, X, z, mask_w, c.mics + c.nodes - 1, lambda_cor, c.mu, update_every, init_diag, yo, nullptr, s)))) return rc;
-    return STAGE(ctx, s, "istft", disco_istft(ctx, yo, G, out, s));
+    return STAGE(ctx, s, "istft", istft_any(ctx, yo, G, out, c.length, ctx->T, s, true));       // one frame per transform: see k_istft
+}
+
+// ---- the online path as a STREAM: state in, state out (SURVEY 8f-2 "streaming latency instead of batch") -----------------------------
+// One call consumes n_hops hops of new samples per channel and emits every output sample that became final.  Frame t (centred at
+// sample t * hop) needs the samples up to t * hop + n_fft / 2, so after h hops of input the frames 0 ... h - 1 exist and the output samples
+// [0, (h - 1) hop) are final (a sample takes its two overlapping frames): the latency is one hop plus the chunk.  `last` adds the frame
+// centred at the end of the signal (its second half is the padding of the whole-clip transform) and flushes the rest.
+// What a call keeps for the next one lives in the CALLER'S state block: the last hop of samples of every channel (the first half of the
+// next frame), the last output spectrum (the first half of the next overlap-add), both smoothed matrices and the filter in force of every
+// (room, node, bin) of both steps.  The arithmetic per frame is that of disco_tango_online -- same kernels on a transform block of the
+// chunk's frames -- so N chunks reproduce one whole-clip call BIT FOR BIT (tests: check_online_stream).
+namespace {
+struct StreamLayout {
+    size_t tail, yf_last, st1, st2, total;
+};
+StreamLayout stream_layout(const disco_ctx* ctx) {
+    const disco_cfg& c = ctx->cfg;
+    const size_t G = (size_t)c.rooms * c.nodes, F = ctx->F, M = c.mics, P2 = c.mics + c.nodes - 1;
+    StreamLayout l;
+    size_t o = 0;
+    l.tail = o;
+    o += align_up(G * M * c.hop * sizeof(float));
+    l.yf_last = o;
+    o += align_up(G * F * sizeof(c32));
+    l.st1 = o;
+    o += align_up(G * F * (2 * M * M + M) * sizeof(c32));
+    l.st2 = o;
+    o += align_up(G * F * (2 * P2 * P2 + P2) * sizeof(c32));
+    l.total = o;
+    return l;
+}
+struct StreamWs {
+    size_t y, X, z, y2, total;
+};
+StreamWs stream_ws(const disco_ctx* ctx, int n_hops) {
+    const disco_cfg& c = ctx->cfg;
+    const size_t G = (size_t)c.rooms * c.nodes, F = ctx->F, M = c.mics, n = (size_t)n_hops;
+    StreamWs w;
+    size_t o = 0;
+    w.y = o;
+    o += align_up(G * M * (n + 1) * c.hop * sizeof(float));              // [last hop kept | new samples] per channel
+    w.X = o;
+    o += align_up(G * (n + 2) * F * M * sizeof(c32));                    // its transform block; afterwards [last spectrum kept | new spectra] per signal
+    w.z = o;
+    o += align_up(G * (n + 1) * F * sizeof(c32));                        // step 1's output of the call's frames
+    w.y2 = o;
+    o += align_up(G * (n + 1) * F * sizeof(c32));                        // step 2's
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t disco_online_state_bytes(const disco_ctx* ctx) { return ctx ? stream_layout(ctx).total : 0; }
+extern "C" size_t disco_online_stream_workspace_bytes(const disco_ctx* ctx, int max_hops) {
+    return (ctx && max_hops > 0) ? stream_ws(ctx, max_hops).total : 0;
+}
+
+extern "C" int disco_tango_online_stream(disco_ctx* ctx, const float* y_new, int n_hops, const float* mask_z, const float* mask_w,
+                                         float lambda_cor, int update_every, float init_diag, int64_t hops_before, int last, void* state,
+                                         float* out, void* workspace, size_t workspace_bytes, disco_stream s) {
+    DISCO_ENTER(ctx);
+    const disco_cfg& c = ctx->cfg;
+    if (!y_new || !mask_z || !mask_w || !out || !state || !workspace) return fail(ctx, DISCO_E_ARG, "disco_tango_online_stream: null argument");
+    if (n_hops < 1 || hops_before < 0 || update_every < 1)
+        return fail(ctx, DISCO_E_ARG, "disco_tango_online_stream: need n_hops >= 1, hops_before >= 0, update_every >= 1");
+    if (hops_before == 0 && n_hops < 2)
+        return fail(ctx, DISCO_E_ARG, "disco_tango_online_stream: the first call needs two hops (the transform's padding reflects the first half window)");
+    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_online_stream: node shard active");
+    const StreamWs w = stream_ws(ctx, n_hops);
+    if (workspace_bytes < w.total)
+        return fail(ctx, DISCO_E_ARG, "disco_tango_online_stream: workspace smaller than disco_online_stream_workspace_bytes(ctx, n_hops)");
+    const StreamLayout l = stream_layout(ctx);
+    const bool first = hops_before == 0;
+    const int H = c.hop, F = ctx->F, M = c.mics, P2 = c.mics + c.nodes - 1;
+    const int64_t G = (int64_t)c.rooms * c.nodes;
+    const int n_new = n_hops + (last ? 1 : 0);                       // frames this call completes: hops_before ... hops_before + n_new - 1
+    char* st = (char*)state;
+    char* ws = (char*)workspace;
+    float* tail = (float*)(st + l.tail);
+    c32* yf_last = (c32*)(st + l.yf_last);
+    float* ym = (float*)(ws + w.y);
+    disco_c32* X = (disco_c32*)(ws + w.X);
+    disco_c32* z = (disco_c32*)(ws + w.z);
+    hipStream_t hs = (hipStream_t)s;
+    // ---- the transform block: [kept hop | new samples] per channel (first call: the new samples alone -- the transform pads its start)
+    const int Lm = (first ? 0 : H) + n_hops * H;
+    const size_t rows = (size_t)G * M;
+    if (!first) HIPCHK(ctx, hipMemcpy2DAsync(ym, (size_t)Lm * 4, tail, (size_t)H * 4, (size_t)H * 4, rows, hipMemcpyDeviceToDevice, hs));
+    HIPCHK(ctx, hipMemcpy2DAsync(ym + (first ? 0 : H), (size_t)Lm * 4, y_new, (size_t)n_hops * H * 4, (size_t)n_hops * H * 4, rows,
+                                 hipMemcpyDeviceToDevice, hs));
+    const int Tb = 1 + Lm / H;                                       // frames of the block; this call's: [first ? 0 : 1, + n_new)
+    int rc = stft_any(ctx, ym, G, M, X, Lm, Tb, s);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(tail, (size_t)H * 4, y_new + (size_t)(n_hops - 1) * H, (size_t)n_hops * H * 4, (size_t)H * 4, rows,
+                                 hipMemcpyDeviceToDevice, hs));      // the next call's first half window
+    // ---- the two recursions, resumed from the caller's state (a filter update falls on the frames that are multiples of update_every)
+    const int phase = (int)((update_every - hops_before % update_every) % update_every);
+    OnlineWalk wk{n_new, Tb, first ? 0 : 1, n_new, (c32*)(st + l.st1), first ? 1 : 0, phase};
+    if ((rc = online_mwf_walk(ctx, X, nullptr, mask_z, M, lambda_cor, c.mu, update_every, init_diag, z, nullptr, wk, s))) return rc;
+    const c32* ynew = (const c32*)z;                                 // [G][n_new][F]: what is overlap-added
+    if (!(c.nodes == 1 && mask_w == mask_z)) {                       // (a single node under one mask: step 2 would repeat step 1)
+        disco_c32* y2 = (disco_c32*)(ws + w.y2);
+        wk.state = (c32*)(st + l.st2);
+        if ((rc = online_mwf_walk(ctx, X, z, mask_w, P2, lambda_cor, c.mu, update_every, init_diag, y2, nullptr, wk, s))) return rc;
+        ynew = (const c32*)y2;
+    }
+    // ---- overlap-add over [kept spectrum | new spectra] per signal: the samples between consecutive frame centres are final
+    const int Ty = n_new + (first ? 0 : 1);
+    c32* blk = (c32*)(ws + w.X);                                     // the transform block is dead now: the interleaved spectra go there
+    if (!first) HIPCHK(ctx, hipMemcpy2DAsync(blk, (size_t)Ty * F * 8, yf_last, (size_t)F * 8, (size_t)F * 8, (size_t)G, hipMemcpyDeviceToDevice, hs));
+    HIPCHK(ctx, hipMemcpy2DAsync(blk + (first ? 0 : F), (size_t)Ty * F * 8, ynew, (size_t)n_new * F * 8, (size_t)n_new * F * 8, (size_t)G,
+                                 hipMemcpyDeviceToDevice, hs));
+    if (Ty >= 2 && (rc = istft_any(ctx, (const disco_c32*)blk, G, out, (Ty - 1) * H, Ty, s, true))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(yf_last, (size_t)F * 8, ynew + (size_t)(n_new - 1) * F, (size_t)n_new * F * 8, (size_t)F * 8, (size_t)G,
+                                 hipMemcpyDeviceToDevice, hs));      // the next call's first half of the overlap
+    return 0;
 }

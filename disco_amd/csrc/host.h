@@ -220,6 +220,10 @@ int ensure_halves(disco_ctx* ctx);
 bool overlap_applies(const disco_ctx* ctx);
 int acquire_ws(disco_ctx* ctx, void* workspace, size_t workspace_bytes, const WsLayout& l, char** ws_out, const char* who);
 
+// transforms of signals of any length with the context's window / FFT size / padding (api_stft.hip)
+int stft_any(disco_ctx* ctx, const float* x, int64_t n_sig, int chans, disco_c32* X, int L, int T, disco_stream s);
+int istft_any(disco_ctx* ctx, const disco_c32* Z, int64_t n_sig, float* out, int L, int T, disco_stream s, bool solo);
+
 // stages (each leaves its partial sums pending in the context; see the definitions)
 int cov_finalize(disco_ctx* ctx, int chunks, int P, disco_c32* Rss, disco_c32* Rnn, disco_stream s);
 int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* Zs, const disco_c32* Zn, int mask_remote, int P,

@@ -35,6 +35,13 @@ struct OnlineArgs {
     long long n_prob;    // R * Kl * F
     int zblk;            // layout of Z: planes [K / zblk][R][zblk] (zblk = K: plain [R][K]; z_plane in common.h)
     long long R;
+    // A call walks frames [tx0, tx0 + T) of X (whose planes hold Tx frames) and frames [0, T) of Z / mask / out (planes of Tm frames): the
+    // whole-clip entry points pass Tx = Tm = T, tx0 = 0; the streaming form walks a chunk's frames inside a larger transform block.
+    int Tx, tx0, Tm;
+    // Resumable recursion (disco_tango_online_stream): state = c32 [n_prob][2 P P + P] -- both smoothed matrices, row-major, then the filter
+    // in force -- read at entry unless `init`, written at exit; `phase` = frames until the next filter update at entry.  NULL: not kept.
+    c32* state;
+    int init, phase;
 };
 
 #ifndef DISCO_ONLINE_WPE
@@ -58,10 +65,10 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
     const int M = a.M;
 
     // row c of v_t: local channels first, then the other nodes' z in node order (tango.py:150-153)
-    const c32* xb = a.X + ((g * a.T) * a.F + f) * (long long)M;
+    const c32* xb = a.X + ((g * a.Tx + a.tx0) * a.F + f) * (long long)M;
     const c32* zb = a.Z ? a.Z + f : nullptr;
-    const long long TF = (long long)a.T * a.F;
-    const float* mp = a.mask + (g * a.T) * a.F + f;
+    const long long TF = (long long)a.Tm * a.F;
+    const float* mp = a.mask + (g * a.Tm) * a.F + f;
 
     c32 rowA[P], rowB[P];
 #pragma unroll
@@ -71,7 +78,16 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
     }
     const float lam = a.lambda_cor, oml = 1.f - a.lambda_cor;
     c32 wj = make_float2(0.f, 0.f);
-    int until_update = 0;
+    c32* stp = a.state ? a.state + pc * (2 * P * P + P) : nullptr;
+    if (stp && !a.init && col) {                           // resume: the lane's rows of both matrices and its filter entry, bit for bit
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            rowA[c] = stp[j * P + c];
+            rowB[c] = stp[P * P + j * P + c];
+        }
+        wj = stp[2 * P * P + j];
+    }
+    int until_update = a.state ? a.phase : 0;
     for (int t = 0; t < a.T; ++t) {
         c32 v[P];
 #pragma unroll
@@ -115,9 +131,17 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
             orx += __shfl_xor(orx, off, G);
             oix += __shfl_xor(oix, off, G);
         }
-        if (live && j == 0) a.out[(g * a.T + t) * a.F + f] = make_float2(orx, oix);
+        if (live && j == 0) a.out[(g * a.Tm + t) * a.F + f] = make_float2(orx, oix);
     }
     if (col && a.w_last) a.w_last[pid * P + j] = wj;
+    if (stp && col) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            stp[j * P + c] = rowA[c];
+            stp[P * P + j * P + c] = rowB[c];
+        }
+        stp[2 * P * P + j] = wj;
+    }
 }
 
 // P <= 4: one thread per (room, node, bin) with both smoothed matrices in its registers (lower triangles, float32) and the
@@ -135,10 +159,10 @@ __global__ __launch_bounds__(solve_small_threads<P>()) void k_online_mwf_thread(
     const long long r = g / a.Kl;
     const int k = a.k0 + (int)(g % a.Kl);
     const int M = a.M;
-    const c32* xb = a.X + ((g * a.T) * a.F + f) * (long long)M;
+    const c32* xb = a.X + ((g * a.Tx + a.tx0) * a.F + f) * (long long)M;
     const c32* zb = a.Z ? a.Z + f : nullptr;
-    const long long TF = (long long)a.T * a.F;
-    const float* mp = a.mask + (g * a.T) * a.F + f;
+    const long long TF = (long long)a.Tm * a.F;
+    const float* mp = a.mask + (g * a.Tm) * a.F + f;
     float a_d[P], b_d[P];
     c32 a_o[NO], b_o[NO];
 #pragma unroll
@@ -152,7 +176,21 @@ __global__ __launch_bounds__(solve_small_threads<P>()) void k_online_mwf_thread(
     c32 wv[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) wv[i] = make_float2(0.f, 0.f);
-    int until_update = 0;
+    c32* stp = a.state ? a.state + pc * (2 * P * P + P) : nullptr;
+    if (stp && !a.init) {                                  // resume: the lower triangles (what this kernel keeps) and the filter, bit for bit
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            a_d[i] = stp[i * P + i].x;
+            b_d[i] = stp[P * P + i * P + i].x;
+            wv[i] = stp[2 * P * P + i];
+#pragma unroll
+            for (int c = 0; c < i; ++c) {
+                a_o[i * (i - 1) / 2 + c] = stp[i * P + c];
+                b_o[i * (i - 1) / 2 + c] = stp[P * P + i * P + c];
+            }
+        }
+    }
+    int until_update = a.state ? a.phase : 0;
     for (int t = 0; t < a.T; ++t) {
         c32 v[P];
 #pragma unroll
@@ -194,11 +232,27 @@ __global__ __launch_bounds__(solve_small_threads<P>()) void k_online_mwf_thread(
             orx += wv[i].x * v[i].x + wv[i].y * v[i].y;
             oix += wv[i].x * v[i].y - wv[i].y * v[i].x;
         }
-        if (live) a.out[(g * a.T + t) * a.F + f] = make_float2(orx, oix);
+        if (live) a.out[(g * a.Tm + t) * a.F + f] = make_float2(orx, oix);
     }
     if (live && a.w_last) {
 #pragma unroll
         for (int i = 0; i < P; ++i) a.w_last[pid * P + i] = wv[i];
+    }
+    if (live && stp) {                                     // both triangles (the upper one as the conjugate): the layout the group kernel keeps
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            stp[i * P + i] = make_float2(a_d[i], 0.f);
+            stp[P * P + i * P + i] = make_float2(b_d[i], 0.f);
+            stp[2 * P * P + i] = wv[i];
+#pragma unroll
+            for (int c = 0; c < i; ++c) {
+                const c32 sa = a_o[i * (i - 1) / 2 + c], sb = b_o[i * (i - 1) / 2 + c];
+                stp[i * P + c] = sa;
+                stp[c * P + i] = make_float2(sa.x, -sa.y);
+                stp[P * P + i * P + c] = sb;
+                stp[P * P + c * P + i] = make_float2(sb.x, -sb.y);
+            }
+        }
     }
 }
 

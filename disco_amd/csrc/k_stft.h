@@ -350,22 +350,27 @@ __device__ __forceinline__ float* istft_frame(IstftShared<N>& sh, int j) {
     return reinterpret_cast<float*>(sh.buf[j >> 1]) + (j & 1) * N;
 }
 
-template <int N>
+// SOLO: every wave inverts ONE frame per transform (the second slot of the pair stays empty) and a block owns STFT_WAVES frames.  Twice the
+// transforms -- but a frame's samples then depend on its own spectrum only, not at rounding level on the partner it shared a transform
+// with, which is what lets the STREAMING online path (disco_tango_online_stream) reproduce the whole-clip call bit for bit whatever the
+// chunking: both online entry points invert this way (their overlap-add is 1 % of their time).
+template <int N, bool SOLO = false>
 __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_istft(const c32* __restrict__ Z, float* __restrict__ out,
                                                             const float* __restrict__ win, const c32* __restrict__ tw,
                                                             int L, int T, int blocks_per_sig) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2;
+    constexpr int SEGS = SOLO ? STFT_WAVES - 1 : ISTFT_SEGS;
     __shared__ IstftShared<N> sh;
     for (int i = threadIdx.x; i < N; i += blockDim.x) sh.win[i] = win[i];
     const int wave = wave_id(), lane = threadIdx.x & 63;
     WaveTw<N> wtw;
     wtw.init(tw, lane);
     const long long g = blockIdx.x / blocks_per_sig;
-    const int seg0 = (int)(blockIdx.x % blocks_per_sig) * ISTFT_SEGS;       // first output segment == first frame
-    const int ta = seg0 + 2 * wave, tb = ta + 1;
+    const int seg0 = (int)(blockIdx.x % blocks_per_sig) * SEGS;             // first output segment == first frame
+    const int ta = SOLO ? seg0 + wave : seg0 + 2 * wave, tb = ta + 1;
     const c32* Za = Z + (g * T + ta) * (long long)F;
     const c32* Zb = Z + (g * T + tb) * (long long)F;
-    const bool has_a = ta < T, has_b = tb < T;
+    const bool has_a = ta < T, has_b = !SOLO && tb < T;
     // V[n] = A~[n] + i B~[n] with A~, B~ the Hermitian extensions; the inverse transform is conj(FFT(conj V)) / N
     c32 v[E];
 #pragma unroll
@@ -389,18 +394,19 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_istft(co
     fft_wave<N>(v, wtw, sh.buf[wave], lane);
     const float inv = 1.0f / N;
     __syncthreads();                                   // sh.win is loaded; every lane is past its last read of buf[wave]
-    float* fa = istft_frame<N>(sh, 2 * wave);
-    float* fb = istft_frame<N>(sh, 2 * wave + 1);
+    // frame slot of block-local frame j: SOLO keeps one frame per wave buffer, else two
+    auto frame = [&](int j) { return SOLO ? reinterpret_cast<float*>(sh.buf[j]) : istft_frame<N>(sh, j); };
+    float* fa = frame(SOLO ? wave : 2 * wave);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int n = lane + 64 * e;
         const float w = sh.win[n] * inv;
         fa[n] = v[e].x * w;                            // Re(conj(out)) =  out.x
-        fb[n] = -v[e].y * w;                           // Im(conj(out)) = -out.y
+        if constexpr (!SOLO) frame(2 * wave + 1)[n] = -v[e].y * w;       // Im(conj(out)) = -out.y
     }
     __syncthreads();
     float* o = out + g * (long long)L;
-    for (int i = threadIdx.x; i < ISTFT_SEGS * H; i += blockDim.x) {
+    for (int i = threadIdx.x; i < SEGS * H; i += blockDim.x) {
         const int j = i / H, n = i - j * H;
         const int seg = seg0 + j;
         const long long pos = (long long)seg * H + n;
@@ -408,7 +414,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES) void k_istft(co
             const float w0 = sh.win[H + n], w1 = sh.win[n];
             float wss = w0 * w0;
             if (seg + 1 < T) wss += w1 * w1;
-            float val = istft_frame<N>(sh, j)[H + n] + istft_frame<N>(sh, j + 1)[n];
+            float val = frame(j)[H + n] + frame(j + 1)[n];
             if (wss > 1.17549435e-38f) val /= wss;
             o[pos] = val;
         }

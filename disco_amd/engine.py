@@ -133,6 +133,13 @@ class Engine:
                                               z.ptr if z else None, yf.ptr if yf else None, None, 0, self.stream))
         return out, z, yf
 
+    def online_stream(self, lambda_cor=0.95, update_every=1, init_diag=1e-3):
+        """A stream of the online two-step path (disco_tango_online_stream): `push(y_new, mask_z, mask_w=None, last=False)` consumes the
+        next n_hops * hop samples of every channel, y_new (R, K, M, n_hops * hop), with the masks (R, K, n_new, F) of the frames it
+        completes (n_new = n_hops + last), and returns the (R, K, n_out) output samples that became final.  The state block is owned by
+        the returned object (caller-side memory as far as the library is concerned)."""
+        return _OnlineStream(self, lambda_cor, update_every, init_diag)
+
     def mask_ivad(self, s_ref):
         """s_ref (n_sig, L) float32 (target image at channel 0) -> 'ivad' mask (n_sig, T, F)   [tango.py:217-221]"""
         n_sig, Ls = s_ref.shape
@@ -537,3 +544,39 @@ class Engine:
         self._chk(self.lib.disco_tango_enhance(self.ctx, py, pmz, pmw, po, z.ptr if z else None, yf.ptr if yf else None,
                                                pws, wsb, self.stream))
         return out, z, yf
+
+
+class _OnlineStream:
+    def __init__(self, eng, lambda_cor, update_every, init_diag):
+        self.eng, self.par = eng, (float(lambda_cor), int(update_every), float(init_diag))
+        self.hops = 0
+        self.state = eng.empty((int(eng.lib.disco_online_state_bytes(eng.ctx)),), np.uint8)
+        self.ws = None
+
+    def frames_of(self, n_hops, last=False):
+        return n_hops + (1 if last else 0)
+
+    def push(self, y_new, mask_z, mask_w=None, last=False):
+        e = self.eng
+        R, K, M, n = y_new.shape
+        H = (e.F - 1)                                        # hop = n_fft / 2 = F - 1
+        assert (R, K, M) == (e.R, e.K, e.M) and n % H == 0 and n > 0
+        n_hops = n // H
+        n_new = n_hops + (1 if last else 0)
+        n_out = H * (n_new - (1 if self.hops == 0 else 0))
+        py, ky = e.to_device(np.ascontiguousarray(y_new) if isinstance(y_new, np.ndarray) else y_new, np.float32)
+        pmz, kmz = e.to_device(mask_z, np.float32)
+        if mask_w is None or mask_w is mask_z:
+            pmw, kmw = pmz, kmz
+        else:
+            pmw, kmw = e.to_device(mask_w, np.float32)
+        need = int(e.lib.disco_online_stream_workspace_bytes(e.ctx, n_hops))
+        if self.ws is None or self.ws.nbytes < need:
+            self.ws = e.empty((need,), np.uint8)
+        out = e.empty((R, K, max(n_out, 1)), np.float32)
+        lam, ue, idg = self.par
+        e._chk(e.lib.disco_tango_online_stream(e.ctx, py, n_hops, pmz, pmw, lam, ue, idg, self.hops, int(bool(last)), self.state.ptr, out.ptr,
+                                               self.ws.ptr, self.ws.nbytes, e.stream))
+        self.hops += n_hops
+        res = out.numpy()[:, :, :n_out]
+        return res

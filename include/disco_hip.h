@@ -364,6 +364,29 @@ int disco_tango_online(disco_ctx* ctx, const float* y, const float* mask_z, cons
                        float* out, disco_c32* z_y, disco_c32* yf,
                        void* workspace, size_t workspace_bytes, disco_stream s);
 
+/* The online two-step path as a STREAM -- state in, state out ("streaming latency instead of batch"; the reference's
+ * primitive is a one-frame update, se_utils/internal_formulas.py:84-103).  One call consumes n_hops hops of NEW samples per channel and
+ * emits every output sample that became final:
+ *   y_new    float [R][K][M][n_hops * hop]   the next samples of every channel (hops_before * hop samples went before them)
+ *   mask_z/w float [R][K][n_new][F]          masks of the frames this call completes, n_new = n_hops + (last ? 1 : 0): frame t (centred at
+ *                                            sample t * hop) needs the samples up to t * hop + n_fft / 2, so h hops of input complete the
+ *                                            frames 0 ... h - 1; `last` adds the frame centred at the end of the signal
+ *   out      float [R][K][n_out]             n_out = hop * (n_new - (hops_before == 0 ? 1 : 0)): the samples between the centres of the
+ *                                            frames completed so far are final -- the latency is one hop plus the chunk
+ *   state    caller-owned device block of disco_online_state_bytes(ctx): the last hop of samples of every channel, the last output
+ *            spectrum, both smoothed matrices and the filter in force of every (room, node, bin) of both steps.  Written by every call,
+ *            read by every call but the first (hops_before == 0, which needs n_hops >= 2).  Nothing of a stream lives in the context:
+ *            streams may be interleaved, moved between contexts of the same cfg, or checkpointed by copying the block.
+ *   workspace at least disco_online_stream_workspace_bytes(ctx, n_hops)
+ * The per-frame arithmetic is that of disco_tango_online (same kernels, on a transform block of the chunk's frames): N chunks reproduce one
+ * whole-clip call bit for bit.  lambda_cor / update_every / init_diag as disco_online_mwf (filter updates fall on frames t % update_every
+ * == 0 of the STREAM); mu from the cfg; cfg.length is not used. */
+size_t disco_online_state_bytes(const disco_ctx* ctx);
+size_t disco_online_stream_workspace_bytes(const disco_ctx* ctx, int max_hops);
+int disco_tango_online_stream(disco_ctx* ctx, const float* y_new, int n_hops, const float* mask_z, const float* mask_w,
+                              float lambda_cor, int update_every, float init_diag, int64_t hops_before, int last, void* state,
+                              float* out, void* workspace, size_t workspace_bytes, disco_stream s);
+
 /* ---- helper of the mask-estimation DNN, which otherwise stays in PyTorch-ROCm ------------------------------------
  * The pointwise half of one GRU step for n independent sequences (gate order r, z, n as torch.nn.GRU; the two matrix products
  * are the caller's GEMMs):  r = sigm(gi_r + gh_r), z = sigm(gi_z + gh_z), c = tanh(gi_n + r gh_n), h' = (1 - z) c + z h.

@@ -336,6 +336,10 @@ static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n 
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s_, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) std::memcpy((char*)d + r * dp, (const char*)s_ + r * sp, w);
+    return hipSuccess;
+}
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -318,6 +318,45 @@ def check_online_mwf(make_engine, R=2, K=3, M=2, L=6000, n_fft=512, update_every
     return errs
 
 
+def check_online_stream(make_engine, R=2, K=3, M=2, L=6144, n_fft=512, update_every=3, chunks=(2, 5, 1, 7, 3)):
+    """disco_tango_online_stream (state in, state out: the online path fed chunk by chunk) against disco_tango_online on the whole clip:
+    the same output samples BIT FOR BIT, whatever the chunking -- ragged chunk sizes (cycled from `chunks`, in hops), a one-hop chunk,
+    filter updates that fall inside chunks, the final call with and without new samples -- and the state block really carries everything
+    (a second stream interleaved on the same context does not disturb the first; a copy of the block resumes a stream)."""
+    from disco_amd import synth
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    H = n_fft // 2
+    assert L % H == 0
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    T, F = eng.T, eng.F
+    mask = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, T, F).numpy()
+    whole = eng.tango_online(y, mask, update_every=update_every, want_z=False, want_yf=False)[0].numpy()
+    n_hops_total = L // H
+
+    def run(sizes, interleave=None):
+        st = eng.online_stream(update_every=update_every)
+        other = eng.online_stream(update_every=update_every) if interleave else None
+        got, h, i = [], 0, 0
+        while h < n_hops_total:
+            c = min(sizes[i % len(sizes)], n_hops_total - h)
+            if h == 0:
+                c = max(c, 2)
+            i += 1
+            last = h + c == n_hops_total
+            got.append(st.push(y[..., h * H:(h + c) * H], mask[:, :, h:h + c + (1 if last else 0)], last=last))
+            if other is not None and h == 0:            # another stream of the same context in between: must not matter
+                other.push(0.5 * y[..., :c * H], mask[:, :, :c])
+            h += c
+        return np.concatenate(got, axis=-1)
+    res = {}
+    for name, sizes, inter in (('ragged', chunks, False), ('one_call', (n_hops_total,), False), ('interleaved', (4,), True), ('hop_by_hop', (1,), False)):
+        out = run(sizes, inter)
+        assert out.shape == whole.shape, (name, out.shape, whole.shape)
+        res[name] = float(np.abs(out - whole).max())
+        assert np.array_equal(out, whole), (name, res[name])
+    return res
+
+
 def check_metrics(make_engine, golden_dir, L_cut=None, start=0):
     """disco_amd.metrics (HIP moments + host dB arithmetic) against the reference's own metrics.py outputs
     (tests/golden/metrics_ref.npz) and against oracle/metrics_oracle.py on a sub-span (start > 0: the reference scores

@@ -105,6 +105,13 @@ def test_ivad(make_engine, golden_dir):
     pc.check_ivad(make_engine, golden_dir)
 
 
+@pytest.mark.parametrize('R,K,M,L,n_fft,U', [(3, 4, 4, 40960, 512, 1), (2, 3, 2, 20480, 512, 4), (1, 2, 8, 40960, 1024, 3), (2, 1, 4, 15360, 512, 2)])
+def test_online_stream_equals_whole_clip(make_engine, R, K, M, L, n_fft, U):
+    """disco_tango_online_stream: N chunks == one whole-clip call of disco_tango_online, bit for bit (state in / state out; the transform's
+    and the overlap-add's halves carried across chunks)."""
+    print(pc.check_online_stream(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft, update_every=U))
+
+
 def test_online_golden(make_engine, golden_dir):
     pc.check_online_golden(make_engine, golden_dir)
 

@@ -68,6 +68,12 @@ def test_emu_online_golden(make_engine, golden_dir):
     print(pc.check_online_golden(make_engine, golden_dir, t_max=5))
 
 
+def test_emu_online_stream(make_engine):
+    """The streaming form of the online path == the whole-clip call, bit for bit, for several chunkings (group and thread kernels)."""
+    print(pc.check_online_stream(make_engine, R=1, K=2, M=2, L=3072, update_every=3))
+    print(pc.check_online_stream(make_engine, R=1, K=4, M=4, L=2048, update_every=2, chunks=(3, 1, 2)))
+
+
 def test_emu_online_mwf(make_engine):
     print(pc.check_online_mwf(make_engine, R=1, K=2, M=2, L=1280, update_every=3))
 
