@@ -24,7 +24,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-f
 SCRATCH_LIMIT = {'k_room_cov_dma': 64, 'k_gevd_mwf_r1_dpp': 0}
 # units whose kernels read other lanes' registers through DPP inside inline asm (csrc/dpp64.h): hipcc cannot see those reads, so
 # the two DPP hazards (a VALU write of the source within 2 wait states, an EXEC write within 5) are checked on the device
-# assembly of the unit (tools/check_dpp_hazards.py) and a build with a hazard is refused
+# assembly of the unit (disco_amd/check_dpp_hazards.py) and a build with a hazard is refused
 DPP_UNITS = ('api_solve_dpp',)
 
 
@@ -41,8 +41,15 @@ def _newer(target, deps):
     return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
 
 
-def up_to_date():
-    return _newer(OUT, units() + headers())
+FLAG_STAMP = OUT + '.flags'     # the extra flags (DISCO_CXXFLAGS) the library at OUT was linked from: a variant build must not pass for the default one
+
+
+def _stamp():
+    return open(FLAG_STAMP).read() if os.path.exists(FLAG_STAMP) else ''
+
+
+def up_to_date(extra=()):
+    return _newer(OUT, units() + headers()) and _stamp() == ' '.join(extra)
 
 
 def _extra_flags():
@@ -78,12 +85,8 @@ def _compile(src, hipcc, extra, verbose):
 
 
 def _dpp_hazards(unit):
-    """Runs tools/check_dpp_hazards.py's check over the device listing --save-temps left beside the object; removes the other temporaries."""
-    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tools'))
-    try:
-        import check_dpp_hazards as chk
-    finally:
-        sys.path.pop(0)
+    """Runs check_dpp_hazards.py's check over the device listing --save-temps left beside the object; removes the other temporaries."""
+    from disco_amd import check_dpp_hazards as chk
     listing = os.path.join(OBJ, unit + '-hip-amdgcn-amd-amdhsa-gfx950.s')
     out, n_dpp = [], 0
     for name, lines in chk.kernels(open(listing).read()).items():
@@ -100,7 +103,7 @@ def _dpp_hazards(unit):
 
 def build_hip(force=False, verbose=True, jobs=None):
     extra = _extra_flags()
-    if not force and not extra and up_to_date():
+    if not force and up_to_date(extra):
         return OUT
     os.makedirs(OBJ, exist_ok=True)
     if force:
@@ -124,6 +127,7 @@ def build_hip(force=False, verbose=True, jobs=None):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    open(FLAG_STAMP, 'w').write(' '.join(extra))
     return OUT
 
 

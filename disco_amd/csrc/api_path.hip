@@ -77,23 +77,35 @@ int run_pipelined(disco_ctx* ctx, Steps (&steps)[2], disco_stream s) {
                 rc = run_step(ctx->half[h], steps[h][i], (disco_stream)(h ? s1 : s0));
                 if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", ctx->half[h]->err);
             }
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join, s1));
-        HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_join, 0));
+        const hipError_t e1 = hipEventRecord(ctx->ev_join, s1), e2 = hipStreamWaitEvent(s0, ctx->ev_join, 0);       // the join, whatever happened above
+        if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) {
+            snprintf(ctx->err, sizeof(ctx->err), "joining the side stream failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            rc = DISCO_E_HIP_BASE - (int)(e1 != hipSuccess ? e1 : e2);
+        }
         return rc;
     }
+    // a HIP failure inside the loop is collected, not returned: the join below must be reached whatever happened, or the caller's
+    // stream stays forked (and a capture unjoined)
+    auto hip = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && !rc) {
+            snprintf(ctx->err, sizeof(ctx->err), "%s failed: %s", what, hipGetErrorString(e));
+            rc = DISCO_E_HIP_BASE - (int)e;
+        }
+    };
     for (size_t i = 0; i < n && !rc; ++i)
         for (int h = 0; h < 2 && !rc; ++h) {
             disco_ctx* ch = ctx->half[h];
             Step& x = steps[h][i];
             hipStream_t cur = x.side ? s1 : s0;
-            if (i > 0 && steps[h][i - 1].side != x.side) HIPCHK(ctx, hipStreamWaitEvent(cur, ctx->step_events[2 * (i - 1) + h], 0));
+            if (i > 0 && steps[h][i - 1].side != x.side) hip(hipStreamWaitEvent(cur, ctx->step_events[2 * (i - 1) + h], 0), "hipStreamWaitEvent");
+            if (rc) break;
             rc = run_step(ch, x, (disco_stream)cur);
             if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", ch->err);
             // the child's next step runs on the other stream: mark the end of this one there
-            if (!rc && i + 1 < n && steps[h][i + 1].side != x.side) HIPCHK(ctx, hipEventRecord(ctx->step_events[2 * i + h], cur));
+            if (!rc && i + 1 < n && steps[h][i + 1].side != x.side) hip(hipEventRecord(ctx->step_events[2 * i + h], cur), "hipEventRecord");
         }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, s1));             // joined even after a failure: the caller's stream must not be left forked
-    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_join, 0));
+    hip(hipEventRecord(ctx->ev_join, s1), "hipEventRecord");    // joined even after a failure: the caller's stream must not be left forked
+    hip(hipStreamWaitEvent(s0, ctx->ev_join, 0), "hipStreamWaitEvent");
     return rc;
 }
 

@@ -1,12 +1,11 @@
-"""tools/check_dpp_hazards.py -- the check disco_amd/build.py runs on the device listing of the units that read other lanes' registers through
+"""disco_amd/check_dpp_hazards.py -- the check disco_amd/build.py runs on the device listing of the units that read other lanes' registers through
 DPP inside inline asm (csrc/dpp64.h): it must flag both hazards hipcc cannot see there, and accept the sequences the helpers emit."""
 import os
 import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
-import check_dpp_hazards as chk     # noqa: E402
+from disco_amd import check_dpp_hazards as chk
 
 DPP = '\tv_fmac_f64_dpp v[0:1], -v[2:3], v[8:9] row_newbcast:3 row_mask:0xf bank_mask:0xf'
 
