@@ -101,69 +101,6 @@ __device__ __forceinline__ void dftR(c32* u) {
     else dft16(u);
 }
 
-// ---- 512 points with ONE trip through LDS ------------------------------------------------------------------------------
-// Measured on the MI355X (tools/gpu/kbench/fft_rate.hip): the two LDS exchanges of the Stockham schedule below cost 275 ns per
-// transform and SIMD, the butterflies 250 ns -- the wave transforms are LDS-BANDWIDTH-bound (118 of the CU's 128 B/clk).
-// fft_wave_xlane runs the same three radix-8 passes as a decimation in frequency on n = 64 n2 + 8 n1 + n0 (slot = n2,
-// lane = 8 n1 + n0), k = k0 + 8 k1 + 64 k2:
-//   pass 1 over the slots (n2 -> k0), twiddle W_512^(k0 lane);
-//   8 x 8 transpose between the slot index and lane bits 5:3 WITHOUT LDS: v_permlane32_swap / v_permlane16_swap (the 2 x 2 block
-//   transposes of gfx950) for lane bits 5 and 4, a DPP row rotate by 8 with bank masks for lane bit 3  (slot = n1, lane = 8 k0 + n0);
-//   pass 2 over the slots (n1 -> k1), twiddle W_64^(k1 n0);
-//   one LDS exchange that also undoes the digit order (lane = k0 + 8 k1, slot = n0);
-//   pass 3 over the slots (n0 -> k2): lane holds X[lane + 64 slot], the natural order of fft_wave.
-// MEASURED SLOWER and therefore off: 408 ns per transform and SIMD at 4 waves/SIMD against 363 ns for the Stockham schedule
-// (442 vs 390 at 3 waves): the 16 permlane swaps + 16 DPP moves cost more VALU time than the LDS exchange they replace
-// frees.  Kept (checked against the oracle on the emulated build, and on the MI355X by fft_rate's check) as the record of it.
-#ifndef DISCO_FFT_XLANE
-#define DISCO_FFT_XLANE 0
-#endif
-template <int N>
-constexpr bool fft_xlane_plan() { return DISCO_FFT_XLANE && N == 512; }
-
-// 2 x 2 transpose between two registers and lane bit BIT (8, 16 or 32): lanes with the bit set receive the partner's b in a,
-// lanes with it clear receive the partner's a in b (partner = lane ^ BIT).
-template <int BIT>
-__device__ __forceinline__ void xlane_swap(float& a, float& b, int lane) {
-#if defined(__clang__)
-    (void)lane;
-    if constexpr (BIT == 32) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        a = __uint_as_float(r[0]);
-        b = __uint_as_float(r[1]);
-    } else if constexpr (BIT == 16) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        a = __uint_as_float(r[0]);
-        b = __uint_as_float(r[1]);
-    } else {
-        static_assert(BIT == 8, "lane bit");
-        const int ai = __float_as_int(a), bi = __float_as_int(b);
-        // row_ror:8 (0x128): lane i of a 16-lane row reads lane i - 8 (mod 16); bank_mask picks lanes 8..15 (0xc) / 0..7 (0x3)
-        a = __int_as_float(__builtin_amdgcn_update_dpp(ai, bi, 0x128, 0xf, 0xc, false));
-        b = __int_as_float(__builtin_amdgcn_update_dpp(bi, ai, 0x128, 0xf, 0x3, false));
-    }
-#else
-    const float pa = __shfl_xor(a, BIT), pb = __shfl_xor(b, BIT);
-    if (lane & BIT) a = pb;
-    else b = pa;
-#endif
-}
-template <int BIT>
-__device__ __forceinline__ void xlane_swap(c32& a, c32& b, int lane) {
-    xlane_swap<BIT>(a.x, b.x, lane);
-    xlane_swap<BIT>(a.y, b.y, lane);
-}
-// slot index <-> lane bits 5:3
-__device__ __forceinline__ void xlane_transpose8(c32* v, int lane) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xlane_swap<32>(v[s], v[s + 4], lane);
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-        if ((s & 2) == 0) xlane_swap<16>(v[s], v[s + 2], lane);
-#pragma unroll
-    for (int s = 0; s < 8; s += 2) xlane_swap<8>(v[s], v[s + 1], lane);
-}
-
 // Per-lane twiddle factors of passes 2 and 3, gathered once per kernel from the N-entry table
 // tw[j] = exp(-2 pi i j / N): they depend on the lane only, so they live in registers for every transform
 // the wave performs (saves 14 LDS reads per 512-point transform and the LDS table itself).
@@ -175,14 +112,6 @@ struct WaveTw {
     c32 t1[Q1 * (Pl::R1 - 1)];
     c32 t2[Q2 * (Pl::R2 - 1)];
     __device__ __forceinline__ void init(const c32* __restrict__ tw, int lane) {
-        if constexpr (fft_xlane_plan<N>()) {      // decimation in frequency, see fft_wave_xlane
-#pragma unroll
-            for (int r = 1; r < 8; ++r) {
-                t1[r - 1] = tw[r * lane];                   // W_512^(k0 (8 n1 + n0))
-                t2[r - 1] = tw[8 * r * (lane & 7)];         // W_64^(k1 n0)
-            }
-            return;
-        }
         constexpr int P1 = Pl::R0, P2 = Pl::R0 * Pl::R1;
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
@@ -242,34 +171,12 @@ __device__ __forceinline__ void fft_pass(c32* v, const c32* tw, c32* buf, int la
 
 // Forward complex FFT of the wave's N points.  In: v[e] = x[lane + 64 e].  Out: v[e] = X[lane + 64 e].
 // `buf` = wave-private LDS of fft_buf_len<N>() c32.
-template <int N>
-__device__ __forceinline__ void fft_wave_xlane(c32* v, const WaveTw<N>& tw, c32* buf, int lane) {
-    static_assert(N == 512, "cross-lane plan: 512 points");
-    dft8(v);                                                     // n2 -> k0
-#pragma unroll
-    for (int r = 1; r < 8; ++r) v[r] = cmul_pk(v[r], tw.t1[r - 1]);
-    xlane_transpose8(v, lane);                                   // slot = n1, lane = 8 k0 + n0
-    dft8(v);                                                     // n1 -> k1
-#pragma unroll
-    for (int r = 1; r < 8; ++r) v[r] = cmul_pk(v[r], tw.t2[r - 1]);
-    DISCO_LDS_WAR();        // the previous user of `buf` is done in every lane
-    const int w0 = (lane >> 3) + 64 * (lane & 7);                // element (k0, n0; k1 = r) -> position k0 + 8 k1 + 64 n0
-#pragma unroll
-    for (int r = 0; r < 8; ++r) buf[fft_pad<N>(w0 + 8 * r)] = v[r];
-    DISCO_LDS_RAW();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = buf[fft_pad<N>(lane + 64 * e)];
-    DISCO_LDS_WAR();
-    dft8(v);                                                     // n0 -> k2: v[e] = X[lane + 64 e]
-}
-
+// (Two other plans were built, measured and are NOT here: an 8 x 8 register <-> lane transpose in place of one exchange -- 408 against
+// 363 ns per transform and SIMD --, and two transforms per wave at 16 points per lane with ONE exchange -- 347 against 363: the exchange halves,
+// the butterflies grow by a quarter.  Both live in tools/gpu/kbench/fft_plans.h with their numbers in profiles/r04_k_fft_rate_one_exchange.txt.)
 template <int N>
 __device__ __forceinline__ void fft_wave(c32* v, const WaveTw<N>& tw, c32* buf, int lane) {
     using Pl = FftPlan<N>;
-    if constexpr (fft_xlane_plan<N>()) {
-        fft_wave_xlane<N>(v, tw, buf, lane);
-        return;
-    }
     DISCO_LDS_WAR();        // the previous user of `buf` (an earlier item's untangle reads) is done in every lane
     fft_pass<N, Pl::R0, 1, true, false>(v, nullptr, buf, lane);
     fft_pass<N, Pl::R1, Pl::R0, false, false>(v, tw.t1, buf, lane);

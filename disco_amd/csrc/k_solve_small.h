@@ -290,15 +290,17 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(solve_small_threads<P>()) void k
                 const int e = lane + 64 * k, pe = e / NP, q = e % NP;     // element e of the wave's block belongs to lane pe's pencil
                 const long long o = ((long long)__shfl(off_hi, pe) << 32) | (unsigned)__shfl(off_lo, pe);
                 const float4* ptr = src.part + o + q;
-                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                // the chunk sums are combined in float64 and rounded ONCE, as in every other loader (k_solve.h, k_solve_dpp.h, k_cov_finalize)
+                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
                 for (int ch = 0; ch < src.chunks; ++ch) {
                     const float4 v = ptr[(long long)ch * src.F * NP];
-                    sum.x += v.x;
-                    sum.y += v.y;
-                    sum.z += v.z;
-                    sum.w += v.w;
+                    sx += (double)v.x;
+                    sy += (double)v.y;
+                    sz += (double)v.z;
+                    sw += (double)v.w;
                 }
-                s_tile[wv][e] = sum;
+                const double it = (double)src.inv_T;
+                s_tile[wv][e] = make_float4((float)(sx * it), (float)(sy * it), (float)(sz * it), (float)(sw * it));
             }
             DISCO_GROUP_SYNC();                                           // wave-local hand-over
 #pragma unroll
@@ -307,11 +309,11 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(solve_small_threads<P>()) void k
                 for (int k = 0; k <= i; ++k) {
                     const float4 v = s_tile[wv][lane * NP + (k * P - (k * (k - 1)) / 2 + (i - k))];      // stored (k, i): R[i][k] = conj
                     if (i == k) {
-                        a_d[i] = v.x * src.inv_T;
-                        b_d[i] = v.z * src.inv_T;
+                        a_d[i] = v.x;
+                        b_d[i] = v.z;
                     } else {
-                        a_o[i * (i - 1) / 2 + k] = make_float2(v.x * src.inv_T, -v.y * src.inv_T);
-                        b_o[i * (i - 1) / 2 + k] = make_float2(v.z * src.inv_T, -v.w * src.inv_T);
+                        a_o[i * (i - 1) / 2 + k] = make_float2(v.x, -v.y);
+                        b_o[i * (i - 1) / 2 + k] = make_float2(v.z, -v.w);
                     }
                 }
             loaded = true;
