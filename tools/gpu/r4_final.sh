@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round 4, FINAL-state pass on the committed sources: GPU suite, the plain bench line, kernel stats + HBM counters (+ calibration) of
+# C3 / C5 / C2 / C2x4000, SQ / LDS counters of C3 / C5, side lines (overlap off, node-sharded, online every 8).   Usage: r4_final.sh <tag>
+TAG=${1:-r04_m}
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+mkdir -p gpurun_out
+T0=$(date +%s)
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc $? ($(( $(date +%s) - T0 )) s)"; grep -E "passed|failed" gpurun_out/${TAG}_tests.log | tail -2; grep -E "^FAILED|^E  " gpurun_out/${TAG}_tests.log | head -10
+T1=$(date +%s)
+timeout 900 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc $? ($(( $(date +%s) - T1 )) s)"; tail -3 gpurun_out/${TAG}_bench_default.err
+python - <<PY
+import json
+d = json.loads(open('gpurun_out/${TAG}_bench_default.json').read().strip().splitlines()[-1])
+print('C3', round(d['ms_per_step'], 3), 'ms', d['roofline']['kernel'], d['roofline']['frac'], 'pipe', d['roofline']['pipeline']['frac'], 'parity', d['parity_sample'] and d['parity_sample']['worst_rel_all_ranks'], d['roofline'].get('sanity_errors'))
+print('   ', {s: x['ms'] for s, x in d['stages'].items()})
+for k, v in d.get('configs', {}).items():
+    if 'error' in v:
+        print(k, 'ERROR', v['error'][:300]); continue
+    rf = v.get('roofline') or {}
+    print(k, round(v['ms_per_step'], 3), 'ms', 'xRT', round(v['x_realtime'], 1), rf.get('kernel', '')[:40], rf.get('frac'), 'pipe', (rf.get('pipeline') or {}).get('frac'), 'parity', (v.get('parity_sample') or {}).get('worst_rel_all_ranks'), 'ok', (v.get('parity_sample') or {}).get('ok'), rf.get('sanity_errors'))
+    print('   ', {s: x['ms'] for s, x in (v.get('stages') or {}).items()})
+PY
+bash tools/profile_round.sh ${TAG}_C3 2>&1 | tail -9
+bash tools/profile_round.sh ${TAG}_C5 --config C5 2>&1 | tail -12
+bash tools/profile_round.sh ${TAG}_C2 --config C2 2>&1 | tail -6
+bash tools/profile_round.sh ${TAG}_C2x4000 --config C2 --rooms 4000 2>&1 | tail -6
+BARGS="" bash tools/gpu/pmc_alu.sh ${TAG}_C3 2>&1 | grep -E "rc|disco::" | cut -c1-400
+BARGS="--config C5" bash tools/gpu/pmc_alu.sh ${TAG}_C5 2>&1 | grep -E "rc|disco::" | cut -c1-400
+DISCO_OVERLAP_SOLVES=0 timeout 300 python bench.py --extras none --no-cpu-baseline > gpurun_out/${TAG}_bench_C3_overlap0.json 2>/dev/null
+timeout 300 python bench.py --shard nodes --rooms 250 --extras none --no-cpu-baseline > gpurun_out/${TAG}_bench_nodeshard.json 2>/dev/null
+timeout 300 python bench.py --rooms 1000 --online-every 8 --steps 2 --warmup 1 --extras none --no-cpu-baseline > gpurun_out/${TAG}_bench_online8.json 2>/dev/null
+python - <<PY
+import json
+for n in ('C3_overlap0', 'nodeshard', 'online8'):
+    try:
+        d = json.loads(open(f'gpurun_out/${TAG}_bench_{n}.json').read().strip().splitlines()[-1])
+        print(n, round(d['ms_per_step'], 3), 'ms xRT', round(d['x_realtime'], 1), 'parity', (d.get('parity_sample') or {}).get('worst_rel_all_ranks'))
+    except Exception as e:
+        print(n, 'failed', e)
+PY
+echo "total $(( $(date +%s) - T0 )) s"
