@@ -55,9 +55,11 @@ CONFIGS = {
 }
 # what the plain command runs after the headline (name -> workload, steps, warmup, rooms rank 0 checks against the oracle)
 EXTRAS = {
-    'C5': (dict(CONFIGS['C5']), 5, 2, 3),
-    'C2': (dict(CONFIGS['C2']), 10, 3, 3),
+    # (the launch-bound C2 first, right behind the headline: a 0.9 ms step does not survive the host being shared with the oracle
+    # workers of a wide-shape workload -- 2.8 instead of 0.87 ms behind C5's three 8 x 8 rooms)
+    'C2': (dict(CONFIGS['C2']), 30, 3, 3),
     'C2x4000': (dict(CONFIGS['C2'], rooms=4000), 5, 2, 2),
+    'C5': (dict(CONFIGS['C5']), 5, 2, 3),
     'C4': (dict(CONFIGS['C4']), 3, 1, 2),
     'C4_bf16': (dict(CONFIGS['C4'], dnn_dtype='bf16'), 3, 1, 2),      # the networks' convolutions / GEMMs on bf16 operands (explicit switch)
     'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 1),

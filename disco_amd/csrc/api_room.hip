@@ -59,7 +59,10 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
         a.tiles = (ctx->F + nb - 1) / nb;
         const long long items = (long long)c.rooms * a.tiles;
         if (items > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
-        const unsigned nwg = (unsigned)std::min<long long>(items, ctx->n_cu);               // one persistent workgroup per CU
+        // one persistent workgroup per CU; a whole number of 64-workgroup blocks when the batch allows it (the kernel then keeps neighbouring
+        // tiles on one XCD); a workgroup whose first item lies beyond the batch simply returns
+        unsigned nwg = (unsigned)std::min<long long>(items, ctx->n_cu);
+        if (items >= 64) nwg = std::max(64u, nwg / 64 * 64);
         const hipStream_t st = (hipStream_t)s;
         const bool ok = sub == 4 ? launch_room_s4(M, K, nwg, st, a) : launch_room_s8(M, K, nwg, st, a);
         if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: shape not instantiated");

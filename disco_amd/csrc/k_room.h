@@ -593,15 +593,28 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
 
     // ---- the pipeline over this workgroup's items blockIdx.x, + gridDim.x, ...  Three positions, one iteration apart: (Ii, ji) is
     // issued, (If, jf) formed, (Id, jd) folded; room / first bin of each are cached.  All of it is wave-uniform.
-    int Ii = blockIdx.x, ji = 0, ni = 0;                // item, iteration inside it, ordinal of the item (its tap buffer is n & 1)
-    if (Ii >= n_items) return;                          // (the launcher never starts more workgroups than items)
+    // Which items: round n of the grid covers items [n G, (n + 1) G) (G workgroups), dealt so that the 8 NEIGHBOURING TILES of a room run
+    // at the same time ON ONE XCD (one L2): a tile is 32 / SUB bins wide, so 8 / SUB ... 8 tiles share every 128-byte line of the masks and
+    // of z.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs; with the plain map (item = id + n G) neighbouring tiles
+    // sat on 8 different L2s, each of which fetched the shared mask lines for itself and wrote its 32-byte piece of a z line separately:
+    // 29.1 GB read per C5 launch for 18.5 GB of inputs (profiles/r04_m_C5_pmc_traffic.json).  Needs G a multiple of 64; else the plain map.
+    const int G = gridDim.x;
+    auto item_of = [&](int n) {
+        const int w = blockIdx.x;
+        if (G % 64 != 0) return n * G + w;
+        const int xcd = w % 8, s_ = w / 8, per = G / 64;          // s_: the workgroup's place on its XCD, per: blocks of 8 items per XCD and round
+        return ((n * per + s_ / 8) * 8 + xcd) * 8 + s_ % 8;
+    };
+    int nr = 0;                                         // round of the issue position
+    int Ii = item_of(0), ji = 0, ni = 0;                // item, iteration inside it, ordinal of the item (its tap buffer is n & 1)
+    if (Ii >= n_items) return;
     int ri = Ii / a.tiles, fi = (Ii % a.tiles) * NB;
     int rf = ri, ff = fi, jf = 0, nf = 0;
     int rd = ri, fd = fi, jd = 0;
     bool vi = true, vf = true;                          // position still inside the workgroup's items
     auto advance_issue = [&]() {
         if (++ji == J) {
-            Ii += gridDim.x;
+            Ii = item_of(++nr);
             vi = Ii < n_items;
             if (vi) {
                 ri = Ii / a.tiles;

@@ -138,7 +138,8 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *                         "step2_stft_apply_istft") instead of reading the stored spectra ("step2_apply_istft")
  *   "room_cov"           (DISCO_ROOM_COV, 1)   wide shapes: z + step-2 statistics of a whole room in one pass ("room_cov2") instead of
  *                         disco_apply + disco_cov_masked ("apply1" + "cov2")
- *   "room_dma"           (DISCO_ROOM_DMA, 1)   that pass on its LDS-DMA ring ("room_cov2"); 0: register-staged ("room_cov2_reg")
+ *   "room_dma"           (DISCO_ROOM_DMA, 1)   that pass as ONE PERSISTENT workgroup per CU on an LDS-DMA ring ("room_cov2"); 0: register-staged, one
+ *                         workgroup per (room, tile, chunk) ("room_cov2_reg")
  *   "overlap_solves"     (DISCO_OVERLAP_SOLVES, 1)  disco_tango_enhance / _iterated on batches of rooms x nodes >= 1024 run as two
  *                         half-batches, the second on an internal stream forked from / joined to the caller's with events (still one
  *                         capturable launch sequence): one half's solves overlap the other half's streaming kernels.  Each stage
@@ -148,8 +149,14 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *   "solve_f32"          (DISCO_SOLVE_F32, 0)  1: group solver (P >= 5) with float32 squarings on packed instructions and a float64
  *                         Rayleigh-quotient finish (same accuracy; measured SLOWER than the all-float64 default on the MI355X: 1.26 vs
  *                         1.07 ms at P = 7, 16.2 vs 14.4 ms at P = 15 -- after round 2 only 3-4 squarings are left to speed up)
- *   "room_tile16"        (DISCO_ROOM_TILE16, 0) 1: the room pass ("room_dma" = 1, K a multiple of 4) on 16-bin tiles: 6-wave workgroups, two per CU
- *                         (measured slower than the 32-bin form on the MI355X: 16.8 against 14.05 ms per C5 step; kept, tested, as a record)
+ *   "room_sub"           (DISCO_ROOM_SUB, 8)    time sub-chunks per workgroup of the persistent room pass ("room_dma" = 1): a workgroup owns 32 / n bins and n
+ *                         consecutive frames at a time, a lane's float32 sums are n times shorter and meet inside the wave (csrc/k_room.h).  8 or 4
+ *   "cov1_mode"          (DISCO_COV1_MODE, 64)  step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (k_cov_loc_f64: their float32
+ *                         summation was what C5's distance from the float64 oracle followed); 4 / 8 = float32 with that many time sub-chunks across
+ *                         the lanes of a wave; anything else = float32, lanes are bins
+ *   "solve_thread"       (DISCO_SOLVE_THREAD, 1) rank-1 GEVD-MWF solves with 5 <= P <= 7 (and the online mode at those sizes) run one THREAD per pencil
+ *                         (csrc/k_solve_small.h, one wave per SIMD, AGPRs as the second register file): 0.48 against 0.73 ms per 1 028 000 P = 7
+ *                         pencils, online mode 32x instead of 15x real-time at 1000 rooms; 0: the LDS group solver
  *   "solve_dpp"          (DISCO_SOLVE_DPP, 1)  rank-1 GEVD-MWF solves with 9 <= P <= 16 run in registers, other lanes' entries read through
  *                         DPP row broadcasts (csrc/k_solve_dpp.h: 3.7 instead of 7.2 ms per C5 launch); 0: the LDS group solver, which P <= 8,
  *                         the online mode and "solve_f32" use in any case.  Same algorithm and breakdown rules; the two are tested against
