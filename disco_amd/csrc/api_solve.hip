@@ -13,8 +13,8 @@ void launch_solve_dpp(int P, const SolveSrc& src, long long n_prob, double mu, c
 
 template <int P>
 static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s, bool mixed, bool thread) {
-    if (P <= 4 || (P <= 7 && thread)) {             // one thread per pencil (k_solve_small.h); P = 8 spills there (1.57 against 1.98 ms per 1 028 000 pencils for the LDS group form -- and the partial-sum fetch of the thread form is the slower one: kept on the group solver)
-        if constexpr (P <= 7) {
+    if (P <= 4 || (P <= 8 && thread)) {             // one thread per pencil (k_solve_small.h)
+        if constexpr (P <= 8) {
         constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P>();
         const long long grid = (n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;
         if (src.part)

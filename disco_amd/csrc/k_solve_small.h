@@ -22,24 +22,14 @@ struct HermReg {                       // Hermitian P x P: d[i] = A[i][i] (real)
     }
 };
 
-// Rxx, Rnn given as (diag, strict lower triangle) in float32.  w, t1: this problem's P filter entries.
-// Contains a wave-wide vote: every lane of the wave must call it (dead lanes pass Rxx = 0, Rnn = I).
-template <int P>
-__device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a_o, const float* b_d, const c32* b_o, const double mu,
-                                                  c64* w, c64* t1) {
-    constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
+// Cholesky Rnn = L L^H with the pivot floor of k_solve.h (numerically singular noise statistics): Ld = diag L, rL = 1 / diag L,
+// Lo = strict lower triangle.  bd(i) / bo(i, k) (i > k) hand out Rnn's entries -- from registers, an LDS tile or memory.
+template <int P, class BD, class BO>
+__device__ __forceinline__ void thread_cholesky(BD bd, BO bo, double* Ld, double* rL, c64* Lo) {
     auto lo = [](int i, int k) { return i * (i - 1) / 2 + k; };
-    auto A = [&](int i, int k) -> c64 {        // Rxx[i][k]
-        if (i == k) return make_double2((double)a_d[i], 0.0);
-        if (i > k) return make_double2((double)a_o[i * (i - 1) / 2 + k].x, (double)a_o[i * (i - 1) / 2 + k].y);
-        return make_double2((double)a_o[k * (k - 1) / 2 + i].x, -(double)a_o[k * (k - 1) / 2 + i].y);
-    };
-    // ---- Cholesky Rnn = L L^H with the pivot floor of k_solve.h (numerically singular noise statistics)
-    double Ld[P], rL[P];
-    c64 Lo[NO];
 #pragma unroll
     for (int c = 0; c < P; ++c) {
-        const double a_cc = (double)b_d[c];
+        const double a_cc = bd(c);
         double d2 = a_cc;
 #pragma unroll
         for (int k = 0; k < c; ++k) d2 -= Lo[lo(c, k)].x * Lo[lo(c, k)].x + Lo[lo(c, k)].y * Lo[lo(c, k)].y;
@@ -51,46 +41,82 @@ __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a
         Ld[c] = d2c * rd;
 #pragma unroll
         for (int i = c + 1; i < P; ++i) {
-            c64 s = make_double2((double)b_o[lo(i, c)].x, (double)b_o[lo(i, c)].y);
+            c64 s = bo(i, c);
 #pragma unroll
             for (int k = 0; k < c; ++k) s = zsub(s, zmulc(Lo[lo(i, k)], Lo[lo(c, k)]));
             Lo[lo(i, c)] = brk ? make_double2(0.0, 0.0) : zscale(s, rd);
         }
     }
-    // ---- C = L^-1 Rxx L^-H, column by column; only the lower triangle is kept
+}
+
+// Rank-1 GEVD-MWF of ONE pencil in the registers of one thread.  load_a / load_b(float* d, c32* o) fill (diagonal, strict lower triangle)
+// of Rxx / Rnn in float32 -- from the registers of the caller, an LDS tile or memory -- as ONE batch of independent loads, and may be
+// called again: with RECOMPUTE the Cholesky factor and Rxx are NOT kept across the squarings -- both matrices are fetched and the factor
+// is formed a second time for the back substitution -- so that only B and B^2 live through the loop (P = 7: 2 x 98 registers instead of
+// 2 x 98 + 112 + 49: two waves per SIMD instead of one; P = 8 runs without scratch).
+// Whitening C = L^-1 Rxx L^-H as LAPACK's zhegs2 does it (itype 1, lower): in place on the Hermitian half, P^3 / 2 complex multiply-adds
+// where the column-by-column form of round 2 took 1.2 P^3.
+// w, t1: this problem's P filter entries.  Contains a wave-wide vote: every lane of the wave must call it (dead lanes pass Rxx = 0, Rnn = I).
+template <int P, bool RECOMPUTE, class LA, class LB>
+__device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, const double mu, c64* w, c64* t1) {
+    constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
+    auto lo = [](int i, int k) { return i * (i - 1) / 2 + k; };
+    auto f2z = [](c32 v) { return make_double2((double)v.x, (double)v.y); };
     HermReg<P> B;
     double tr = 0.0;
+    double Ld[P], rL[P];
+    c64 Lo[NO];
+    float a_d[P], b_d[P];
+    c32 a_o[NO], b_o[NO];
+    load_b(b_d, b_o);
+    load_a(a_d, a_o);
+    auto ad = [&](int i) { return (double)a_d[i]; };
+    auto ao = [&](int i, int k) { return f2z(a_o[i * (i - 1) / 2 + k]); };
+    auto bd = [&](int i) { return (double)b_d[i]; };
+    auto bo = [&](int i, int k) { return f2z(b_o[i * (i - 1) / 2 + k]); };
+    thread_cholesky<P>(bd, bo, Ld, rL, Lo);
+    {
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-        // column j of C directly: C[:, j] = L^-1 (Rxx (L^-H e_j)); u = L^-H e_j has entries 0..j only
-        c64 yj[P], u[P];
+        for (int i = 0; i < P; ++i) {
+            B.d[i] = ad(i);
 #pragma unroll
-        for (int i = P - 1; i >= 0; --i) {
-            c64 a = make_double2(i == j ? 1.0 : 0.0, 0.0);
-#pragma unroll
-            for (int k = i + 1; k < P; ++k)
-                if (k <= j) a = zsub(a, zmul(make_double2(Lo[lo(k, i)].x, -Lo[lo(k, i)].y), u[k]));
-            u[i] = i <= j ? zscale(a, rL[i]) : make_double2(0.0, 0.0);
+            for (int k = 0; k < i; ++k) B.o[lo(i, k)] = ao(i, k);
         }
 #pragma unroll
-        for (int i = 0; i < P; ++i) {            // yj = Rxx u
-            c64 a = make_double2(0.0, 0.0);
+        for (int k = 0; k < P; ++k) {
+            const double akk = B.d[k] * rL[k] * rL[k];
+            B.d[k] = akk;
+            tr += akk;
+            const double ct = -0.5 * akk;
 #pragma unroll
-            for (int k = 0; k < P; ++k)
-                if (k <= j) a = zadd(a, zmul(A(i, k), u[k]));
-            yj[i] = a;
+            for (int i = k + 1; i < P; ++i) {                    // x = A(k+1:, k) / L(k, k) + ct L(k+1:, k)
+                const c64 l_ik = Lo[lo(i, k)];
+                c64 x = zscale(B.o[lo(i, k)], rL[k]);
+                x.x = fma(ct, l_ik.x, x.x);
+                x.y = fma(ct, l_ik.y, x.y);
+                B.o[lo(i, k)] = x;
+            }
+#pragma unroll
+            for (int i = k + 1; i < P; ++i) {                    // A(k+1:, k+1:) -= x y^H + y x^H,  y = L(k+1:, k)   (lower triangle)
+                const c64 xi = B.o[lo(i, k)], yi = Lo[lo(i, k)];
+                B.d[i] -= 2.0 * (xi.x * yi.x + xi.y * yi.y);
+#pragma unroll
+                for (int j = k + 1; j < i; ++j) {
+                    const c64 xj = B.o[lo(j, k)], yj = Lo[lo(j, k)];
+                    B.o[lo(i, j)] = zsub(zsub(B.o[lo(i, j)], zmulc(xi, yj)), zmulc(yi, xj));
+                }
+            }
+#pragma unroll
+            for (int i = k + 1; i < P; ++i) {                    // x += ct y, then x <- L(k+1:, k+1:)^-1 x
+                const c64 l_ik = Lo[lo(i, k)];
+                c64 x = B.o[lo(i, k)];
+                x.x = fma(ct, l_ik.x, x.x);
+                x.y = fma(ct, l_ik.y, x.y);
+#pragma unroll
+                for (int m = k + 1; m < i; ++m) x = zsub(x, zmul(Lo[lo(i, m)], B.o[lo(m, k)]));
+                B.o[lo(i, k)] = zscale(x, rL[i]);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < P; ++i) {            // c = L^-1 yj (in place)
-            c64 a = yj[i];
-#pragma unroll
-            for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lo[lo(i, k)], yj[k]));
-            yj[i] = zscale(a, rL[i]);
-        }
-        B.d[j] = yj[j].x;
-        tr += yj[j].x;
-#pragma unroll
-        for (int i = j + 1; i < P; ++i) B.o[lo(i, j)] = yj[i];
     }
     // ---- dominant eigenpair by repeated squaring of B = C / tr C (see k_solve.h); tau = tr(B^2) = ||B||_F^2 is real here
     const bool ok = tr > 0.0 && tr < 1.7e308;
@@ -189,6 +215,14 @@ __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a
         }
     }
     // ---- q = L^-H v0, d0 = q^H Rxx q (q^H Rnn q = 1), t1 = q L[0][0] conj(v0[0]), w = t1 d0 / (d0 + mu)
+    if constexpr (RECOMPUTE) {
+        // the squarings must not see the factor as live: an opaque touch of v0 keeps hipcc from hoisting this second factorisation
+        // (bit-identical to the first) above the loop and carrying it through
+        DISCO_CONSUME(v0[0].x);
+        load_b(b_d, b_o);
+        load_a(a_d, a_o);
+        thread_cholesky<P>(bd, bo, Ld, rL, Lo);
+    }
     c64 q[P];
 #pragma unroll
     for (int i = P - 1; i >= 0; --i) {
@@ -200,9 +234,13 @@ __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a
     double d0 = 0.0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        c64 sj = make_double2(0.0, 0.0);
+        c64 sj = make_double2(ad(i) * q[i].x, ad(i) * q[i].y);
 #pragma unroll
-        for (int k = 0; k < P; ++k) sj = zadd(sj, zmul(A(i, k), q[k]));
+        for (int k = 0; k < P; ++k) {
+            if (k == i) continue;
+            const c64 e = k < i ? ao(i, k) : ao(k, i);
+            sj = zadd(sj, zmul(k < i ? e : make_double2(e.x, -e.y), q[k]));
+        }
         d0 += q[i].x * sj.x + q[i].y * sj.y;
     }
     d0 = have ? d0 : 0.0;
@@ -216,47 +254,18 @@ __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a
     }
 }
 
-// (diag, strict lower triangle) of both matrices of problem pid, from full row-major matrices or from chunk partials
-template <int P, bool FROM_PART>
-__device__ __forceinline__ void solve_load_tri(const SolveSrc& src, long long pid, float* a_d, c32* a_o, float* b_d, c32* b_o) {
+// the same with both matrices handed over in registers as (diag, strict lower triangle) in float32 (the online kernel's state)
+template <int P>
+__device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a_o, const float* b_d, const c32* b_o, const double mu,
+                                                  c64* w, c64* t1) {
+    constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
+    auto copy = [](const float* sd, const c32* so, float* d, c32* o) {
 #pragma unroll
-    for (int i = 0; i < P; ++i)
+        for (int i = 0; i < P; ++i) d[i] = sd[i];
 #pragma unroll
-        for (int k = 0; k <= i; ++k) {
-            c32 rs, rn;                          // R[i][k], i >= k
-            if constexpr (!FROM_PART) {
-                rs = src.Rss[pid * P * P + i * P + k];
-                rn = src.Rnn[pid * P * P + i * P + k];
-            } else {
-                constexpr int NP = P * (P + 1) / 2;
-                const long long g = pid / src.F;
-                const int f = (int)(pid % src.F);
-                const bool loc = i < src.M_loc;                                   // upper-triangle entry (k, i): k <= i < M_loc
-                const int Pq = loc ? src.M_loc : P;
-                const int q = k * Pq - (k * (k - 1)) / 2 + (i - k);
-                const float4* base = loc ? src.part_loc : src.part;
-                const int nch = loc ? src.chunks_loc : src.chunks;
-                const long long npq = loc ? (long long)(src.M_loc * (src.M_loc + 1) / 2) : (long long)NP;
-                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;                      // float64 combination, one rounding (as k_solve.h)
-                for (int ch = 0; ch < nch; ++ch) {
-                    const float4 v = base[(((g * nch + ch) * src.F) + f) * npq + q];
-                    sx += (double)v.x;
-                    sy += (double)v.y;
-                    sz += (double)v.z;
-                    sw += (double)v.w;
-                }
-                const double it = (double)src.inv_T;
-                rs = make_float2((float)(sx * it), -(float)(sy * it));             // stored (k, i) -> R[i][k] = conj
-                rn = make_float2((float)(sz * it), -(float)(sw * it));
-            }
-            if (i == k) {
-                a_d[i] = rs.x;
-                b_d[i] = rn.x;
-            } else {
-                a_o[i * (i - 1) / 2 + k] = rs;
-                b_o[i * (i - 1) / 2 + k] = rn;
-            }
-        }
+        for (int q = 0; q < NO; ++q) o[q] = so[q];
+    };
+    gevd_solve_thread_acc<P, (P >= 6)>([&](float* d, c32* o) { copy(a_d, a_o, d, o); }, [&](float* d, c32* o) { copy(b_d, b_o, d, o); }, mu, w, t1);
 }
 
 // threads per workgroup: two waves, one for the larger pencils (the wave-cooperative fetch stages 64 * NP float4 per wave in LDS)
@@ -266,82 +275,97 @@ constexpr int solve_small_threads() { return P <= 6 ? 128 : 64; }
 template <int P, bool FROM_PART>
 __global__ DISCO_KERNEL_ALIGN __launch_bounds__(solve_small_threads<P>()) void k_gevd_mwf_r1_thread(SolveSrc src, long long n_prob, double mu,
                                                                               c32* __restrict__ w_out, c32* __restrict__ t1_out) {
-    constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
     constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P>();
+    constexpr int NP = P * (P + 1) / 2;
+    constexpr bool RECOMPUTE = P >= 6;
     const long long pid = (long long)blockIdx.x * SOLVE_SMALL_THREADS + threadIdx.x;
     const bool live = pid < n_prob;
-    float a_d[P], b_d[P];
-    c32 a_o[NO], b_o[NO];
-    bool loaded = false;
+    const long long pc = live ? pid : n_prob - 1;                 // dead lanes stand in for the last pencil (and store nothing)
+    c64 w[P], t1[P];
     if constexpr (FROM_PART) {
-        // The partial sums of a wave's 64 pencils are 64 * NP consecutive float4 per chunk (pencils are (g, f)-major like the
-        // partial array): fetched lane-linearly, summed over the chunks, and handed over through LDS -- a thread loading its own
-        // NP entries reads 16 bytes of every 160, ten times over, and the lines do not survive in L1/L2 between the ten
-        // (PMC, C3: 2.07 GB fetched for 0.33 GB of partial sums).  Blocks that carry a step-1 block (M_loc) keep the direct path.
-        constexpr int NP = P * (P + 1) / 2;
+        // The partial sums of a wave's 64 pencils are 64 * NP consecutive float4 per block (pencils are (g, f)-major like the partial
+        // array): fetched lane-linearly, the blocks of an entry combined in float64 and rounded once (as in every other loader), and
+        // handed over through LDS -- a thread loading its own NP entries reads 16 bytes of every 16 NP, NP times over, and the lines do
+        // not survive in L1 / L2 in between (PMC, C3: 2.07 GB fetched for 0.33 GB of partial sums).  Entries of the leading
+        // M_loc x M_loc block come from the step-1 partial sums (SolveSrc::part_loc) -- since round 4 through the same fetch.
         __shared__ float4 s_tile[SOLVE_SMALL_THREADS / 64][64 * NP];
-        if (src.M_loc == 0) {                                             // block-uniform
-            const int lane = threadIdx.x & 63, wv = wave_id();
-            const long long pc = live ? pid : n_prob - 1;                 // dead lanes stand in for the last pencil
-            const long long off = ((pc / src.F) * src.chunks * src.F + pc % src.F) * (long long)NP;      // chunk 0 of this lane's pencil
-            const int off_lo = (int)(unsigned)(off & 0xffffffffLL), off_hi = (int)(off >> 32);
+        const int lane = threadIdx.x & 63, wv = wave_id();
+        const int ML = src.M_loc, NPL = ML * (ML + 1) / 2;
+        const long long g = pc / src.F;
+        const int f = (int)(pc % src.F);
+        const long long off = ((g * src.chunks) * src.F + f) * (long long)NP;                    // block 0 of this lane's pencil
+        const long long offl = ML > 0 ? ((g * src.chunks_loc) * src.F + f) * (long long)NPL : 0;
+        const int off_lo = (int)(unsigned)(off & 0xffffffffLL), off_hi = (int)(off >> 32);
+        const int offl_lo = (int)(unsigned)(offl & 0xffffffffLL), offl_hi = (int)(offl >> 32);
+        const double it = (double)src.inv_T;
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int e = lane + 64 * k, pe = e / NP, q = e % NP;     // element e of the wave's block belongs to lane pe's pencil
-                const long long o = ((long long)__shfl(off_hi, pe) << 32) | (unsigned)__shfl(off_lo, pe);
-                const float4* ptr = src.part + o + q;
-                // the chunk sums are combined in float64 and rounded ONCE, as in every other loader (k_solve.h, k_solve_dpp.h, k_cov_finalize)
-                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                for (int ch = 0; ch < src.chunks; ++ch) {
-                    const float4 v = ptr[(long long)ch * src.F * NP];
-                    sx += (double)v.x;
-                    sy += (double)v.y;
-                    sz += (double)v.z;
-                    sw += (double)v.w;
+        for (int k = 0; k < NP; ++k) {
+            const int e = lane + 64 * k, pe = e / NP, q = e % NP;     // element e of the wave's block belongs to lane pe's pencil
+            int r = 0, rem = q;                                       // q = (r, c), r <= c, in the row-major upper triangle of P
+#pragma unroll
+            for (int rr = 0; rr < P - 1; ++rr) {
+                if (rem >= P - r) {
+                    rem -= P - r;
+                    ++r;
                 }
-                const double it = (double)src.inv_T;
-                s_tile[wv][e] = make_float4((float)(sx * it), (float)(sy * it), (float)(sz * it), (float)(sw * it));
             }
-            DISCO_GROUP_SYNC();                                           // wave-local hand-over
-#pragma unroll
-            for (int i = 0; i < P; ++i)
-#pragma unroll
-                for (int k = 0; k <= i; ++k) {
-                    const float4 v = s_tile[wv][lane * NP + (k * P - (k * (k - 1)) / 2 + (i - k))];      // stored (k, i): R[i][k] = conj
-                    if (i == k) {
-                        a_d[i] = v.x;
-                        b_d[i] = v.z;
-                    } else {
-                        a_o[i * (i - 1) / 2 + k] = make_float2(v.x, -v.y);
-                        b_o[i * (i - 1) / 2 + k] = make_float2(v.z, -v.w);
-                    }
-                }
-            loaded = true;
+            const int c = r + rem;
+            const bool loc = c < ML;
+            const long long o_main = ((long long)__shfl(off_hi, pe) << 32) | (unsigned)__shfl(off_lo, pe);
+            const long long o_loc = ((long long)__shfl(offl_hi, pe) << 32) | (unsigned)__shfl(offl_lo, pe);
+            const float4* ptr = loc ? src.part_loc + o_loc + (r * ML - (r * (r - 1)) / 2 + (c - r)) : src.part + o_main + q;
+            const long long stride = loc ? (long long)src.F * NPL : (long long)src.F * NP;
+            const int nch = loc ? src.chunks_loc : src.chunks;
+            // the first two blocks unconditionally (the second one weighed 0 when there is none: clamped address), so that the loads of
+            // ALL entries of the unrolled loop are independent and in flight together; further blocks, rare, in a loop
+            const float4 v0 = ptr[0], v1 = ptr[nch > 1 ? stride : 0];
+            const double m1 = nch > 1 ? 1.0 : 0.0;
+            double sx = (double)v0.x + m1 * (double)v1.x, sy = (double)v0.y + m1 * (double)v1.y;
+            double sz = (double)v0.z + m1 * (double)v1.z, sw = (double)v0.w + m1 * (double)v1.w;
+            for (int ch = 2; ch < nch; ++ch) {
+                const float4 v = ptr[ch * stride];
+                sx += (double)v.x;
+                sy += (double)v.y;
+                sz += (double)v.z;
+                sw += (double)v.w;
+            }
+            s_tile[wv][e] = make_float4((float)(sx * it), (float)(sy * it), (float)(sz * it), (float)(sw * it));
         }
-    }
-    if (loaded) {
-        if (!live) {
+        DISCO_GROUP_SYNC();                                           // wave-local hand-over
+        const float4* tp = &s_tile[wv][lane * NP];
+        // entry (i, k), i >= k, of the Hermitian matrices = conj of the stored upper-triangle entry (k, i)
+        auto tri = [](int k, int i) { return k * P - (k * (k - 1)) / 2 + (i - k); };
+        gevd_solve_thread_acc<P, RECOMPUTE>(
+            [&](float* d, c32* o) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    d[i] = tp[tri(i, i)].x;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) o[i * (i - 1) / 2 + k] = make_float2(tp[tri(k, i)].x, -tp[tri(k, i)].y);
+                }
+            },
+            [&](float* d, c32* o) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    d[i] = tp[tri(i, i)].z;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) o[i * (i - 1) / 2 + k] = make_float2(tp[tri(k, i)].z, -tp[tri(k, i)].w);
+                }
+            },
+            mu, w, t1);
+    } else {
+        const c32* A = src.Rss + pc * P * P;
+        const c32* Bm = src.Rnn + pc * P * P;
+        auto ld = [](const c32* m, float* d, c32* o) {
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                a_d[i] = 0.f;
-                b_d[i] = 1.f;
+                d[i] = m[i * P + i].x;
+#pragma unroll
+                for (int k = 0; k < i; ++k) o[i * (i - 1) / 2 + k] = m[i * P + k];
             }
-#pragma unroll
-            for (int q = 0; q < NO; ++q) a_o[q] = b_o[q] = make_float2(0.f, 0.f);
-        }
-    } else if (live) {
-        solve_load_tri<P, FROM_PART>(src, pid, a_d, a_o, b_d, b_o);
-    } else {
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            a_d[i] = 0.f;
-            b_d[i] = 1.f;
-        }
-#pragma unroll
-        for (int q = 0; q < NO; ++q) a_o[q] = b_o[q] = make_float2(0.f, 0.f);
+        };
+        gevd_solve_thread_acc<P, RECOMPUTE>([&](float* d, c32* o) { ld(A, d, o); }, [&](float* d, c32* o) { ld(Bm, d, o); }, mu, w, t1);
     }
-    c64 w[P], t1[P];
-    gevd_solve_thread<P>(a_d, a_o, b_d, b_o, mu, w, t1);
     if (live) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
