@@ -94,6 +94,7 @@ def kernel_alg_bytes(M, K, F, H):
         'stft_apply_istft': M * H * 4 + H * 4,                # samples in, hop samples out (single node, nothing materialised)
         'step2_stft_apply_istft': M * H * 4 + H * 4,          # samples in, hop samples out (spectra re-transformed, z / yf on chip)
         'istft': F * 8 + H * 4,                               # yf in, hop samples out
+        'apply2_istft': M * F * 8 + F * 8 + H * 4,            # X + z in, hop samples out (wide shapes: yf stays on chip)
         'apply_istft': M * F * 8 + H * 4,
         'online1': M * F * 8 + F * 4 + F * 8,                 # X + mask in, z out (the smoothed matrices live in registers)
         'online2': M * F * 8 + (K - 1) * F * 8 + F * 4 + F * 8,   # X + remote z + mask in, yf out

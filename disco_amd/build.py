@@ -21,7 +21,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-f
 # every wait is a full `s_waitcnt vmcnt(0)` (round 4: no hand-counted queue depth any more), so a scratch access cannot break it; 168
 # registers at 3 waves / SIMD leave hipcc a few words short in the A-role loop of some shapes (the loader's per-lane constants: <= 5 reloads
 # per iteration) -- tolerated up to 64 bytes, anything larger means the accumulators went to scratch and is refused.
-SCRATCH_LIMIT = {'k_room_cov_dma': 64, 'k_gevd_mwf_r1_dpp': 0}
+SCRATCH_LIMIT = {'k_room_cov_dma': 64, 'k_gevd_mwf_r1_dpp': 0, 'k_apply_istft_wide': 0}
 # units whose kernels read other lanes' registers through DPP inside inline asm (csrc/dpp64.h): hipcc cannot see those reads, so
 # the two DPP hazards (a VALU write of the source within 2 wait states, an EXEC write within 5) are checked on the device
 # assembly of the unit (disco_amd/check_dpp_hazards.py) and a build with a hazard is refused

@@ -298,6 +298,7 @@ const OptionInfo* option_table() {
         {"room_sub", "DISCO_ROOM_SUB", 8},
         {"cov1_mode", "DISCO_COV1_MODE", 64},
         {"solve_thread", "DISCO_SOLVE_THREAD", 1},
+        {"fuse_wide_istft", "DISCO_FUSE_WIDE_ISTFT", 1},
     };
     return t;
 }

@@ -256,6 +256,10 @@ static void enhance_steps(disco_ctx* ctx, const PathArgs& a, Steps& st) {
         return STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &ch, s, same_mask && c.nodes > 1));
     }});
     st.push_back({"solve2", true, solve_pending(w)});
+    if (c.nodes > 1 && apply_istft_wide_ok(ctx)) {      // wide shapes: yf stays on chip (and goes out only when the caller asked for it)
+        st.push_back({"apply2_istft", false, [=](disco_stream s) { return apply_istft_wide(ctx, X, z, w, yf, out, s); }});
+        return;
+    }
     st.push_back({"apply2", false, [=](disco_stream s) { return disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w, P2, 1, yo, s); }});
     st.push_back({"istft", false, [=](disco_stream s) { return disco_istft(ctx, yo, G, out, s); }});
 }
@@ -522,6 +526,10 @@ static void iterated_steps(disco_ctx* ctx, const PathArgs& a, int iters, Steps& 
                                (const c32*)w_glo, (c32*)w_loc, nb, M, P2);
             return check_launch(ctx, "k_filter_head");
         }});
+    }
+    if (c.nodes > 1 && apply_istft_wide_ok(ctx)) {
+        st.push_back({"apply2_istft", false, [=](disco_stream s) { return apply_istft_wide(ctx, X, z, w_glo, a.yf, out, s); }});
+        return;
     }
     st.push_back({"apply2", false, [=](disco_stream s) { return disco_apply(ctx, X, c.nodes > 1 ? z : nullptr, w_glo, P2, 1, yo, s); }});
     st.push_back({"istft", false, [=](disco_stream s) { return disco_istft(ctx, yo, G, out, s); }});

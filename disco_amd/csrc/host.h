@@ -38,6 +38,7 @@ enum {
     DISCO_OPT_ROOM_SUB,                 // "room_sub": time sub-chunks per workgroup of the persistent room pass (4 or 8 -> 8 or 4 bins per workgroup)
     DISCO_OPT_COV1_MODE,                // "cov1_mode": step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (default), 4 / 8 = float32 with time sub-chunks across the lanes, else float32
     DISCO_OPT_SOLVE_THREAD,             // "solve_thread": 5 <= P <= 8 solved one THREAD per pencil (k_solve_small.h at one wave per SIMD, AGPRs as the second register file) instead of the LDS group solver
+    DISCO_OPT_FUSE_WIDE_ISTFT,          // "fuse_wide_istft": whole-path calls of the wide shapes (P > 8) end in ONE filter + iSTFT pass (k_apply_istft_wide) instead of disco_apply + disco_istft
     DISCO_N_OPTIONS
 };
 namespace disco_host {
@@ -238,5 +239,7 @@ int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask_w, 
 int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, float* out, disco_stream s);
 bool from_samples_shape(const disco_cfg& c);
 bool step2_apply_istft_ok(const disco_ctx* ctx);
+bool apply_istft_wide_ok(const disco_ctx* ctx);
+int apply_istft_wide(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, disco_c32* yf, float* out, disco_stream s);
 int step2_stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w_loc, const disco_c32* w_glo, float* out, disco_stream s);
 }  // namespace disco_host

@@ -1038,6 +1038,51 @@ def check_room_cov(make_engine, K=2, M=8, L=6000, n_fft=512, iters=2, R=2, tunin
     return errs
 
 
+def check_apply_istft_wide(make_engine, K=2, M=8, L=6000, n_fft=1024, iters=2, R=2, pairs=0, tol=1e-4, oracle=True):
+    """k_apply_istft_wide (csrc/k_fused.h: the final filter + iSTFT of the wide shapes in one pass, stage "apply2_istft") against the route
+    it replaces (disco_set_option("fuse_wide_istft", 0): "apply2" + "istft") and the float64 oracle, with and without the filtered spectra
+    requested, both whole-path entry points.  yf must be BIT-identical between the routes (same arithmetic per bin); the samples differ by
+    the rounding of which two frames share an inverse transform."""
+    from disco_amd import synth
+    from oracle import stft_oracle as so
+    from oracle import tango_oracle as to
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    res = {}
+    for mode in ('fused', 'staged'):
+        e = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+        e.set_option('fuse_wide_istft', 1 if mode == 'fused' else 0)
+        if pairs:
+            e.set_tuning(0, 0, 0, pairs)
+        m = e.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, e.T, e.F)
+        e.stage_timing(True)
+        out_i, yf_i = e.tango_enhance_iterated(y, m, iters=iters)
+        stages = set(e.stage_report())
+        e.stage_timing(False)
+        assert ('apply2_istft' in stages) == (mode == 'fused') and ('istft' in stages) == (mode == 'staged'), (mode, stages)
+        out_e, _, yf_e = e.tango_enhance(y, m)
+        out_n, _, none_ = e.tango_enhance(y, m, want_z=False, want_yf=False)
+        assert none_ is None
+        res[mode] = (out_i.numpy(), yf_i.numpy(), out_e.numpy(), yf_e.numpy(), out_n.numpy())
+    f, g = res['fused'], res['staged']
+    assert np.array_equal(f[1], g[1]) and np.array_equal(f[3], g[3]), 'yf differs between the one-pass and the staged route'
+    assert np.array_equal(f[2], f[4]), 'the samples depend on whether yf was requested'
+    errs = {'out_iter_vs_staged': max(relerr(f[0][r, k], g[0][r, k]) for r in range(R) for k in range(K)),
+            'out_vs_staged': max(relerr(f[2][r, k], g[2][r, k]) for r in range(R) for k in range(K))}
+    assert max(errs.values()) < 2e-6, errs
+    if not oracle:              # (clips of fewer frames than channels: singular statistics, the oracle's Cholesky refuses them)
+        return errs
+    for r in range(R):
+        for it_, (o_idx, yf_idx) in ((iters, (0, 1)), (1, (2, 3))):
+            o = to.offline_tango_vec(y[r], s[r], n[r], vads=['irm1', 'irm1'], n_fft=n_fft, hop=n_fft // 2, precision='f64', solver='eigh',
+                                     extra_iters=it_ - 1)
+            for k in range(K):
+                ref = so.istft(o['yf'][k], L, n_fft, n_fft // 2, work_dtype=np.float64)
+                errs['out_oracle'] = max(errs.get('out_oracle', 0.0), relerr(f[o_idx][r, k], ref))
+                errs['yf_oracle'] = max(errs.get('yf_oracle', 0.0), relerr(f[yf_idx][r, k].T, o['yf'][k]))
+    assert errs['out_oracle'] < tol and errs['yf_oracle'] < tol, errs
+    return errs
+
+
 def check_overlapped_halves(make_engine, K=2, M=2, L=6000, n_fft=512, R=3, iters=1, mode=2):
     """Option "overlap_solves" (include/disco_hip.h): the whole-path calls run the batch as two half-batch children, the second on the
     context's side stream.  Rooms are independent and the children keep the launch geometry of the whole batch, so the outputs

@@ -274,6 +274,15 @@ def test_room_cov(make_engine, K, M, n_fft, L, tuning):
     print(pc.check_room_cov(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M > 32 else 2, tuning=tuning))
 
 
+@pytest.mark.parametrize('K,M,n_fft,L,pairs,R', [(8, 8, 1024, 40000, 0, 3), (8, 8, 1024, 24000, 2, 1), (2, 8, 1024, 30011, 0, 5), (6, 4, 512, 20000, 0, 2),
+                                                 (4, 8, 512, 16384, 3, 2), (8, 4, 1024, 16384, 5, 2), (2, 8, 512, 300, 0, 2)])
+def test_apply_istft_wide(make_engine, K, M, n_fft, L, pairs, R):
+    """k_apply_istft_wide (csrc/k_fused.h: the wide shapes' final filter + iSTFT in one pass) against disco_apply + disco_istft (yf bit for
+    bit, the samples to rounding) and against the float64 oracle: C5's shape, short runs (several chunks per node, runs past the end of
+    the signal), a clip of one hop, lengths that are and are not multiples of the hop."""
+    print(pc.check_apply_istft_wide(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=R, pairs=pairs, oracle=L > 1000))
+
+
 @pytest.mark.parametrize('mode', [2, 3])
 @pytest.mark.parametrize('K,M,n_fft,iters,R', [(4, 4, 512, 1, 5), (1, 4, 512, 1, 4), (8, 8, 1024, 2, 2), (2, 8, 512, 2, 3)])
 def test_overlapped_halves(make_engine, K, M, n_fft, iters, R, mode):

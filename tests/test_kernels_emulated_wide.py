@@ -110,3 +110,11 @@ def test_emu_room_cov(make_engine, K, M, n_fft, L, tuning):
     replaces and against the oracle; several frame chunks (down to chunks of one or two frames: shorter than the three-frame
     look-ahead of the LDS-DMA ring), a last tile with one live bin (the Nyquist bin)."""
     print(pc.check_room_cov(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M >= 32 else 2, tuning=tuning, subs=(4,)))
+
+
+@pytest.mark.parametrize('K,M,n_fft,L,pairs', [(2, 8, 1024, 9000, 0), (8, 8, 1024, 24000, 2), (6, 4, 512, 5000, 0), (4, 8, 512, 7000, 3),
+                                               (8, 4, 1024, 16384, 0), (2, 8, 512, 300, 0)])
+def test_emu_apply_istft_wide(make_engine, K, M, n_fft, L, pairs):
+    """k_apply_istft_wide (the wide shapes' final filter + iSTFT in one pass) against disco_apply + disco_istft and the oracle: runs of
+    two or three pairs (several chunks, runs past the signal's end), a clip of one hop, L a multiple of the hop and not."""
+    print(pc.check_apply_istft_wide(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M >= 32 else 2, pairs=pairs, oracle=L > 1000))
