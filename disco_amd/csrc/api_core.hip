@@ -299,6 +299,7 @@ const OptionInfo* option_table() {
         {"cov1_mode", "DISCO_COV1_MODE", 64},
         {"solve_thread", "DISCO_SOLVE_THREAD", 1},
         {"fuse_wide_istft", "DISCO_FUSE_WIDE_ISTFT", 1},
+        {"online_sq32", "DISCO_ONLINE_SQ32", 1},
     };
     return t;
 }

@@ -54,7 +54,10 @@ static int online_mwf_walk(disco_ctx* ctx, const disco_c32* X, const disco_c32* 
     case P_: {                          /* one thread per (room, node, bin) */                                          \
         constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P_>();                                                  \
         const long long grid = (a.n_prob + SOLVE_SMALL_THREADS - 1) / SOLVE_SMALL_THREADS;                              \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf_thread<P_>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, st, a); \
+        if (P_ > 1 && ctx->opt[DISCO_OPT_ONLINE_SQ32] != 0)     /* the squarings in packed float32 (k_solve_small.h) */           \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf_thread<P_, (P_ > 1)>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, st, a); \
+        else                                                                                                            \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_online_mwf_thread<P_, false>), dim3((unsigned)grid), dim3(SOLVE_SMALL_THREADS), 0, st, a); \
     } break;
         C_(1) C_(2) C_(3) C_(4)
         default: break;

@@ -39,6 +39,7 @@ enum {
     DISCO_OPT_COV1_MODE,                // "cov1_mode": step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (default), 4 / 8 = float32 with time sub-chunks across the lanes, else float32
     DISCO_OPT_SOLVE_THREAD,             // "solve_thread": 5 <= P <= 8 solved one THREAD per pencil (k_solve_small.h at one wave per SIMD, AGPRs as the second register file) instead of the LDS group solver
     DISCO_OPT_FUSE_WIDE_ISTFT,          // "fuse_wide_istft": whole-path calls of the wide shapes (P > 8) end in ONE filter + iSTFT pass (k_apply_istft_wide) instead of disco_apply + disco_istft
+    DISCO_OPT_ONLINE_SQ32,              // "online_sq32": the online mode's thread solves (P <= 7) square in packed float32 (k_solve_small.h); 0: float64 throughout
     DISCO_N_OPTIONS
 };
 namespace disco_host {

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(SolveGeom<P>::THREADS, (P > 4 && P <= 8) ? DISCO_ON
 // P <= 4: one thread per (room, node, bin) with both smoothed matrices in its registers (lower triangles, float32) and the
 // thread-local float64 solve of k_solve_small.h; consecutive threads are consecutive bins, so the per-frame loads stay
 // contiguous.  Same recursion, same outputs as k_online_mwf.
-template <int P>
+template <int P, bool SQ32>
 __global__ __launch_bounds__(solve_small_threads<P>()) void k_online_mwf_thread(OnlineArgs a) {
     constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P>();
     constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(solve_small_threads<P>()) void k_online_mwf_thread(
         }
         if (until_update == 0) {                           // uniform: every problem updates at the same frames
             c64 w[P], t1[P];
-            gevd_solve_thread<P>(a_d, a_o, b_d, b_o, a.mu, w, t1);
+            gevd_solve_thread<P, SQ32>(a_d, a_o, b_d, b_o, a.mu, w, t1);
 #pragma unroll
             for (int i = 0; i < P; ++i) wv[i] = make_float2((float)w[i].x, (float)w[i].y);
             until_update = a.update_every;

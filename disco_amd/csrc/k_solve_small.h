@@ -22,6 +22,92 @@ struct HermReg {                       // Hermitian P x P: d[i] = A[i][i] (real)
     }
 };
 
+// ---- the squarings in packed float32 (round 4) ------------------------------------------------------------------------------------
+// The eigenvector that the squarings find is only as good as the pencil: Rxx / Rnn arrive ROUNDED TO FLOAT32 (6e-8 relative), which moves
+// the whitened matrix by 6e-8 cond(Rnn) and its dominant eigenvector by that over the relative gap.  A float32 rounding inside squaring j
+// moves the vector by 6e-8 / (2^j gap) -- the gap doubles with every squaring --: summed over the squarings, twice the rounding of a
+// matrix that is better conditioned than the input by cond(Rnn).  So the squarings (two thirds of the solve's instructions: P^3 / 2
+// complex multiply-adds each, as many as the wave's slowest pencil needs) run on v_pk_fma_f32 -- one complex multiply-add = 2 instructions
+// instead of 4 float64 ones -- and everything that touches the ill-conditioned factor (Cholesky, whitening, back substitution, the
+// Rayleigh quotient) stays float64.
+// WHERE: the online mode (template parameter SQ32 of the solve; option "online_sq32"), which re-solves every (bin, frame) and spends
+// 3/4 of its time squaring: 185 -> 143 ms per C3-shaped step, parity 2.0e-6 either way.  On random pencils the added error measured half
+// of what the complex64 rounding of the inputs costs, at every gap (tests: check_solver_small_gap's `inherent`).  The offline solves keep
+// float64 squarings: they are 4 % of a C3 step, and on C5's ill-conditioned 8-microphone statistics (cond(Rnn) 1e4..1e5) the float32
+// squarings moved room 199 between 3.0e-5 and 7.5e-5 with the order of the additions -- too close to the 1e-4 bar for 0.06 ms.
+template <int P>
+struct HermPk {                        // Hermitian P x P in float32: o as HermReg, the real diagonal two to a register pair (d[2m], d[2m+1])
+    static constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1, ND = (P + 1) / 2;
+    c32 o[NO];
+    c32 dp[ND];
+};
+// S = B B on the stored half; returns tr S.  Term k of S[i][j] (i > j) is B[i][k] B[k][j] with the upper triangle read as the conjugate of
+// the stored entry: a conjugating multiply-add (k < j, k > i), a plain one (j < k < i), a real scaling (k = j, k = i).
+// Order of the instructions: a complex multiply-add is two DEPENDENT v_pk_fma_f32 and the kernel runs one or two waves per SIMD, so the
+// sums advance together -- for every k the first halves of all P (P - 1) / 2 sums, then their second halves -- instead of one sum after
+// the other (the compiler schedules inline asm in source order: back-to-back dependent instructions made the first version of this
+// slower than float64 wherever few squarings were needed: C5's step-1 solves 0.71 -> 0.98 ms).
+template <int P>
+__device__ __forceinline__ float herm_square_pk(const HermPk<P>& B, HermPk<P>& S) {
+    constexpr int NO = HermPk<P>::NO;
+    auto lo = [](int i, int k) { return i * (i - 1) / 2 + k; };
+    // |off-diagonal|^2 into the row's and the column's sum (two squares per sum kept apart until the end), walked along the diagonals
+    // i - j = d so that neighbouring instructions touch different sums
+    c32 accr[P], accc[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) accr[j] = accc[j] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int d = 1; d < P; ++d) {
+#pragma unroll
+        for (int j = 0; j + d < P; ++j) accr[j + d] = PkD::template fma<0, 0, 1, 1>(B.o[lo(j + d, j)], B.o[lo(j + d, j)], accr[j + d]);
+#pragma unroll
+        for (int j = 0; j + d < P; ++j) accc[j] = PkD::template fma<0, 0, 1, 1>(B.o[lo(j + d, j)], B.o[lo(j + d, j)], accc[j]);
+    }
+    // k = j and k = i: the real diagonal
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = j + 1; i < P; ++i)
+            S.o[lo(i, j)] = (j & 1) ? scale_by_half<1>(B.o[lo(i, j)], B.dp[j / 2]) : scale_by_half<0>(B.o[lo(i, j)], B.dp[j / 2]);
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = j + 1; i < P; ++i)
+            S.o[lo(i, j)] = (i & 1) ? fma_by_half<1>(B.o[lo(i, j)], B.dp[i / 2], S.o[lo(i, j)]) : fma_by_half<0>(B.o[lo(i, j)], B.dp[i / 2], S.o[lo(i, j)]);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+#pragma unroll
+                for (int i = j + 1; i < P; ++i) {
+                    if (k == i || k == j) continue;
+                    // (u, v): the two stored entries; conj: u enters conjugated
+                    const bool cj = k < j || k > i;
+                    const c32 u = k < j ? B.o[lo(j, k)] : (k < i ? B.o[lo(i, k)] : B.o[lo(k, i)]);
+                    const c32 v = k < j ? B.o[lo(i, k)] : B.o[lo(k, j)];
+                    c32& a = S.o[lo(i, j)];
+                    if (half == 0) a = PkD::template fma<0, 0, 0, 1>(u, v, a);                 // (u.x v.x + ., u.x v.y + .)
+                    else if (cj) a = PkD::template fma<1, 1, 1, 0, 0, 1>(u, v, a);             // (+u.y v.y + ., -u.y v.x + .)
+                    else a = PkD::template fma<1, 1, 1, 0, 1, 0>(u, v, a);                     // (-u.y v.y + ., +u.y v.x + .)
+                }
+            }
+        }
+    }
+    float tau = 0.f;
+#pragma unroll
+    for (int m = 0; m < HermPk<P>::ND; ++m) {
+        c32 d2 = PkD::template mul<0, 0, 1, 1>(B.dp[m], B.dp[m]);
+        d2.x += (accr[2 * m].x + accr[2 * m].y) + (accc[2 * m].x + accc[2 * m].y);
+        if (2 * m + 1 < P) d2.y += (accr[2 * m + 1].x + accr[2 * m + 1].y) + (accc[2 * m + 1].x + accc[2 * m + 1].y);
+        S.dp[m] = d2;
+        tau += d2.x + (2 * m + 1 < P ? d2.y : 0.f);
+    }
+    (void)NO;
+    return tau;
+}
+
 // Cholesky Rnn = L L^H with the pivot floor of k_solve.h (numerically singular noise statistics): Ld = diag L, rL = 1 / diag L,
 // Lo = strict lower triangle.  bd(i) / bo(i, k) (i > k) hand out Rnn's entries -- from registers, an LDS tile or memory.
 template <int P, class BD, class BO>
@@ -57,7 +143,7 @@ __device__ __forceinline__ void thread_cholesky(BD bd, BO bo, double* Ld, double
 // Whitening C = L^-1 Rxx L^-H as LAPACK's zhegs2 does it (itype 1, lower): in place on the Hermitian half, P^3 / 2 complex multiply-adds
 // where the column-by-column form of round 2 took 1.2 P^3.
 // w, t1: this problem's P filter entries.  Contains a wave-wide vote: every lane of the wave must call it (dead lanes pass Rxx = 0, Rnn = I).
-template <int P, bool RECOMPUTE, class LA, class LB>
+template <int P, bool RECOMPUTE, bool SQ32, class LA, class LB>
 __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, const double mu, c64* w, c64* t1) {
     constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
     auto lo = [](int i, int k) { return i * (i - 1) / 2 + k; };
@@ -128,6 +214,31 @@ __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, cons
         for (int q = 0; q < NO; ++q) B.o[q] = ok ? zscale(B.o[q], rt) : make_double2(0.0, 0.0);
     }
     bool done = !ok || P == 1;
+    if constexpr (SQ32 && P > 1) {
+        HermPk<P> Bf;
+#pragma unroll
+        for (int m = 0; m < HermPk<P>::ND; ++m) Bf.dp[m] = make_float2((float)B.d[2 * m], 2 * m + 1 < P ? (float)B.d[2 * m + 1] : 0.f);
+#pragma unroll
+        for (int q = 0; q < NO; ++q) Bf.o[q] = make_float2((float)B.o[q].x, (float)B.o[q].y);
+        for (int it = 0; it < DISCO_SQUARINGS_MAX; ++it) {
+            if (!__any(!done)) break;
+            HermPk<P> S;
+            const float tau = herm_square_pk<P>(Bf, S);
+            const float rtau = tau > 0.f ? 1.0f / tau : 0.f;
+            const c32 rr = make_float2(rtau, rtau);
+            if (!done) {
+#pragma unroll
+                for (int m = 0; m < HermPk<P>::ND; ++m) Bf.dp[m] = PkD::template mul<0, 0, 1, 1>(S.dp[m], rr);
+#pragma unroll
+                for (int q = 0; q < NO; ++q) Bf.o[q] = scale_by_half<0>(S.o[q], rr);
+            }
+            done = done || (1.0f - tau < (float)DISCO_SQUARING_DONE) || !(tau > 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) B.d[i] = (double)((i & 1) ? Bf.dp[i / 2].y : Bf.dp[i / 2].x);
+#pragma unroll
+        for (int q = 0; q < NO; ++q) B.o[q] = make_double2((double)Bf.o[q].x, (double)Bf.o[q].y);
+    } else {
     for (int it = 0; it < DISCO_SQUARINGS_MAX; ++it) {
         if (!__any(!done)) break;
         HermReg<P> S;
@@ -162,6 +273,7 @@ __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, cons
             for (int q = 0; q < NO; ++q) B.o[q] = zscale(S.o[q], rtau);
         }
         done = done || (1.0 - tau < DISCO_SQUARING_DONE) || !(tau > 0.0);
+    }
     }
     // ---- B = v0 v0^H: the longest column (ties: lowest index), normalised
     c64 v0[P];
@@ -255,7 +367,7 @@ __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, cons
 }
 
 // the same with both matrices handed over in registers as (diag, strict lower triangle) in float32 (the online kernel's state)
-template <int P>
+template <int P, bool SQ32 = false>
 __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a_o, const float* b_d, const c32* b_o, const double mu,
                                                   c64* w, c64* t1) {
     constexpr int NO = P > 1 ? P * (P - 1) / 2 : 1;
@@ -265,7 +377,7 @@ __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a
 #pragma unroll
         for (int q = 0; q < NO; ++q) o[q] = so[q];
     };
-    gevd_solve_thread_acc<P, (P >= 6)>([&](float* d, c32* o) { copy(a_d, a_o, d, o); }, [&](float* d, c32* o) { copy(b_d, b_o, d, o); }, mu, w, t1);
+    gevd_solve_thread_acc<P, (P >= 6), SQ32>([&](float* d, c32* o) { copy(a_d, a_o, d, o); }, [&](float* d, c32* o) { copy(b_d, b_o, d, o); }, mu, w, t1);
 }
 
 // threads per workgroup: two waves, one for the larger pencils (the wave-cooperative fetch stages 64 * NP float4 per wave in LDS)
@@ -335,7 +447,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(solve_small_threads<P>()) void k
         const float4* tp = &s_tile[wv][lane * NP];
         // entry (i, k), i >= k, of the Hermitian matrices = conj of the stored upper-triangle entry (k, i)
         auto tri = [](int k, int i) { return k * P - (k * (k - 1)) / 2 + (i - k); };
-        gevd_solve_thread_acc<P, RECOMPUTE>(
+        gevd_solve_thread_acc<P, RECOMPUTE, false>(
             [&](float* d, c32* o) {
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
@@ -364,7 +476,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(solve_small_threads<P>()) void k
                 for (int k = 0; k < i; ++k) o[i * (i - 1) / 2 + k] = m[i * P + k];
             }
         };
-        gevd_solve_thread_acc<P, RECOMPUTE>([&](float* d, c32* o) { ld(A, d, o); }, [&](float* d, c32* o) { ld(Bm, d, o); }, mu, w, t1);
+        gevd_solve_thread_acc<P, RECOMPUTE, false>([&](float* d, c32* o) { ld(A, d, o); }, [&](float* d, c32* o) { ld(Bm, d, o); }, mu, w, t1);
     }
     if (live) {
 #pragma unroll

@@ -154,9 +154,17 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  *   "cov1_mode"          (DISCO_COV1_MODE, 64)  step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (k_cov_loc_f64: their float32
  *                         summation was what C5's distance from the float64 oracle followed); 4 / 8 = float32 with that many time sub-chunks across
  *                         the lanes of a wave; anything else = float32, lanes are bins
- *   "solve_thread"       (DISCO_SOLVE_THREAD, 1) rank-1 GEVD-MWF solves with 5 <= P <= 7 (and the online mode at those sizes) run one THREAD per pencil
- *                         (csrc/k_solve_small.h, one wave per SIMD, AGPRs as the second register file): 0.48 against 0.73 ms per 1 028 000 P = 7
- *                         pencils, online mode 32x instead of 15x real-time at 1000 rooms; 0: the LDS group solver
+ *   "solve_thread"       (DISCO_SOLVE_THREAD, 1) rank-1 GEVD-MWF solves with 5 <= P <= 8 (and the online mode with 5 <= P <= 7) run one THREAD per
+ *                         pencil (csrc/k_solve_small.h: Hermitian halves in registers, AGPRs as the second register file at P = 8): 0.26 against
+ *                         0.61 ms per 1 028 000 P = 7 pencils, 0.39 against 0.81 at P = 8; 0: the LDS group solver.  P <= 4 always runs per thread
+ *   "online_sq32"        (DISCO_ONLINE_SQ32, 1) online mode, thread solves (P <= 7): the repeated squarings on packed float32 (v_pk_fma_f32), Cholesky,
+ *                         whitening, back substitution and the Rayleigh quotient in float64 (csrc/k_solve_small.h): 193 instead of 240 ms per
+ *                         C3-shaped 1000-room step (52x instead of 42x real-time), the same 2.0e-6 from the oracle; 0: float64 squarings.  The
+ *                         offline solves always square in float64
+ *   "fuse_wide_istft"    (DISCO_FUSE_WIDE_ISTFT, 1) disco_tango_enhance / _iterated on the wide shapes (M + K - 1 > 8; 512 / 1024-point STFT) end in ONE
+ *                         filter + iSTFT pass (csrc/k_fused.h k_apply_istft_wide, stage "apply2_istft": the filtered spectra stay on chip, and are
+ *                         written only when the caller asks for yf) instead of disco_apply + disco_istft ("apply2" + "istft"): 4.0-4.6 against 5.5 ms
+ *                         per C5 step
  *   "solve_dpp"          (DISCO_SOLVE_DPP, 1)  rank-1 GEVD-MWF solves with 9 <= P <= 16 run in registers, other lanes' entries read through
  *                         DPP row broadcasts (csrc/k_solve_dpp.h: 3.7 instead of 7.2 ms per C5 launch); 0: the LDS group solver, which P <= 8,
  *                         the online mode and "solve_f32" use in any case.  Same algorithm and breakdown rules; the two are tested against

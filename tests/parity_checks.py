@@ -312,6 +312,15 @@ def check_online_mwf(make_engine, R=2, K=3, M=2, L=6000, n_fft=512, update_every
             errs['yf'] = max(errs['yf'], relerr(yf[r, k].T, o['yf'][k]))
             errs['out'] = max(errs['out'], relerr(out[r, k], o['out'][k]))
     assert errs['z'] < tol and errs['yf'] < tol and errs['out'] < tol, errs
+    # option "online_sq32" = 0: the thread solves (P <= 7) with float64 squarings; both routes within the bar, and close to each other
+    e64 = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+    e64.set_option('online_sq32', 0)
+    out64 = e64.tango_online(y, mask, update_every=update_every)[0].numpy()
+    errs['out_f64_squarings'] = max(relerr(out64[r, k], oo.online_tango(y[r], s[r], n[r], n_fft=n_fft, hop=n_fft // 2,
+                                                                         update_every=update_every)['out'][k])
+                                    for r in range(R) for k in range(K))
+    errs['sq32_vs_f64'] = relerr(out, out64)
+    assert errs['out_f64_squarings'] < tol and errs['sq32_vs_f64'] < 2e-5, errs
     # the staged call with a node shard: nodes [1, K) only, remote rows from the full z
     if K > 1:
         X = eng.stft(y.reshape(R * K, M, L)).numpy().reshape(R, K, T, F, M)
@@ -802,12 +811,14 @@ def check_solver_small_gap(make_engine, sizes=(2, 4, 7, 15)):
             d = np.concatenate([[1.0, ratio], ratio * rng.uniform(0.0, 0.9, max(P - 2, 0))])[:P]
             d = 3.0 * np.sort(d)[::-1]
             Rxx, Rnn = _pencil_with_spectrum(rng, 64, P, d)
+            w64, _, _ = mo.gevd_mwf_r1_hermitian(Rxx, Rnn, 1.0)
             Rxx, Rnn = Rxx.astype(np.complex64), Rnn.astype(np.complex64)
             w, t1 = eng.gevd_mwf_r1(Rxx, Rnn)
             wr, t1r, _ = mo.gevd_mwf_r1_hermitian(Rxx, Rnn, 1.0)
             e = max(relerr(w.numpy(), wr), relerr(t1.numpy(), t1r))
-            out[(P, ratio)] = e
-            assert e < 2e-6, (P, ratio, e)              # same inputs on both sides: float64 accuracy regardless of the gap
+            inherent = relerr(wr, w64)                  # what rounding the pencil to complex64 -- the solver's input format -- costs
+            out[(P, ratio)] = (e, inherent)
+            assert e < 2e-6, (P, ratio, e, inherent)    # same inputs on both sides: float64 accuracy regardless of the gap
     # one slow pencil (d1/d0 = 0.99999, ~20 squarings) in a batch of quick ones whose Rxx is NOT exactly Hermitian (the two
     # triangles differ at float32 rounding level, as in the online kernel where every lane accumulates its own row): the
     # quick ones wait in the same wave and must come out untouched.  (A normaliser that ignores the imaginary part of
