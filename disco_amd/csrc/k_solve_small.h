@@ -59,9 +59,9 @@ __device__ __forceinline__ float herm_square_pk(const HermPk<P>& B, HermPk<P>& S
 #pragma unroll
     for (int d = 1; d < P; ++d) {
 #pragma unroll
-        for (int j = 0; j + d < P; ++j) accr[j + d] = PkD::template fma<0, 0, 1, 1>(B.o[lo(j + d, j)], B.o[lo(j + d, j)], accr[j + d]);
+        for (int j = 0; j + d < P; ++j) accr[j + d] = PkD::fma_comp(B.o[lo(j + d, j)], B.o[lo(j + d, j)], accr[j + d]);
 #pragma unroll
-        for (int j = 0; j + d < P; ++j) accc[j] = PkD::template fma<0, 0, 1, 1>(B.o[lo(j + d, j)], B.o[lo(j + d, j)], accc[j]);
+        for (int j = 0; j + d < P; ++j) accc[j] = PkD::fma_comp(B.o[lo(j + d, j)], B.o[lo(j + d, j)], accc[j]);
     }
     // k = j and k = i: the real diagonal
 #pragma unroll
@@ -88,9 +88,9 @@ __device__ __forceinline__ float herm_square_pk(const HermPk<P>& B, HermPk<P>& S
                     const c32 u = k < j ? B.o[lo(j, k)] : (k < i ? B.o[lo(i, k)] : B.o[lo(k, i)]);
                     const c32 v = k < j ? B.o[lo(i, k)] : B.o[lo(k, j)];
                     c32& a = S.o[lo(i, j)];
-                    if (half == 0) a = PkD::template fma<0, 0, 0, 1>(u, v, a);                 // (u.x v.x + ., u.x v.y + .)
-                    else if (cj) a = PkD::template fma<1, 1, 1, 0, 0, 1>(u, v, a);             // (+u.y v.y + ., -u.y v.x + .)
-                    else a = PkD::template fma<1, 1, 1, 0, 1, 0>(u, v, a);                     // (-u.y v.y + ., +u.y v.x + .)
+                    if (half == 0) a = PkD::cfma_lo(u, v, a);
+                    else if (cj) a = PkD::cfma_hi_conj(u, v, a);
+                    else a = PkD::cfma_hi(u, v, a);
                 }
             }
         }
@@ -98,7 +98,7 @@ __device__ __forceinline__ float herm_square_pk(const HermPk<P>& B, HermPk<P>& S
     float tau = 0.f;
 #pragma unroll
     for (int m = 0; m < HermPk<P>::ND; ++m) {
-        c32 d2 = PkD::template mul<0, 0, 1, 1>(B.dp[m], B.dp[m]);
+        c32 d2 = PkD::mul_comp(B.dp[m], B.dp[m]);
         d2.x += (accr[2 * m].x + accr[2 * m].y) + (accc[2 * m].x + accc[2 * m].y);
         if (2 * m + 1 < P) d2.y += (accr[2 * m + 1].x + accr[2 * m + 1].y) + (accc[2 * m + 1].x + accc[2 * m + 1].y);
         S.dp[m] = d2;
@@ -228,7 +228,7 @@ __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, cons
             const c32 rr = make_float2(rtau, rtau);
             if (!done) {
 #pragma unroll
-                for (int m = 0; m < HermPk<P>::ND; ++m) Bf.dp[m] = PkD::template mul<0, 0, 1, 1>(S.dp[m], rr);
+                for (int m = 0; m < HermPk<P>::ND; ++m) Bf.dp[m] = PkD::mul_comp(S.dp[m], rr);
 #pragma unroll
                 for (int q = 0; q < NO; ++q) Bf.o[q] = scale_by_half<0>(S.o[q], rr);
             }

@@ -136,6 +136,14 @@ struct Pk {
     // e + s h and e - s h (component-wise), hh = (h, h) a compile-time constant pair
     static __device__ __forceinline__ c32 cfma_scale(c32 s, c32 hh, c32 e) { return fma<0, 0, 1, 1, 0, 0, true>(s, hh, e); }
     static __device__ __forceinline__ c32 cfms_scale(c32 s, c32 hh, c32 e) { return fma<0, 0, 1, 1, 1, 1, true>(s, hh, e); }
+    // component-wise: (a.x b.x, a.y b.y) and (c.x + a.x b.x, c.y + a.y b.y)  (a real diagonal held two to a pair; |z|^2 as two squares)
+    static __device__ __forceinline__ c32 mul_comp(c32 a, c32 b) { return mul<0, 0, 1, 1>(a, b); }
+    static __device__ __forceinline__ c32 fma_comp(c32 a, c32 b, c32 c) { return fma<0, 0, 1, 1>(a, b, c); }
+    // the two halves of acc + u v and of acc + conj(u) v as separate instructions, for callers that advance many sums together
+    // (k_solve_small.h): lo = (u.x v.x + ., u.x v.y + .), hi = (-u.y v.y + ., +u.y v.x + .), hi_conj = (+u.y v.y + ., -u.y v.x + .)
+    static __device__ __forceinline__ c32 cfma_lo(c32 u, c32 v, c32 acc) { return fma<0, 0, 0, 1>(u, v, acc); }
+    static __device__ __forceinline__ c32 cfma_hi(c32 u, c32 v, c32 acc) { return fma<1, 1, 1, 0, 1, 0>(u, v, acc); }
+    static __device__ __forceinline__ c32 cfma_hi_conj(c32 u, c32 v, c32 acc) { return fma<1, 1, 1, 0, 0, 1>(u, v, acc); }
     // (a.x w[S], a.y w[S]): both halves weighted by one half of the pair w
     template <int S>
     static __device__ __forceinline__ c32 scale_by_half(c32 a, c32 w) { return mul<0, S, 1, S>(a, w); }
@@ -166,7 +174,7 @@ __device__ __forceinline__ c32 fma_by_half(c32 p, c32 w, c32 acc) { return PkD::
 
 // Self-test (disco_selftest_pk): every operation above through the instruction forms (out_hw) and through the C++ forms
 // (out_ref) on the same operands; the GPU test demands bit equality of the two and agreement with complex arithmetic in NumPy.
-constexpr int PK_SELFTEST_OPS = 17;
+constexpr int PK_SELFTEST_OPS = 23;
 template <bool HW>
 __device__ __forceinline__ void pk_selftest_ops(c32 a, c32 b, c32 c, c32* o) {
     const c32 hh = make_float2(0.70710678118654752440f, 0.70710678118654752440f);
@@ -188,6 +196,12 @@ __device__ __forceinline__ void pk_selftest_ops(c32 a, c32 b, c32 c, c32* o) {
     o[14] = Pk<HW>::template scale_by_half<1>(a, b);
     o[15] = Pk<HW>::template fma_by_half<1>(a, b, c);
     o[16] = Pk<HW>::cfma(a, b, c);
+    o[17] = Pk<HW>::mul_comp(a, b);
+    o[18] = Pk<HW>::fma_comp(a, b, c);
+    o[19] = Pk<HW>::cfma_lo(a, b, c);
+    o[20] = Pk<HW>::cfma_hi(a, b, c);
+    o[21] = Pk<HW>::cfma_hi_conj(a, b, c);
+    o[22] = Pk<HW>::template fma_by_half<0>(a, b, c);
 }
 static __global__ void k_pk_selftest(const c32* __restrict__ a, const c32* __restrict__ b, const c32* __restrict__ c, long long n,
                               c32* __restrict__ out_hw, c32* __restrict__ out_ref) {

@@ -203,13 +203,13 @@ class Engine:
         return st
 
     def selftest_pk(self, a, b, c):
-        """a, b, c (n,) complex64 -> (out_hw, out_ref), each (n, 17) complex64: the packed complex operations of
+        """a, b, c (n,) complex64 -> (out_hw, out_ref), each (n, 23) complex64: the packed complex operations of
         csrc/pk.h through the v_pk_* instruction forms and through their C++ statement (include/disco_hip.h)."""
         n = a.shape[0]
         pa, ka = self.to_device(a, np.complex64)
         pb, kb = self.to_device(b, np.complex64)
         pc, kc = self.to_device(c, np.complex64)
-        hw, ref = self.empty((n, 17), np.complex64), self.empty((n, 17), np.complex64)
+        hw, ref = self.empty((n, 23), np.complex64), self.empty((n, 23), np.complex64)
         self._chk(self.lib.disco_selftest_pk(self.ctx, pa, pb, pc, n, hw.ptr, ref.ptr, self.stream))
         return hw, ref
 

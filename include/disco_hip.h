@@ -478,7 +478,7 @@ int disco_selftest_stream(disco_ctx* ctx, const float* src, float* dst, int64_t 
 #define DISCO_DPP_SELFTEST_OPS 8
 int disco_selftest_dpp(disco_ctx* ctx, const double* a, const double* b, int64_t n, double* out_hw, double* out_ref, disco_stream s);
 
-#define DISCO_PK_SELFTEST_OPS 17
+#define DISCO_PK_SELFTEST_OPS 23
 int disco_selftest_pk(disco_ctx* ctx, const disco_c32* a, const disco_c32* b, const disco_c32* c, int64_t n,
                       disco_c32* out_hw, disco_c32* out_ref, disco_stream s);
 

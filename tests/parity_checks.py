@@ -925,7 +925,9 @@ def check_pk_selftest(make_engine, n=4096, seed=11):
     h = 0.70710678118654752440
     kt = 0.92387953251128675613 - 0.38268343236508977173j
     want = [A + np.conj(B), -1j * (A - np.conj(B)), A - 1j * B, A + 1j * B, np.conj(A + 1j * B), (1 - 1j) * A, (1 + 1j) * A,
-            A * B, A * kt, A * np.conj(B), C_ + np.conj(A) * B, C_ + h * A, C_ - h * A, A * B.real, A * B.imag, C_ + A * B.imag, C_ + A * B]
+            A * B, A * kt, A * np.conj(B), C_ + np.conj(A) * B, C_ + h * A, C_ - h * A, A * B.real, A * B.imag, C_ + A * B.imag, C_ + A * B,
+            A.real * B.real + 1j * A.imag * B.imag, C_ + A.real * B.real + 1j * A.imag * B.imag, C_ + A.real * B, C_ + 1j * A.imag * B,
+            C_ - 1j * A.imag * B, C_ + A * B.real]
     errs = {}
     for q, w in enumerate(want):
         errs[q] = float(np.abs(hw[:, q] - w).max() / np.abs(w).max())
