@@ -273,6 +273,9 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeom<M, K>::NT), DISCO_ROOM
 // asm: hipcc's own LDS-DMA tracking would wait for vmcnt(0) before every LDS read, the ring index being a run-time value); every
 // iteration waits for everything it issued, so nothing depends on the order in which loads and stores retire.  The kernel must
 // not spill: build.py checks the resource usage.
+#ifndef DISCO_ROOM_EXP
+#define DISCO_ROOM_EXP 0
+#endif
 #ifndef DISCO_ROOM_DEPTH
 #define DISCO_ROOM_DEPTH 6              // ring slots: two groups per iteration, issued two iterations ahead
 #endif
@@ -644,23 +647,27 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
     int s0 = 0, zb0 = 0;                                // ring slot / z buffer of the fold position's first group
     int rp = rd, fp = fd;                               // the item whose last groups were folded in the previous iteration (pending)
     bool pending = false;
+    // DISCO_ROOM_EXP (default 0): TIMING-ONLY builds with parts of the loop body removed -- bit 0 the folds, 1 the z formation, 2 the loads,
+    // 3 the barrier; the results are garbage (tools/gpu/mk_room_exp.sh, profiles/r04_u_room_parts.txt)
     while (true) {
-        if (vi) {
+        if (vi && !(DISCO_ROOM_EXP & 4)) {
             if (ji == 0) issue_taps(ri, fi, ni & 1);    // (the form position left that buffer's item an iteration ago)
             issue(ri, fi, 2 * ji, (s0 + 4) % D);
             issue(ri, fi, 2 * ji + 1, (s0 + 5) % D);
         }
         if (pending) finish(rp, fp);
-        if (vf) {
+        if (vf && !(DISCO_ROOM_EXP & 2)) {
             form_z(rf, ff, 2 * jf, (s0 + 2) % D, zb0 ^ 2, nf & 1);
             form_z(rf, ff, 2 * jf + 1, (s0 + 3) % D, (zb0 ^ 2) + 1, nf & 1);
         }
-        fold(fd, 2 * jd, s0, zb0);
-        fold(fd, 2 * jd + 1, (s0 + 1) % D, zb0 + 1);
+        if (!(DISCO_ROOM_EXP & 1)) {
+            fold(fd, 2 * jd, s0, zb0);
+            fold(fd, 2 * jd + 1, (s0 + 1) % D, zb0 + 1);
+        }
         pending = jd == J - 1;
         rp = rd, fp = fd;
         vm_wait_all();
-        __syncthreads();
+        if (!(DISCO_ROOM_EXP & 8)) __syncthreads();
         if (!vf) break;                                 // the fold position was this workgroup's last iteration
         s0 = (s0 + 2) % D;
         zb0 ^= 2;

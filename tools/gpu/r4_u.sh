@@ -1,3 +1,5 @@
+#!/bin/bash
+# Round 4, pass u: the room pass with parts of its loop body removed (libraries from tools/gpu/mk_room_exp.sh 1 2 4 8 3 7): C5 step and room_cov2 time
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 for e in 0 1 2 4 8 3 7; do
   if [ $e = 0 ]; then L=disco_amd/lib/libdisco_hip.so; else L=exp_libs/libdisco_roomexp$e.so; fi
