@@ -24,9 +24,9 @@ bool apply_istft_wide_ok(const disco_ctx* ctx) {
 int apply_istft_wide(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, disco_c32* yf, float* out, disco_stream s) {
     const disco_cfg& c = ctx->cfg;
     if (!apply_istft_wide_ok(ctx)) return DISCO_E_UNSUPPORTED;
-    const int K = c.nodes, WV = c.n_fft / 128;
+    const int K = c.nodes, WV = c.n_fft / 256;        // runs of frame pairs per workgroup (= its transform waves)
     const int n_seg = (c.length + c.hop - 1) / c.hop;
-    // a workgroup = one node x WV runs of `pairs` frame pairs.  Runs as long as the signal allows while the grid keeps >= ~8 workgroups per
+    // a workgroup = one node x WV runs of `pairs` frame pairs (2 WV filter waves + WV transform waves).  Runs as long as the signal allows while the grid keeps >= ~8 workgroups per
     // CU (a run re-reads one frame of its predecessor: 1 / (2 pairs - 1) of the traffic)
     const long long nodes = (long long)ctx->geom_rooms * K;
     const long long chunks_wanted = std::max<long long>(1, (8LL * ctx->n_cu + nodes - 1) / nodes);
@@ -54,10 +54,10 @@ int apply_istft_wide(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, con
     if (!launched && c.mics == M_ && K == K_) {                                                                                             \
         launched = true;                                                                                                                    \
         if (c.n_fft == 1024)                                                                                                                \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_istft_wide<1024, M_, K_ - 1>), dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)s, a,   \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_istft_wide<1024, M_, K_ - 1>), dim3((unsigned)nblk), dim3(768), 0, (hipStream_t)s, a,   \
                                ctx->d_win, ctx->d_tw);                                                                                      \
         else                                                                                                                                \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_istft_wide<512, M_, K_ - 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, a,    \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_istft_wide<512, M_, K_ - 1>), dim3((unsigned)nblk), dim3(384), 0, (hipStream_t)s, a,    \
                                ctx->d_win, ctx->d_tw);                                                                                      \
     }
     DISCO_FOR_ROOM(X_)

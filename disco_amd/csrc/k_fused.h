@@ -449,19 +449,24 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 :
 // ---- the final filter + iSTFT of the WIDE shapes in one pass (tango.py:445 + 528; P = M + K - 1 > 8; round 4) ------------------------------
 // disco_apply(X, z, w_glo) followed by disco_istft wrote yf (8 F bytes per node-frame) and read it back: 4.3 GB of C5's step, and the iSTFT
 // pass ran at half the rate of the filter pass.  The narrow kernel above keeps a node's filters in registers with a lane owning 9 bins; 9 x 15
-// complex taps do not fit.  So the two halves of the work are split DIFFERENTLY over the WV = N / 128 waves of a workgroup, which serves one
-// node and WV consecutive runs of frame pairs:
-//   filter:  wave w owns the BINS 64 w + lane (k_apply_mq's layout: the P taps of one bin in registers, the node's spectra fetched as
-//            contiguous 16-byte granules through a swizzled LDS tile, the K - 1 remote z rows as contiguous rows) and filters, per step, the
-//            frame pair of EVERY run: 2 WV frames -> an LDS ring [2 WV][F];
-//   iSTFT:   wave w owns RUN w (k_step2_apply_istft's layout: lane holds bins lane + 64 j of both frames of its pair, read from the ring),
-//            packs the pair into one complex inverse FFT, windows, overlap-adds against the half frame it carries in registers, stores hop
-//            segments.  The FFT scratch of a wave doubles as its granule tile (the two uses alternate).
-// The Nyquist bin (the 513th of 1024 / 2 + 1) has no lane in the WV full tiles: lanes 0 / 1 of wave w filter it for the two frames of run w's
-// pair with plain loads issued at the top of the step; its taps sit in LDS.
+// complex taps do not fit.  Here a workgroup serves one node and NR = N / 256 consecutive runs of frame pairs with TWO KINDS OF WAVES:
+//   WF = N / 128 filter waves: wave w owns the BINS 64 w + lane (k_apply_mq's layout: the P taps of one bin in registers, the node's spectra
+//            fetched as contiguous 16-byte granules through a wave-private swizzled LDS tile, the K - 1 remote z rows as contiguous rows) and
+//            filters, per step, the frame pair of EVERY run: 2 NR frames -> one of two LDS rings [2 NR][F].  Its loads run two frames ahead
+//            and never pause;
+//   NR transform waves: wave x owns RUN x (k_step2_apply_istft's layout: lane holds bins lane + 64 j of both frames of its pair, read from
+//            the ring the filter waves have just completed), packs the pair into one complex inverse FFT, windows, overlap-adds against the
+//            half frame it carries in registers, stores hop segments -- while the filter waves fill the other ring.
+// ONE barrier per step: the filter waves arrive with ring pr & 1 written, the transform waves with ring (pr - 1) & 1 read.
+// (The first version gave every wave both roles in turn -- 16 frames filtered, barrier, one transform per wave, barrier: its loads stood
+// still during the transforms, 0.8 of its 4.3 ms per C5 launch, and the second frame's look-ahead had to be re-issued behind them for lack of
+// registers: profiles/r04_v_wide_parts.txt.  This form: 4.36 against 4.62 + 1.07 ms for disco_apply + disco_istft on the same box, 21.7 GB
+// of traffic at 5 TB/s: the read rate of the filter pass itself.)
+// The Nyquist bin (the 513th of 1024 / 2 + 1) has no lane in the WF full tiles: filter wave w handles it for frame w of the step, one value
+// per lane loaded at the top of the step, lane 0 doing the arithmetic; its taps sit in LDS.
 // The arithmetic of a bin is k_apply_mq's instruction for instruction, the transform and the overlap-add are k_step2_apply_istft's.
 // grid: (chunk, room, node) items, node fastest, dealt XCD-aware (the nodes of a room read the same z rows); a workgroup covers
-// WV * (2 * pairs - 1) hop segments, consecutive runs overlap by one frame.
+// NR * (2 * pairs - 1) hop segments, consecutive runs overlap by one frame.
 struct ApplyIstftWideArgs {
     const c32* X;        // [R][K][T][F][M]
     const c32* Z;        // [R][K][T][F]
@@ -473,24 +478,29 @@ struct ApplyIstftWideArgs {
 };
 template <int N, int M, int KR>
 struct alignas(16) ApplyIstftWideShared {
-    static constexpr int WV = N / 128, F = N / 2 + 1;
+    static constexpr int WF = N / 128, NR = N / 256, F = N / 2 + 1;
     static constexpr int NT1 = WaveTw<N>::Q1 * (FftPlan<N>::R1 - 1), NT2 = WaveTw<N>::Q2 * (FftPlan<N>::R2 - 1), EH = FftPlan<N>::E / 2;
     static constexpr int NL = M / 2 + KR;               // loads of one frame's Nyquist bin: M / 2 granules of X + KR remote z's
-    c32 buf[WV][fft_buf_len<N>()];
-    c32 ring[2 * WV][F + 1];
-    c32 twl[NT1 + NT2][64];                             // WaveTw<N> and OlaWeights<N>, lane-minor: the same for every wave, 72 registers each
-    float olw[2 * EH][64];                              // wave would hold across the filter loop
-    float4 nyq[WV][2 * NL];
+    float4 tile[WF][64 * (M / 2)];                      // a filter wave's granules of one frame, swizzled
+    c32 buf[NR][fft_buf_len<N>()];                      // a transform wave's FFT scratch
+    c32 ring[2][2 * NR][F + 1];
+    c32 twl[NT1 + NT2][64];                             // WaveTw<N> and OlaWeights<N>, lane-minor: the same for every transform wave, loaded per pass
+    float olw[2 * EH][64];
+    float4 nyq[WF][NL];
     c32 wn[M + KR + 1];
 };
+#ifndef DISCO_WIDE_EXP
+#define DISCO_WIDE_EXP 0                                // TIMING-ONLY builds: bit 0 no transform / overlap-add, 1 no filter arithmetic, 2 no loads (garbage results)
+#endif
 template <int N, int M, int KR>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__(N / 2, 1) void k_apply_istft_wide(ApplyIstftWideArgs a, const float* __restrict__ win,
-                                                                                const c32* __restrict__ tw) {
-    constexpr int WV = N / 128, E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, NJ = EH + 1, P = M + KR, K = KR + 1;
-    constexpr int MH = M / 2, BPR = 16 / MH;
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * (N / 128 + N / 256), 1) void k_apply_istft_wide(ApplyIstftWideArgs a, const float* __restrict__ win,
+                                                                                                     const c32* __restrict__ tw) {
+    using Sh = ApplyIstftWideShared<N, M, KR>;
+    constexpr int WF = Sh::WF, NR = Sh::NR, E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, NJ = EH + 1, P = M + KR, K = KR + 1;
+    constexpr int MH = M / 2, BPR = 16 / MH, NL = Sh::NL;
     static_assert(M == 4 || M == 8, "whole 256-byte bank rows per group of bins");
-    static_assert(64 * MH * sizeof(float4) <= fft_buf_len<N>() * sizeof(c32), "the granule tile lives in the wave's FFT scratch");
-    __shared__ ApplyIstftWideShared<N, M, KR> sh;
+    static_assert(2 * NR == WF && NL <= 64, "filter wave w takes the Nyquist bin of frame w of a step");
+    __shared__ Sh sh;
     const int wv = wave_id(), lane = threadIdx.x & 63;
     const int T = a.T;
     const long long n_items = a.R * K * (long long)a.chunks;
@@ -502,56 +512,15 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(N / 2, 1) void k_apply_istft_wid
     const int chunk = (int)(item / a.R);
     const long long g = r * K + k;
     const int run_len = 2 * a.pairs - 1;
-    const int s_base = chunk * WV * run_len;                                 // run u starts at frame (= hop segment) s_base + u * run_len
+    const int s_base = chunk * NR * run_len;                                 // run u starts at frame (= hop segment) s_base + u * run_len
     const long long TF = (long long)T * F;
-    // ---- filter role: bin f of the tile, its taps (conjugated once, as k_apply_mq with conj_w = 1)
-    const int f = wv * 64 + lane;
-    const c32* wf = a.w + (g * F + f) * (long long)P;
-    c32 wl[M], wr[KR];
-#pragma unroll
-    for (int i = 0; i < M; ++i) wl[i] = make_float2(wf[i].x, -1.f * wf[i].y);
-    const c32* zrow[KR];                                                     // (wave-uniform) remote rows in concatenate_signals order
-#pragma unroll
-    for (int jj = 0; jj < KR; ++jj) {
-        wr[jj] = make_float2(wf[M + jj].x, -1.f * wf[M + jj].y);
-        zrow[jj] = a.Z + (r * K + (jj < k ? jj : jj + 1)) * TF;
-    }
+    auto frame_of = [&](int pr, int u, int fr) { return s_base + u * run_len + 2 * pr + fr; };
+    // tables every wave reads: the Nyquist bin's taps (conjugated once), the transform waves' twiddles and overlap-add weights
     if (threadIdx.x < P) {
         const c32 t_ = a.w[(g * F + (F - 1)) * (long long)P + threadIdx.x];
         sh.wn[threadIdx.x] = make_float2(t_.x, -1.f * t_.y);
     }
-    // granule r * 64 + lane of the tile's frame = (bin b, granule lane % MH); LDS position of that granule (k_apply_mq)
-    int lgo[MH], lpos[MH];
-#pragma unroll
-    for (int q_ = 0; q_ < MH; ++q_) {
-        const int gi = q_ * 64 + lane, b = gi / MH, pp = gi % MH;
-        lgo[q_] = (wv * 64 + b) * MH + pp;
-        lpos[q_] = b * MH + (pp ^ ((b / BPR) % MH));
-    }
-    const int swz = (lane / BPR) % MH;
-    float4* sx = reinterpret_cast<float4*>(sh.buf[wv]);
-    const float4* Xq = reinterpret_cast<const float4*>(a.X + g * TF * M);
-    c32* yg = a.yf ? a.yf + g * TF : nullptr;
-    auto frame_of = [&](int pr, int u, int fr) { return s_base + u * run_len + 2 * pr + fr; };
-    float q[2][MH][4];                                  // (scalars on purpose, see k_apply_mq)
-    c32 zq[2][KR];
-    auto fetch = [&](int pr, int u, int fr) {
-        const long long tF = (long long)min(frame_of(pr, u, fr), T - 1) * F;   // frames past the signal: clamped (finite) data, zeroed at the ring
-#pragma unroll
-        for (int q_ = 0; q_ < MH; ++q_) {
-            const float4 v = Xq[tF * MH + lgo[q_]];
-            q[fr][q_][0] = v.x;
-            q[fr][q_][1] = v.y;
-            q[fr][q_][2] = v.z;
-            q[fr][q_][3] = v.w;
-        }
-#pragma unroll
-        for (int jj = 0; jj < KR; ++jj) zq[fr][jj] = zrow[jj][tF + f];
-    };
-    // ---- iSTFT role: run wv.  The per-lane twiddles and overlap-add weights are the same in every wave: computed once, parked in LDS, loaded
-    // for the transform only (72 registers the filter loop's prefetch needs)
-    using Sh = ApplyIstftWideShared<N, M, KR>;
-    if (wv == 0) {
+    if (wv == WF) {
         WaveTw<N> w0;
         w0.init(tw, lane);
         OlaWeights<N> o0;
@@ -566,143 +535,192 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(N / 2, 1) void k_apply_istft_wid
             sh.olw[EH + e][lane] = o0.cB[e];
         }
     }
-    float carry[EH];
+    if (wv < WF) {
+        // ================= filter wave: bin f of tile wv, its taps (conjugated once, as k_apply_mq with conj_w = 1)
+        const int f = wv * 64 + lane;
+        const c32* wf = a.w + (g * F + f) * (long long)P;
+        c32 wl[M], wr[KR];
 #pragma unroll
-    for (int e = 0; e < EH; ++e) carry[e] = 0.f;
-    float* og = a.out + g * (long long)a.L;
-    const int s0 = s_base + wv * run_len;
-    // Nyquist bin of this wave's own pair: load i of frame fr sits in lane fr * NL + i (a granule of X or one remote z)
-    constexpr int NL = Sh::NL;
-    const int n_fr = lane / NL, n_i = lane % NL;
-    const bool n_ld = lane < 2 * NL, n_isx = n_i < MH;
-    const int n_jj = max(n_i - MH, 0);
-    const float* n_src = n_isx ? reinterpret_cast<const float*>(Xq + (long long)(F - 1) * MH + n_i)
-                               : reinterpret_cast<const float*>(a.Z + (r * K + (n_jj < k ? n_jj : n_jj + 1)) * TF + (F - 1));
-    const long long n_stride = n_isx ? (long long)F * M * 2 : (long long)F * 2;        // floats per frame
-    fetch(0, 0, 0);
-    fetch(0, 0, 1);
-    __syncthreads();                                    // wn, twl, olw
-    for (int pr = 0; pr < a.pairs; ++pr) {
-        // Nyquist bin of this wave's own pair: loads issued now (one per lane), used after the tile loop
-        float nv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (n_ld) {
-            const float* p_ = n_src + (long long)min(frame_of(pr, wv, n_fr), T - 1) * n_stride;
-            if (n_isx) {
-                const float4 v = *reinterpret_cast<const float4*>(p_);
-                nv[0] = v.x;
-                nv[1] = v.y;
-                nv[2] = v.z;
-                nv[3] = v.w;
-            } else {
-                const float2 v = *reinterpret_cast<const float2*>(p_);
-                nv[0] = v.x;
-                nv[1] = v.y;
-            }
+        for (int i = 0; i < M; ++i) wl[i] = make_float2(wf[i].x, -1.f * wf[i].y);
+        const c32* zrow[KR];                                                 // (wave-uniform) remote rows in concatenate_signals order
+#pragma unroll
+        for (int jj = 0; jj < KR; ++jj) {
+            wr[jj] = make_float2(wf[M + jj].x, -1.f * wf[M + jj].y);
+            zrow[jj] = a.Z + (r * K + (jj < k ? jj : jj + 1)) * TF;
         }
-        for (int u = 0; u < WV; ++u) {
-            const bool wrap = u + 1 == WV;
-            const int pn = wrap ? min(pr + 1, a.pairs - 1) : pr, un = wrap ? 0 : u + 1;     // (the last pair again at the very end)
+        // granule r * 64 + lane of the tile's frame = (bin b, granule lane % MH); LDS position of that granule (k_apply_mq)
+        int lgo[MH], lpos[MH];
 #pragma unroll
-            for (int fr = 0; fr < 2; ++fr) {
-                DISCO_LDS_WAR();                        // the wave's previous use of the tile (a frame's reads, its inverse FFT) is over
+        for (int q_ = 0; q_ < MH; ++q_) {
+            const int gi = q_ * 64 + lane, b = gi / MH, pp = gi % MH;
+            lgo[q_] = (wv * 64 + b) * MH + pp;
+            lpos[q_] = b * MH + (pp ^ ((b / BPR) % MH));
+        }
+        const int swz = (lane / BPR) % MH;
+        float4* sx = sh.tile[wv];
+        const float4* Xq = reinterpret_cast<const float4*>(a.X + g * TF * M);
+        c32* yg = a.yf ? a.yf + g * TF : nullptr;
+        float q[2][MH][4];                              // (scalars on purpose, see k_apply_mq)
+        c32 zq[2][KR];
+        auto fetch = [&](int pr, int u, int fr) {
+            if (DISCO_WIDE_EXP & 4) return;
+            const long long tF = (long long)min(frame_of(pr, u, fr), T - 1) * F;   // frames past the signal: clamped (finite) data, zeroed at the ring
 #pragma unroll
-                for (int q_ = 0; q_ < MH; ++q_) sx[lpos[q_]] = make_float4(q[fr][q_][0], q[fr][q_][1], q[fr][q_][2], q[fr][q_][3]);
-                c32 z[KR];
+            for (int q_ = 0; q_ < MH; ++q_) {
+                const float4 v = Xq[tF * MH + lgo[q_]];
+                q[fr][q_][0] = v.x;
+                q[fr][q_][1] = v.y;
+                q[fr][q_][2] = v.z;
+                q[fr][q_][3] = v.w;
+            }
 #pragma unroll
-                for (int jj = 0; jj < KR; ++jj) z[jj] = zq[fr][jj];
-                DISCO_LDS_RAW();
-                // the same frame slot of the next pair is on its way while this one is filtered -- except the second frame across the
-                // transform (its 30 registers are what the radix-16 pass needs): issued after it
-                if (!(wrap && fr == 1)) fetch(pn, un, fr);
-                c32 x[M];
-#pragma unroll
-                for (int pp = 0; pp < MH; ++pp) {
-                    const float4 v = sx[lane * MH + (pp ^ swz)];
-                    x[2 * pp] = make_float2(v.x, v.y);
-                    x[2 * pp + 1] = make_float2(v.z, v.w);
+            for (int jj = 0; jj < KR; ++jj) zq[fr][jj] = zrow[jj][tF + f];
+        };
+        // Nyquist bin of frame wv of a step (run wv / 2, frame wv % 2): load i sits in lane i (a granule of X or one remote z)
+        const bool n_ld = lane < NL, n_isx = lane < MH;
+        const int n_jj = max(lane - MH, 0);
+        const float* n_src = n_isx ? reinterpret_cast<const float*>(Xq + (long long)(F - 1) * MH + lane)
+                                   : reinterpret_cast<const float*>(a.Z + (r * K + (n_jj < k ? n_jj : n_jj + 1)) * TF + (F - 1));
+        const long long n_stride = n_isx ? (long long)F * M * 2 : (long long)F * 2;        // floats per frame
+        fetch(0, 0, 0);
+        fetch(0, 0, 1);
+        __syncthreads();                                // wn (and the transform waves' tables)
+        for (int pr = 0; pr < a.pairs; ++pr) {
+            c32(*ring)[F + 1] = sh.ring[pr & 1];
+            const int tn = frame_of(pr, wv / 2, wv & 1);
+            float nv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n_ld && !(DISCO_WIDE_EXP & 4)) {
+                const float* p_ = n_src + (long long)min(tn, T - 1) * n_stride;
+                if (n_isx) {
+                    const float4 v = *reinterpret_cast<const float4*>(p_);
+                    nv[0] = v.x;
+                    nv[1] = v.y;
+                    nv[2] = v.z;
+                    nv[3] = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(p_);
+                    nv[0] = v.x;
+                    nv[1] = v.y;
                 }
-                DISCO_LDS_RAW();
+            }
+            for (int u = 0; u < NR; ++u) {
+                const bool wrap = u + 1 == NR;
+                const int pn = wrap ? min(pr + 1, a.pairs - 1) : pr, un = wrap ? 0 : u + 1;     // (the last pair again at the very end)
+#pragma unroll
+                for (int fr = 0; fr < 2; ++fr) {
+                    DISCO_LDS_WAR();                    // the previous frame's reads of the tile are over
+#pragma unroll
+                    for (int q_ = 0; q_ < MH; ++q_) sx[lpos[q_]] = make_float4(q[fr][q_][0], q[fr][q_][1], q[fr][q_][2], q[fr][q_][3]);
+                    c32 z[KR];
+#pragma unroll
+                    for (int jj = 0; jj < KR; ++jj) z[jj] = zq[fr][jj];
+                    DISCO_LDS_RAW();
+                    fetch(pn, un, fr);                  // the same frame slot of the next pair is on its way while this one is filtered
+                    c32 x[M];
+#pragma unroll
+                    for (int pp = 0; pp < MH; ++pp) {
+                        const float4 v = sx[lane * MH + (pp ^ swz)];
+                        x[2 * pp] = make_float2(v.x, v.y);
+                        x[2 * pp + 1] = make_float2(v.z, v.w);
+                    }
+                    DISCO_LDS_RAW();
+                    float ar = 0.f, ai = 0.f;
+                    if (!(DISCO_WIDE_EXP & 2)) {
+#pragma unroll
+                        for (int i = 0; i < M; ++i) {
+                            ar = fmaf(wl[i].x, x[i].x, fmaf(-wl[i].y, x[i].y, ar));
+                            ai = fmaf(wl[i].x, x[i].y, fmaf(wl[i].y, x[i].x, ai));
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < KR; ++jj) {
+                            ar = fmaf(wr[jj].x, z[jj].x, fmaf(-wr[jj].y, z[jj].y, ar));
+                            ai = fmaf(wr[jj].x, z[jj].y, fmaf(wr[jj].y, z[jj].x, ai));
+                        }
+                    } else {
+                        ar = x[0].x + z[0].x;
+                        ai = x[M - 1].y + z[KR - 1].y;
+                    }
+                    const int t = frame_of(pr, u, fr);
+                    ring[2 * u + fr][f] = t < T ? make_float2(ar, ai) : make_float2(0.f, 0.f);
+                    if (yg && t < T) yg[(long long)t * F + f] = make_float2(ar, ai);
+                }
+            }
+            if (n_ld) sh.nyq[wv][lane] = make_float4(nv[0], nv[1], nv[2], nv[3]);
+            DISCO_LDS_RAW();
+            if (lane == 0) {
+                const float4* nb = sh.nyq[wv];
                 float ar = 0.f, ai = 0.f;
 #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    ar = fmaf(wl[i].x, x[i].x, fmaf(-wl[i].y, x[i].y, ar));
-                    ai = fmaf(wl[i].x, x[i].y, fmaf(wl[i].y, x[i].x, ai));
+                for (int pp = 0; pp < MH; ++pp) {
+                    const float4 v = nb[pp];
+                    const c32 w0_ = sh.wn[2 * pp], w1_ = sh.wn[2 * pp + 1];
+                    ar = fmaf(w0_.x, v.x, fmaf(-w0_.y, v.y, ar));
+                    ai = fmaf(w0_.x, v.y, fmaf(w0_.y, v.x, ai));
+                    ar = fmaf(w1_.x, v.z, fmaf(-w1_.y, v.w, ar));
+                    ai = fmaf(w1_.x, v.w, fmaf(w1_.y, v.z, ai));
                 }
 #pragma unroll
                 for (int jj = 0; jj < KR; ++jj) {
-                    ar = fmaf(wr[jj].x, z[jj].x, fmaf(-wr[jj].y, z[jj].y, ar));
-                    ai = fmaf(wr[jj].x, z[jj].y, fmaf(wr[jj].y, z[jj].x, ai));
+                    const c32 w_ = sh.wn[M + jj];
+                    const float4 v = nb[MH + jj];
+                    ar = fmaf(w_.x, v.x, fmaf(-w_.y, v.y, ar));
+                    ai = fmaf(w_.x, v.y, fmaf(w_.y, v.x, ai));
                 }
-                const int t = frame_of(pr, u, fr);
-                sh.ring[2 * u + fr][f] = t < T ? make_float2(ar, ai) : make_float2(0.f, 0.f);
-                if (yg && t < T) yg[(long long)t * F + f] = make_float2(ar, ai);
+                ring[wv][F - 1] = tn < T ? make_float2(ar, ai) : make_float2(0.f, 0.f);
+                if (yg && tn < T) yg[(long long)tn * F + (F - 1)] = make_float2(ar, ai);
             }
+            __syncthreads();                            // ring pr & 1 is complete; the transform waves have read ring (pr - 1) & 1
         }
-        if (n_ld) sh.nyq[wv][lane] = make_float4(nv[0], nv[1], nv[2], nv[3]);
-        DISCO_LDS_RAW();
-        if (lane < 2) {
-            const float4* nb = &sh.nyq[wv][lane * NL];
-            const int tn = frame_of(pr, wv, lane);
-            float ar = 0.f, ai = 0.f;
+    } else {
+        // ================= transform wave: run x
+        const int x_ = wv - WF;
+        float carry[EH];
 #pragma unroll
-            for (int pp = 0; pp < MH; ++pp) {
-                const float4 v = nb[pp];
-                const c32 w0_ = sh.wn[2 * pp], w1_ = sh.wn[2 * pp + 1];
-                ar = fmaf(w0_.x, v.x, fmaf(-w0_.y, v.y, ar));
-                ai = fmaf(w0_.x, v.y, fmaf(w0_.y, v.x, ai));
-                ar = fmaf(w1_.x, v.z, fmaf(-w1_.y, v.w, ar));
-                ai = fmaf(w1_.x, v.w, fmaf(w1_.y, v.z, ai));
-            }
+        for (int e = 0; e < EH; ++e) carry[e] = 0.f;
+        float* og = a.out + g * (long long)a.L;
+        const int s0 = s_base + x_ * run_len;
+        __syncthreads();                                // (tables)
+        for (int pr = 0; pr < a.pairs; ++pr) {
+            __syncthreads();                            // the filter waves have completed ring pr & 1
+            const c32(*ring)[F + 1] = sh.ring[pr & 1];
+            const int tA = s0 + 2 * pr;
+            if (tA - 1 < T && !(DISCO_WIDE_EXP & 1)) {  // (wave-uniform) else: a run past the signal's end, nothing left to emit
+                c32 yf[2][NJ];
 #pragma unroll
-            for (int jj = 0; jj < KR; ++jj) {
-                const c32 w_ = sh.wn[M + jj];
-                const float4 v = nb[MH + jj];
-                ar = fmaf(w_.x, v.x, fmaf(-w_.y, v.y, ar));
-                ai = fmaf(w_.x, v.y, fmaf(w_.y, v.x, ai));
-            }
-            sh.ring[2 * wv + lane][F - 1] = tn < T ? make_float2(ar, ai) : make_float2(0.f, 0.f);
-            if (yg && tn < T) yg[(long long)tn * F + (F - 1)] = make_float2(ar, ai);
-        }
-        __syncthreads();                                // the 2 WV filtered frames of this step are in the ring
-        const int tA = s0 + 2 * pr;
-        c32 yf[2][NJ];
+                for (int fr = 0; fr < 2; ++fr) {
 #pragma unroll
-        for (int fr = 0; fr < 2; ++fr) {
-#pragma unroll
-            for (int j = 0; j < EH; ++j) yf[fr][j] = sh.ring[2 * wv + fr][lane + 64 * j];
-            yf[fr][EH] = sh.ring[2 * wv + fr][F - 1];
-        }
-        __syncthreads();                                // ... and in registers: the next step may overwrite it
-        if (tA - 1 < T) {                               // (wave-uniform) else: a run past the signal's end, nothing left to emit
-            c32 v[E];
-            irfft_pair_pack<N>(yf[0], yf[1], v, lane);
-            {                                           // fft_wave<N> with each pass' twiddles fetched from LDS when the pass needs them
-                using Pl = FftPlan<N>;
-                c32* buf = sh.buf[wv];
-                DISCO_LDS_WAR();
-                fft_pass<N, Pl::R0, 1, true, false>(v, nullptr, buf, lane);
-                {
-                    c32 t1[Sh::NT1];
-#pragma unroll
-                    for (int i = 0; i < Sh::NT1; ++i) t1[i] = sh.twl[i][lane];
-                    fft_pass<N, Pl::R1, Pl::R0, false, false>(v, t1, buf, lane);
+                    for (int j = 0; j < EH; ++j) yf[fr][j] = ring[2 * x_ + fr][lane + 64 * j];
+                    yf[fr][EH] = ring[2 * x_ + fr][F - 1];
                 }
-                {
-                    c32 t2[Sh::NT2];
+                c32 v[E];
+                irfft_pair_pack<N>(yf[0], yf[1], v, lane);
+                {                                       // fft_wave<N> with each pass' twiddles fetched from LDS when the pass needs them
+                    using Pl = FftPlan<N>;
+                    c32* buf = sh.buf[x_];
+                    DISCO_LDS_WAR();
+                    fft_pass<N, Pl::R0, 1, true, false>(v, nullptr, buf, lane);
+                    {
+                        c32 t1[Sh::NT1];
 #pragma unroll
-                    for (int i = 0; i < Sh::NT2; ++i) t2[i] = sh.twl[Sh::NT1 + i][lane];
-                    fft_pass<N, Pl::R2, Pl::R0 * Pl::R1, false, true>(v, t2, buf, lane);
+                        for (int i = 0; i < Sh::NT1; ++i) t1[i] = sh.twl[i][lane];
+                        fft_pass<N, Pl::R1, Pl::R0, false, false>(v, t1, buf, lane);
+                    }
+                    {
+                        c32 t2[Sh::NT2];
+#pragma unroll
+                        for (int i = 0; i < Sh::NT2; ++i) t2[i] = sh.twl[Sh::NT1 + i][lane];
+                        fft_pass<N, Pl::R2, Pl::R0 * Pl::R1, false, true>(v, t2, buf, lane);
+                    }
                 }
-            }
-            OlaWeights<N> ow;
+                OlaWeights<N> ow;
 #pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                ow.cA[e] = sh.olw[e][lane];
-                ow.cB[e] = sh.olw[EH + e][lane];
+                for (int e = 0; e < EH; ++e) {
+                    ow.cA[e] = sh.olw[e][lane];
+                    ow.cB[e] = sh.olw[EH + e][lane];
+                }
+                ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, a.L, lane);
             }
-            ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, a.L, lane);
         }
-        fetch(min(pr + 1, a.pairs - 1), 0, 1);
     }
 }
 
