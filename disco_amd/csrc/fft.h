@@ -26,49 +26,10 @@ struct FftPlan<1024> {
     static constexpr int R0 = 16, R1 = 16, R2 = 4;
 };
 
-// Where element a of a transform sits in the wave's exchange buffer.  Three access patterns meet there, per instruction and 32-lane half:
-//   reads   a = lane + 64 c                      (free bits 0..4)
-//   writes of the first pass   a = R0 lane + r   (free bits log R0 .. log R0 + 4)
-//   writes of the second pass  a = R0 R1 (lane / R0) + R0 r + lane % R0   (free bits: the low log R0 and log R0 R1 ...)
-// With 8-byte elements a half-wave is conflict-free when its 32 elements fall on 32 different bank pairs, i.e. when the low five bits of the
-// position differ.  Rounds 1-3 padded (a + a / 8, a + a / 16): the writes came out conflict-free, every READ two-way conflicted (a
-// half-wave's 32 consecutive elements spanned 36 positions) -- a third of the exchange's LDS cycles, the "20-30 % bank conflicts" of the
-// counters.  Round 4: an XOR swizzle, position = a ^ m(a), m linear over GF(2) and built so that its restriction to the free bits of EACH of
-// the three patterns is invertible (512: bit 5 -> 0, bit 6 -> 1 and 3, bit 7 -> 2 and 4; 1024: bits 5, 6, 7 -> 0, 1, 2, bit 8 -> 3 and 4):
-// all three conflict-free, no padding, and -- m being linear and the lane part L and the unrolled part C of every index occupying
-// disjoint bits -- position = (L ^ m(L)) ^ (C ^ m(C)): one XOR with a compile-time constant per access (fft_idx).
-#ifndef DISCO_FFT_XOR
-#define DISCO_FFT_XOR 1
-#endif
 template <int N>
-__device__ __forceinline__ constexpr int fft_pad(int a) {
-#if DISCO_FFT_XOR
-    if constexpr (N == 512) return a ^ (((a >> 5) & 1) | (((a >> 6) & 1) * 10) | (((a >> 7) & 1) * 20));
-    else if constexpr (N == 1024) return a ^ (((a >> 5) & 7) | (((a >> 8) & 1) * 24));
-    else return a + (a >> FftPlan<N>::PADSH);
-#else
-    return a + (a >> FftPlan<N>::PADSH);
-#endif
-}
-// position of element L + C, L the lane-dependent part of the index (computed once per pass) and C the unrolled part, on disjoint bits.
-// PAD (template parameter of fft_pass / fft_wave): the padded layout of rounds 1-3 -- a transform's layout is its own affair, the buffer is
-// wave-private and empty between transforms.  k_stft_cov keeps it: at its 168-register limit the three hoisted lane parts spill (7.0 -> 7.9 ms
-// per C3 launch) and forming them again for every transform costs more than the conflicts did (C2's statistics pass 4.40 -> 4.85 ms).
-// Measured (profiles/r04_x_*): fft_wave<512> 337-353 against 357-361 ns per transform and SIMD at 4 waves per SIMD; the kernels that took
-// the new layout (k_mask_oracle, k_stft_pairs, the filter + iSTFT kernels) moved by less than the box-to-box spread -- the conflicts were
-// visible in the counters, but not what bounds them.
+__device__ __forceinline__ int fft_pad(int a) { return a + (a >> FftPlan<N>::PADSH); }
 template <int N>
-__device__ __forceinline__ int fft_pad_add(int a) { return a + (a >> FftPlan<N>::PADSH); }
-template <int N>
-__device__ __forceinline__ int fft_idx(int L, int C) {
-#if DISCO_FFT_XOR
-    return fft_pad<N>(L) ^ fft_pad<N>(C);
-#else
-    return fft_pad_add<N>(L + C);
-#endif
-}
-template <int N>
-constexpr int fft_buf_len() { return N + (N >> FftPlan<N>::PADSH); }     // (the padded length of rounds 1-3: callers also park frames here)
+constexpr int fft_buf_len() { return N + (N >> FftPlan<N>::PADSH); }
 
 // ---- small DFTs, forward sign exp(-2 pi i / R), natural-order output, in place ------------------------
 // Written on the packed primitives of pk.h: every +-i rotation rides the add's operand selectors, the 1/sqrt2 rotations of
@@ -170,16 +131,15 @@ struct WaveTw {
 // One Stockham pass of radix R with P_ = product of the previous radices.
 //   butterfly i in [0, N/R): k = i mod P_; u[r] = x[i + r N/R] * W_{P_ R}^{k r}; U = DFT_R(u); y[(i-k) R + k + r P_] = U[r]
 // A lane owns the E/R butterflies i = lane + 64 q; v[q R + r] carries u[r] / U[r].
-template <int N, int R, int P_, bool FIRST, bool LAST, bool PAD = false>
+template <int N, int R, int P_, bool FIRST, bool LAST>
 __device__ __forceinline__ void fft_pass(c32* v, const c32* tw, c32* buf, int lane) {
     constexpr int E = FftPlan<N>::E, S = N / R, Q = E / R;
-    const int ln = lane;
     if constexpr (!FIRST) {
         DISCO_LDS_RAW();
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[q * R + r] = PAD ? buf[fft_pad_add<N>(lane + 64 * q + r * S)] : buf[fft_idx<N>(ln, 64 * q + r * S)];
+            for (int r = 0; r < R; ++r) v[q * R + r] = buf[fft_pad<N>(lane + 64 * q + r * S)];
         DISCO_LDS_WAR();
     }
 #pragma unroll
@@ -192,15 +152,9 @@ __device__ __forceinline__ void fft_pass(c32* v, const c32* tw, c32* buf, int la
         }
         dftR<R>(v + q * R);
         if constexpr (!LAST) {
-            if constexpr (PAD) {
-                const int o = (i - k) * R + k;
+            const int o = (i - k) * R + k;
 #pragma unroll
-                for (int r = 0; r < R; ++r) buf[fft_pad_add<N>(o + r * P_)] = v[q * R + r];
-            } else {
-                const int kl = ln & (P_ - 1), ol = (ln - kl) * R + kl;       // o = (i - k) R + k = ol + 64 q R: lane part and unrolled part
-#pragma unroll
-                for (int r = 0; r < R; ++r) buf[fft_idx<N>(ol, 64 * q * R + r * P_)] = v[q * R + r];
-            }
+            for (int r = 0; r < R; ++r) buf[fft_pad<N>(o + r * P_)] = v[q * R + r];
         }
     }
     if constexpr (LAST && (Q > 1)) {
@@ -220,13 +174,13 @@ __device__ __forceinline__ void fft_pass(c32* v, const c32* tw, c32* buf, int la
 // (Two other plans were built, measured and are NOT here: an 8 x 8 register <-> lane transpose in place of one exchange -- 408 against
 // 363 ns per transform and SIMD --, and two transforms per wave at 16 points per lane with ONE exchange -- 347 against 363: the exchange halves,
 // the butterflies grow by a quarter.  Both live in tools/gpu/kbench/fft_plans.h with their numbers in profiles/r04_k_fft_rate_one_exchange.txt.)
-template <int N, bool PAD = false>
+template <int N>
 __device__ __forceinline__ void fft_wave(c32* v, const WaveTw<N>& tw, c32* buf, int lane) {
     using Pl = FftPlan<N>;
     DISCO_LDS_WAR();        // the previous user of `buf` (an earlier item's untangle reads) is done in every lane
-    fft_pass<N, Pl::R0, 1, true, false, PAD>(v, nullptr, buf, lane);
-    fft_pass<N, Pl::R1, Pl::R0, false, false, PAD>(v, tw.t1, buf, lane);
-    fft_pass<N, Pl::R2, Pl::R0 * Pl::R1, false, true, PAD>(v, tw.t2, buf, lane);
+    fft_pass<N, Pl::R0, 1, true, false>(v, nullptr, buf, lane);
+    fft_pass<N, Pl::R1, Pl::R0, false, false>(v, tw.t1, buf, lane);
+    fft_pass<N, Pl::R2, Pl::R0 * Pl::R1, false, true>(v, tw.t2, buf, lane);
 }
 
 // Spectra of two real sequences a, b from Z = FFT(a + i b):  A[f] = (Z[f] + conj Z[N-f]) / 2,

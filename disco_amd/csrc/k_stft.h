@@ -525,7 +525,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
             for (int p = 0; p < CHP; ++p) {
                 c32 v[E];
                 apply_window<N>(v, raw[p], w, 2 * p + 1 < M);
-                fft_wave<N, true>(v, wtw, sh.buf[wave], lane);           // (the padded exchange layout: fft.h, fft_idx)
+                fft_wave<N>(v, wtw, sh.buf[wave], lane);
                 // (NOT swizzled like k_stft_pairs' tile: measured, the swizzle costs this kernel 8 % -- 7.70 against 7.10 ms per C3 launch;
                 // its stores are 2-way conflicted at worst and the copy-out below wants the plain linear read)
                 rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
