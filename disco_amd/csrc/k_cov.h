@@ -622,6 +622,132 @@ __device__ __forceinline__ void cov_loc_f64_wave(const CovArgs& a, long long g, 
     }
 }
 
+// The same wave roles with the tile's spectra FETCHED ONCE PER WORKGROUP (M = 8; round 4, late): every lane loading its own bin's mics is a
+// 16-byte access every 64 bytes, 32 lines per instruction, and the four roles fetch 2 + 2 + 3 + 3 granules of the same 4 -- 10 KB of L1
+// requests per 4 KB frame-tile (k_apply_mq's finding: 5.5 -> 4.6 ms for contiguous loads).  Here thread i of the workgroup loads granule
+// i of the frame-tile (256 granules = 64 bins x 4: 1 KiB contiguous per wave), three frames ahead in registers (4 registers per frame),
+// parks it in one of two LDS tiles -- written in load order, read bin-major, XOR-swizzled like k_apply_mq's so that both directions are
+// conflict-free -- and after ONE barrier per frame every role reads its mics from there.  The arithmetic is cov_loc_f64_wave's.
+#ifndef DISCO_COV64_AHEAD
+#define DISCO_COV64_AHEAD 3
+#endif
+template <int M>
+struct alignas(16) CovLocTile {
+    float4 x[2][64 * (M / 2)];
+    float m[2][64];
+};
+template <int M, int X0, int X1, int Y0, int Y1, bool TRI>
+__device__ __forceinline__ void cov_loc_f64_wave_tile(const CovArgs& a, long long g, int c, int tile, int lane, CovLocTile<M>& sh) {
+    using Role = CovSplitRole<M, 0, X0, X1, Y0, Y1, TRI>;
+    constexpr int P = M, NP = P * (P + 1) / 2, NX = Role::NX, NY = Role::NY, NPAIR = Role::NPAIR;
+    constexpr int MH = M / 2, BPR = 16 / MH, D = DISCO_COV64_AHEAD;
+    static_assert(M == 8 && NPAIR > 0 && X0 % 2 == 0 && X1 % 2 == 0 && Y0 % 2 == 0 && Y1 % 2 == 0, "whole granules per role; 256 threads = 256 granules");
+    const int T = a.T, F = a.F, nbin = F - 1;
+    const int t0 = (int)(((long long)T * c) / a.chunks), t1 = (int)(((long long)T * (c + 1)) / a.chunks);
+    const int f = tile * 64 + lane;
+    const bool live = f < nbin;
+    // loader: granule gi = threadIdx.x of the frame-tile = (bin lb, granule lp); bins past the last one re-read it (their weights are zero)
+    const int gi = threadIdx.x, lb = gi / MH, lp = gi % MH;
+    const int lgo = min(tile * 64 + lb, nbin) * MH + lp;
+    const int lpos = lb * MH + (lp ^ ((lb / BPR) % MH));
+    const int swz = (lane / BPR) % MH;
+    const float4* xq = reinterpret_cast<const float4*>(a.X + (g * T * (long long)F) * M);
+    const float* mp = a.mask + g * T * (long long)F + min(f, nbin);
+    const bool mload = threadIdx.x < 64;
+    double sr[NPAIR], si[NPAIR], nr[NPAIR], ni[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) sr[q] = si[q] = nr[q] = ni[q] = 0.0;
+    float pq[D][4], pm[D];                                                   // (scalars on purpose, cf. k_apply_mq)
+    auto fetch = [&](int t, int slot) {
+        const int t_ = t < t1 ? t : t1 - 1;
+        const float4 v = xq[(long long)t_ * F * MH + lgo];
+        pq[slot][0] = v.x;
+        pq[slot][1] = v.y;
+        pq[slot][2] = v.z;
+        pq[slot][3] = v.w;
+        pm[slot] = mload ? mp[(long long)t_ * F] : 0.f;
+    };
+    auto pair = [&](const c32 u, const c32 v, const double wa, const double wb, int q) {
+        const c32 p = cmul_aconjb(u, v);
+        const double pr = (double)p.x, pi = (double)p.y;
+        sr[q] = fma(wa, pr, sr[q]);
+        nr[q] = fma(wb, pr, nr[q]);
+        si[q] = fma(wa, pi, si[q]);
+        ni[q] = fma(wb, pi, ni[q]);
+    };
+    auto diag = [&](const c32 u, const double wa, const double wb, int q) {
+        const double pr = (double)fmaf(u.x, u.x, u.y * u.y);
+        sr[q] = fma(wa, pr, sr[q]);
+        nr[q] = fma(wb, pr, nr[q]);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(t0 + d, d);
+    for (int t = t0; t < t1; ++t) {
+        const int s = (t - t0) & 1;
+        sh.x[s][lpos] = make_float4(pq[0][0], pq[0][1], pq[0][2], pq[0][3]);
+        if (mload) sh.m[s][lane] = pm[0];
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pq[d][e] = pq[d + 1][e];
+            pm[d] = pm[d + 1];
+        }
+        fetch(t + D, D - 1);
+        __syncthreads();                                 // (the tile this frame's successor's successor overwrites was read before the next barrier)
+        c32 ux[NX > 0 ? NX : 1], uy[NY > 0 ? NY : 1];
+#pragma unroll
+        for (int p_ = 0; p_ < NX / 2; ++p_) {
+            const float4 v = sh.x[s][lane * MH + ((X0 / 2 + p_) ^ swz)];
+            ux[2 * p_] = make_float2(v.x, v.y);
+            ux[2 * p_ + 1] = make_float2(v.z, v.w);
+        }
+#pragma unroll
+        for (int p_ = 0; p_ < NY / 2; ++p_) {
+            const float4 v = sh.x[s][lane * MH + ((Y0 / 2 + p_) ^ swz)];
+            uy[2 * p_] = make_float2(v.x, v.y);
+            uy[2 * p_ + 1] = make_float2(v.z, v.w);
+        }
+        const float mcur = sh.m[s][lane];
+        const double m = live ? (double)mcur : 0.0, mc = live ? 1.0 - (double)mcur : 0.0;
+        const double wa = m * m, wb = mc * mc;
+        int q = 0;                                       // (the order of cov_split_accumulate / cov_split_store)
+        if constexpr (TRI) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = i; j < NX; ++j, ++q) {
+                    if (j == i) diag(ux[i], wa, wb, q);
+                    else pair(ux[i], ux[j], wa, wb, q);
+                }
+#pragma unroll
+            for (int i = 0; i < NY; ++i)
+#pragma unroll
+                for (int j = i; j < NY; ++j, ++q) {
+                    if (j == i) diag(uy[i], wa, wb, q);
+                    else pair(uy[i], uy[j], wa, wb, q);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NY; ++j, ++q) pair(ux[i], uy[j], wa, wb, q);
+        }
+    }
+    if (live) {
+        c32 hs[NPAIR], hn[NPAIR], ls[NPAIR], ln[NPAIR];
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            hs[q] = make_float2((float)sr[q], (float)si[q]);
+            hn[q] = make_float2((float)nr[q], (float)ni[q]);
+            ls[q] = make_float2((float)(sr[q] - (double)hs[q].x), (float)(si[q] - (double)hs[q].y));
+            ln[q] = make_float2((float)(nr[q] - (double)hn[q].x), (float)(ni[q] - (double)hn[q].y));
+        }
+        float4* o = a.part + (((g * (2 * a.chunks) + 2 * c) * F) + f) * (long long)NP;
+        cov_split_store<P, X0, Y0, TRI, NX, NY>(o, hs, hn);
+        cov_split_store<P, X0, Y0, TRI, NX, NY>(o + (long long)F * NP, ls, ln);
+    }
+}
+
 // grid = R*Kl * (tiles + 1) * chunks blocks of 4 waves, tiles = ceil((F - 1) / 64); partial blocks: 2 * chunks
 template <int M>
 __global__ DISCO_KERNEL_ALIGN __launch_bounds__(256) void k_cov_loc_f64(CovArgs a) {
@@ -633,6 +759,18 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(256) void k_cov_loc_f64(CovArgs 
     const int tile = bid % (tiles + 1);
     const long long g = bid / (tiles + 1);
     const int lane = threadIdx.x & 63;
+    if constexpr (M == 8) {
+        if (tile < tiles) {                              // (uniform over the workgroup) the 64-bin tiles: one fetch per workgroup
+            __shared__ CovLocTile<M> sh;
+            switch (wave_id()) {
+                case 0: cov_loc_f64_wave_tile<M, 0, MA, MA, MA, true>(a, g, c, tile, lane, sh); break;
+                case 1: cov_loc_f64_wave_tile<M, MA, M, M, M, true>(a, g, c, tile, lane, sh); break;
+                case 2: cov_loc_f64_wave_tile<M, 0, MA, MA, MB, false>(a, g, c, tile, lane, sh); break;
+                default: cov_loc_f64_wave_tile<M, 0, MA, MB, M, false>(a, g, c, tile, lane, sh); break;
+            }
+            return;
+        }
+    }
     switch (wave_id()) {
         case 0: cov_loc_f64_wave<M, 0, MA, MA, MA, true>(a, g, c, tile, lane); break;          // tri(A0)
         case 1: cov_loc_f64_wave<M, MA, M, M, M, true>(a, g, c, tile, lane); break;            // tri(A1)

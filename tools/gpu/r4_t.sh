@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 4, pass t: the room pass with one iteration's loads in flight across the barrier (counted vmcnt, raw s_barrier, ring of 8)
+# Round 4, pass t (and later): wide-shape parity tests + two C5 bench lines (used for the room-pass look-ahead and the float64 step-1 pass)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q -x -k "room_cov or iterated or overlapped or c5_full or apply_istft_wide" > gpurun_out/r04_t_tests.log 2>&1; echo "tests rc $?"; tail -3 gpurun_out/r04_t_tests.log
