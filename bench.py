@@ -57,12 +57,12 @@ CONFIGS = {
 EXTRAS = {
     # (the launch-bound C2 first, right behind the headline: a 0.9 ms step does not survive the host being shared with the oracle
     # workers of a wide-shape workload -- 2.8 instead of 0.87 ms behind C5's three 8 x 8 rooms)
-    'C2': (dict(CONFIGS['C2']), 30, 3, 3),
-    'C2x4000': (dict(CONFIGS['C2'], rooms=4000), 5, 2, 2),
-    'C5': (dict(CONFIGS['C5']), 5, 2, 3),
-    'C4': (dict(CONFIGS['C4']), 3, 1, 2),
+    'C2': (dict(CONFIGS['C2']), 30, 3, 4),
+    'C2x4000': (dict(CONFIGS['C2'], rooms=4000), 5, 2, 4),
+    'C5': (dict(CONFIGS['C5']), 5, 2, 8),       # round 5: 8 of the 200 rooms (an 8 x 8 room costs the oracle ~11 s on one core)
+    'C4': (dict(CONFIGS['C4']), 3, 1, 4),
     'C4_bf16': (dict(CONFIGS['C4'], dnn_dtype='bf16'), 3, 1, 2),      # the networks' convolutions / GEMMs on bf16 operands (explicit switch)
-    'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 1),
+    'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 3),
 }
 
 
@@ -295,7 +295,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the sampled-room oracle check after the timed region')
-    ap.add_argument('--parity-rooms', type=int, default=3)
+    ap.add_argument('--parity-rooms', type=int, default=6)
     ap.add_argument('--pmc-calibrate', action='store_true', help='also run a 4 GiB device copy (known bytes) for PMC calibration')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + --single-device: a functional test of the N > 1 bookkeeping on a box with ONE GPU (every rank computes on cuda:0, "
@@ -633,6 +633,12 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                       'mask_z_max_abs': float((dnn['mz'] - mz32).abs().max()), 'mask_z_mean_abs': float((dnn['mz'] - mz32).abs().mean()),
                       'mask_w_max_abs': float((dnn['mw'] - mw32).abs().max()), 'mask_w_mean_abs': float((dnn['mw'] - mw32).abs().mean())}
         del mz32, mw32
+    stream = None
+    if online_every > 0 and rank == 0 and not node_sharded:
+        try:
+            stream = stream_bench(eng, lib, torch, y, mask, online_every, H, F)
+        except Exception as e:                              # reported, never fatal: the whole-clip numbers above stand on their own
+            stream = {'error': repr(e)}
     mask_desc = 'oracle irm1 mask' if mask_kind == 'oracle' else ('CRNN masks in the loop (random weights, PyTorch-ROCm' + (', convolutions / GEMMs on bf16 operands)' if dnn_dtype is not None else ')'))
     par = (f'nodes of every room split over {world} GPU(s) ({Kl} per rank), one RCCL all-gather of z per step-2 iteration'
            if node_sharded else f'rooms sharded over {world} GPU(s), no data-path collective')
@@ -648,6 +654,8 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                    'iters': iters, 'parallelism': par},
         'roofline': roofline, 'stages': stages,
     }
+    if stream:
+        res['stream'] = stream
     if exchange:
         res['exchange'] = exchange
     if mask_error:
@@ -655,6 +663,46 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
     del y, s_ref, n_ref, mask, out, ws, eng
     torch.cuda.empty_cache()
     return res, ticket
+
+
+def stream_bench(eng, lib, torch, y, mask, update_every, H, F, chunk_hops=(1, 4, 16), audio_hops=64):
+    """The STREAMING entry point (disco_tango_online_stream: state in, state out; SURVEY 8f-2 "streaming latency instead of batch") on the
+    batch the whole-clip call was just timed on: after a 16-hop start, `audio_hops` hops of every room are pushed in chunks of 1, 4 and 16
+    hops -> ms per chunk and x real-time (audio time of a chunk / wall time of a chunk: > 1 means the stream keeps up with 1000 live rooms).
+    A chunk's inputs (its samples, its mask rows) are sliced out BEFORE the clock starts -- a live caller hands over exactly such blocks.
+    The bit-for-bit equality of the chunked and the whole-clip outputs is tests/ business (check_online_stream), not repeated here."""
+    R, K, M, L = y.shape
+    state = torch.empty(int(lib.disco_online_state_bytes(eng.ctx)), dtype=torch.uint8, device=y.device)
+    start = 16
+    out = {'chunks': {}, 'rooms': R, 'update_every': update_every, 'hop_ms': 1e3 * H / 16000.0,
+           'what': f'disco_tango_online_stream, {R} concurrent rooms, {audio_hops} hops of audio per chunk size after a {start}-hop start; '
+                   'latency of an output sample = one hop (the centred frame) + the chunk + ms_per_chunk'}
+    for hops in chunk_hops:
+        ws = torch.empty(int(lib.disco_online_stream_workspace_bytes(eng.ctx, max(hops, start))), dtype=torch.uint8, device=y.device)
+        o = torch.empty((R, K, max(hops, start) * H), dtype=torch.float32, device=y.device)
+
+        def push(h0, n):
+            yc = y[:, :, :, h0 * H:(h0 + n) * H].contiguous()
+            mc = mask[:, :, h0:h0 + n].contiguous()
+            return yc, mc
+        y0, m0 = push(0, start)
+        eng._chk(lib.disco_tango_online_stream(eng.ctx, y0.data_ptr(), start, m0.data_ptr(), m0.data_ptr(), 0.95, update_every, 1e-3, 0, 0,
+                                               state.data_ptr(), o.data_ptr(), ws.data_ptr(), ws.numel(), None))
+        n_chunks = max(2, audio_hops // hops)
+        blocks = [push(start + i * hops, hops) for i in range(n_chunks)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i, (yc, mc) in enumerate(blocks):
+            eng._chk(lib.disco_tango_online_stream(eng.ctx, yc.data_ptr(), hops, mc.data_ptr(), mc.data_ptr(), 0.95, update_every, 1e-3,
+                                                   start + i * hops, 0, state.data_ptr(), o.data_ptr(), ws.data_ptr(), ws.numel(), None))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_chunks
+        out['chunks'][str(hops)] = {'ms_per_chunk': round(1e3 * dt, 3), 'chunk_audio_ms': round(1e3 * hops * H / 16000.0, 2),
+                                    'x_realtime': round((hops * H / 16000.0) / dt, 2), 'chunks_timed': n_chunks,
+                                    'node_frames_per_s': round(R * K * hops / dt, 1),
+                                    'finite': bool(torch.isfinite(o[:, :, :hops * H]).all())}
+        del blocks, ws, o
+    return out
 
 
 def finish_parity(ticket, env, timeout=900.0):
@@ -693,6 +741,27 @@ def merge_extras(res, env):
     res['x_realtime'] = (res['config']['length'] / 16000.0) / (max(secs) / res['steps'])
     res['seconds_per_rank'] = secs
     return res
+
+
+def summary_rows(head_name, head, head_parity, extras):
+    """{workload: [ms_per_step, x_realtime, pipeline_frac, dominant_kernel, dominant_frac, traffic_ratio, parity_worst]} -- traffic_ratio =
+    counter traffic / algorithmic bytes of the dominant kernel (None when the counters were taken on other kernel sources)."""
+    def row(r, ps):
+        rf = r.get('roofline') or {}
+        tr = None
+        if rf.get('traffic') and rf.get('alg_bytes_per_launch') and 'traffic_note' not in rf:
+            tr = round(rf['traffic'] / rf['alg_bytes_per_launch'], 3)
+        kern = str(rf.get('kernel', ''))[:24]
+        out = [round(r['ms_per_step'], 3), round(r['x_realtime'], 1), (rf.get('pipeline') or {}).get('frac'), kern, rf.get('frac'), tr,
+               None if ps is None else float('%.3g' % ps.get('worst_rel_all_ranks', float('nan')))]
+        if 'stream' in r:       # the streaming entry point: x real-time at chunks of 1 / 4 / 16 hops
+            out.append({k: v.get('x_realtime') for k, v in r['stream'].get('chunks', {}).items()})
+        return out
+    rows = {'_cols': 'ms_per_step, x_realtime, pipeline_frac, dominant_kernel, dominant_frac_of_peak, traffic/alg_bytes, parity_worst_rel[, stream x_realtime by hops]',
+            head_name: row(head, head_parity)}
+    for nm, r in extras.items():
+        rows[nm] = row(r, r.get('parity_sample')) if 'error' not in r else 'error'
+    return rows
 
 
 def main(argv=None):
@@ -762,7 +831,7 @@ def main(argv=None):
     cfg_shape = CONFIGS[args.config]
     is_cfg = all(head_w[k] == cfg_shape[k] for k in ('nodes', 'mics', 'n_fft', 'iters', 'mask', 'online_every'))
     head_name = args.config if is_cfg else 'custom'
-    n_par = args.parity_rooms if head_w['nodes'] * head_w['mics'] <= 16 else min(args.parity_rooms, 3)
+    n_par = args.parity_rooms if head_w['nodes'] * head_w['mics'] <= 16 else min(args.parity_rooms, 8)
     head, head_ticket = run_workload(head_name, head_w, args.steps, args.warmup, env, True, n_par, args)
 
     extras, tickets = {}, {}
@@ -823,6 +892,8 @@ def main(argv=None):
             line['exchange'] = head['exchange']
         if args.extra_names:
             line['configs'] = extras
+        # LAST key, < 1.5 KB: the five numbers of every workload where a record that keeps only the tail of the line still has them
+        line['summary'] = summary_rows(head_name, head, parity, extras)
         emit(line)
     if dist is not None:
         dist.barrier()                    # leave together

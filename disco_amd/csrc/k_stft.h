@@ -435,16 +435,30 @@ namespace disco {
 // frames per wave per workgroup are a launch parameter (`runw`; a workgroup covers 4 * runw frames): long runs amortise the
 // first-frame load and the partial-sum write-out (80 is best at C3), short ones keep small batches spread over the chip
 
-template <int N, int CHP>
+// ZPITCH: pitch of a pair plane in the Z layout (DISCO_ZTILE below): N + 16 complex, i.e. consecutive planes start 32 banks apart, so the
+// copy-out's ds_read_b64 -- consecutive lanes alternate between the planes of one bin -- never meet on a bank
+template <int N>
+constexpr int stft_cov_zpitch() { return N + 16; }
+template <int N, int CHP, bool ZT>
 struct alignas(16) StftCovShared {
     c32 buf[STFT_WAVES][fft_buf_len<N>()];
-    c32 tile[STFT_WAVES][N / 2 + 1][2 * CHP];
+    c32 tile[STFT_WAVES][ZT ? CHP * stft_cov_zpitch<N>() : (N / 2 + 1) * 2 * CHP];
 };
 
 // 3 waves per SIMD (<= 168 VGPRs) is reachable for the common 512-point, M <= 4 shape and worth ~3 %; larger shapes keep
 // whatever occupancy their register need allows
 #ifndef DISCO_SC_WPE
 #define DISCO_SC_WPE 3
+#endif
+// DISCO_ZTILE: the transform waves park the raw pair spectra Z (natural order, one conflict-free ds_write_b64 per slot) and whoever picks
+// a bin up separates the two channels himself -- A = Z[f] + conj Z[N - f], B = -i (Z[f] - conj Z[N - f]): the very operations of
+// rfft_pair_untangle on the very operands, so every spectrum and every sum is bit for bit what the untangled tile gives.  What it saves
+// sits on the LDS pipe, which together with the VALU bounds the STORE = false variant (profiles/r03_q_C2x4000_pmc_alu.json: ~48 % busy
+// each, barely overlapped) -- per transform the 2 E ds_bpermute of the untangle (an LDS store + load each) and E/2 ds_write_b128 at a
+// 32-byte pitch (13 cycles each, MI355X_MICROARCH.md "LDS") against E ds_write_b64 (6 each): ~280 -> ~180 LDS cycles per transform --
+// and the untangle's registers in the transform phase, the phase that sets this kernel's register count.
+#ifndef DISCO_ZTILE
+#define DISCO_ZTILE 1
 #endif
 // STORE = false: the spectra are reduced into the covariances and dropped (single-node path: the filter pass recomputes them
 // from the samples, k_stft_apply_istft, instead of reading 8 M F bytes per node-frame back)
@@ -457,7 +471,12 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, CHP = (M + 1) / 2, MP = 2 * CHP;
     constexpr int NP = M * (M + 1) / 2;
     constexpr int BPT = (F - 1) / 256;             // bins per thread: 1 (N = 512) or 2 (N = 1024)
-    __shared__ StftCovShared<N, CHP> sh;
+    constexpr bool ZT = DISCO_ZTILE != 0;
+    constexpr int ZP = stft_cov_zpitch<N>();
+    __shared__ StftCovShared<N, CHP, ZT> sh;
+    // X layout: row (frame of wave ww, bin f) = the 2 CHP channels as they go to HBM; Z layout: plane (ww, pair p) = Z[0 .. N)
+    auto xrow = [&](int ww, int f) { return &sh.tile[ww][f * 2 * CHP]; };
+    auto zplane = [&](int ww, int p) { return &sh.tile[ww][p * ZP]; };
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63;
     const long long g = blockIdx.x / chunks;
     const int c = (int)(blockIdx.x % chunks);
@@ -526,11 +545,17 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
                 c32 v[E];
                 apply_window<N>(v, raw[p], w, 2 * p + 1 < M);
                 fft_wave<N>(v, wtw, sh.buf[wave], lane);
-                // (NOT swizzled like k_stft_pairs' tile: measured, the swizzle costs this kernel 8 % -- 7.70 against 7.10 ms per C3 launch;
-                // its stores are 2-way conflicted at worst and the copy-out below wants the plain linear read)
-                rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
-                    *reinterpret_cast<float4*>(&sh.tile[wave][f][2 * p]) = make_float4(a.x, a.y, b.x, b.y);
-                });
+                if constexpr (ZT) {
+                    c32* zp = zplane(wave, p);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) zp[lane + 64 * e] = v[e];
+                } else {
+                    // (NOT swizzled like k_stft_pairs' tile: measured, the swizzle costs this kernel 8 % -- 7.70 against 7.10 ms per C3 launch;
+                    // its stores are 2-way conflicted at worst and the copy-out below wants the plain linear read)
+                    rfft_pair_untangle<N>(v, sh.buf[wave], lane, [&](int, int f, c32 a, c32 b) {
+                        *reinterpret_cast<float4*>(xrow(wave, f) + 2 * p) = make_float4(a.x, a.y, b.x, b.y);
+                    });
+                }
             }
         }
 #pragma unroll
@@ -555,11 +580,22 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
                     // The rows are 8 * M * F bytes long (8224 for M = 4), so they start 0 / 32 / 64 / 96 bytes into a 128-byte line: the
                     // copy is shifted by that much, every wave store then covers whole lines (PMC: stores that straddle lines
                     // at both ends cost a fill read per partial line, +2.8 GB of reads per C3 launch).
-                    const float4* src = reinterpret_cast<const float4*>(&sh.tile[ww][0][0]);
                     float4* dst = reinterpret_cast<float4*>(Xo);
                     const int shift = (int)((reinterpret_cast<unsigned long long>(dst) >> 4) & 7);
-                    for (int i = tid - shift; i < F * M / 2; i += 64 * STFT_WAVES)
-                        if (i >= 0) store_stream16(&dst[i], src[i]);
+                    if constexpr (ZT) {             // granule i = (bin i / CHP, pair i % CHP): untangled on the way out
+                        for (int i = tid - shift; i < F * CHP; i += 64 * STFT_WAVES)
+                            if (i >= 0) {
+                                const int f = i / CHP, pp = i - f * CHP;
+                                const c32* zp = zplane(ww, pp);
+                                const c32 z = zp[f], zc = zp[(N - f) & (N - 1)];
+                                const c32 a = cadd_conj(z, zc), b = csub_conj_mi(z, zc);
+                                store_stream16(&dst[i], make_float4(a.x, a.y, b.x, b.y));
+                            }
+                    } else {
+                        const float4* src = reinterpret_cast<const float4*>(xrow(ww, 0));
+                        for (int i = tid - shift; i < F * M / 2; i += 64 * STFT_WAVES)
+                            if (i >= 0) store_stream16(&dst[i], src[i]);
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < BPT; ++b) {
@@ -567,9 +603,16 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
                     c32 xv[MP];
 #pragma unroll
                     for (int p = 0; p < CHP; ++p) {
-                        const float4 q4 = *reinterpret_cast<const float4*>(&sh.tile[ww][f][2 * p]);
-                        xv[2 * p] = make_float2(q4.x, q4.y);
-                        xv[2 * p + 1] = make_float2(q4.z, q4.w);
+                        if constexpr (ZT) {
+                            const c32* zp = zplane(ww, p);
+                            const c32 z = zp[f], zc = zp[(N - f) & (N - 1)];
+                            xv[2 * p] = cadd_conj(z, zc);
+                            xv[2 * p + 1] = csub_conj_mi(z, zc);
+                        } else {
+                            const float4 q4 = *reinterpret_cast<const float4*>(xrow(ww, f) + 2 * p);
+                            xv[2 * p] = make_float2(q4.x, q4.y);
+                            xv[2 * p + 1] = make_float2(q4.z, q4.w);
+                        }
                     }
                     if (STORE && (M & 1) != 0) {
 #pragma unroll
@@ -579,10 +622,25 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
                     cov_accumulate_shared<M>(xv, m * m, mc * mc, acc_s[b], acc_n[b]);
                 }
                 // Nyquist bin
-                if (STORE && (M & 1) != 0 && tid < M) Xo[(long long)(F - 1) * M + tid] = sh.tile[ww][F - 1][tid];
+                if (STORE && (M & 1) != 0 && tid < M) {
+                    if constexpr (ZT) {
+                        const c32 zq = zplane(ww, tid >> 1)[N / 2];
+                        Xo[(long long)(F - 1) * M + tid] = (tid & 1) ? csub_conj_mi(zq, zq) : cadd_conj(zq, zq);
+                    } else {
+                        Xo[(long long)(F - 1) * M + tid] = xrow(ww, F - 1)[tid];
+                    }
+                }
                 if (tid < 2 * NP) {
                     const float m = (tid & 1) ? 1.f - mny[ww] : mny[ww];
-                    const c32 a = sh.tile[ww][F - 1][ny_i], b2 = sh.tile[ww][F - 1][ny_j];
+                    c32 a, b2;
+                    if constexpr (ZT) {             // channel i of the Nyquist bin from its pair's Z[N / 2] (its own partner)
+                        const c32 zi = zplane(ww, ny_i >> 1)[N / 2], zj = zplane(ww, ny_j >> 1)[N / 2];
+                        a = (ny_i & 1) ? csub_conj_mi(zi, zi) : cadd_conj(zi, zi);
+                        b2 = (ny_j & 1) ? csub_conj_mi(zj, zj) : cadd_conj(zj, zj);
+                    } else {
+                        a = xrow(ww, F - 1)[ny_i];
+                        b2 = xrow(ww, F - 1)[ny_j];
+                    }
                     const float m2 = m * m;
                     acc_ny.x = fmaf(m2, a.x * b2.x + a.y * b2.y, acc_ny.x);
                     if (ny_i != ny_j) acc_ny.y = fmaf(m2, a.y * b2.x - a.x * b2.y, acc_ny.y);

@@ -2,6 +2,7 @@
 tests/hipemu (a CPU emulator of the HIP execution model).  Used ONLY by `-m "not gpu"` tests to check kernel
 logic at toy sizes without a GPU; never loaded by the disco_amd package (which has no CPU path)."""
 import ctypes
+import hashlib
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -9,8 +10,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(REPO, 'disco_amd', 'csrc')
-OUT = os.path.join(HERE, '_emu', 'libdisco_hipemu_TESTONLY.so')
-OBJ = os.path.join(HERE, '_emu', 'obj')
+# DISCO_CXXFLAGS (the -D switches of an A/B build, as disco_amd/build.py reads them) select a variant: its own objects and library
+_EXTRA = os.environ.get('DISCO_CXXFLAGS', '').split()
+_TAG = ('.' + hashlib.sha1(' '.join(_EXTRA).encode()).hexdigest()[:8]) if _EXTRA else ''
+OUT = os.path.join(HERE, '_emu', f'libdisco_hipemu_TESTONLY{_TAG}.so')
+OBJ = os.path.join(HERE, '_emu', 'obj' + _TAG)
 
 
 def build_emu():
@@ -20,7 +24,7 @@ def build_emu():
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in units + hdrs):
         return OUT
     os.makedirs(OBJ, exist_ok=True)
-    flags = ['g++', '-O2', '-std=c++17', '-x', 'c++', '-fPIC', '-pthread', '-ffp-contract=off', '-I', os.path.join(HERE, 'hipemu', 'include')]
+    flags = ['g++', '-O2', '-std=c++17', '-x', 'c++', '-fPIC', '-pthread', '-ffp-contract=off', '-I', os.path.join(HERE, 'hipemu', 'include')] + _EXTRA
 
     def compile_unit(src):
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')

@@ -135,7 +135,7 @@ def test_emu_solver_degenerate(make_engine):
 
 @pytest.mark.parametrize('K,M,L,n_fft,tuning', [(2, 2, 25700, 512, (80, 1, 1, 64)), (3, 2, 13000, 512, (13, 2, 3, 5)),
                                                (2, 2, 9000, 512, (80, 1, 1, 2)), (2, 1, 20000, 1024, (7, 1, 2, 0)),
-                                               (1, 3, 25700, 512, (80, 1, 1, 64))])
+                                               (1, 3, 25700, 512, (80, 1, 1, 64)), (1, 4, 9000, 512, (9, 1, 1, 4)), (1, 2, 5000, 1024, (3, 1, 1, 2))])
 def test_emu_tango_pinned_geometry(make_engine, K, M, L, n_fft, tuning):
     """Large-batch launch geometries (long STFT runs with short / empty last waves, single-chunk covariances, many frame
     pairs per filter+iSTFT workgroup) pinned on a small batch through disco_set_tuning."""
