@@ -91,7 +91,10 @@ extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w,
     src.part = (const float4*)(ctx->pending_skiploc ? ctx->scratch2 : ctx->scratch);
     src.F = ctx->F;
     src.chunks = ctx->pending_chunks;
-    src.inv_T = 1.0f / (float)ctx->T;
+    // The partial sums go to the solvers UNSCALED (round 5): w and t1 do not change when Rxx and Rnn are scaled together, and without the
+    // multiplication by 1 / T an entry that arrives as one float32 block (the fused step-2 pass and the room pass leave one block per node)
+    // reaches the float64 arithmetic exactly as it was summed; a product with 1 / T cost every entry a rounding (k_solve_dpp.h)
+    src.inv_T = 1.0f;
     src.part_loc = ctx->pending_skiploc ? (const float4*)ctx->scratch : nullptr;
     src.chunks_loc = ctx->pending_skiploc ? ctx->loc_chunks : 0;
     src.M_loc = ctx->pending_skiploc ? ctx->loc_M : 0;

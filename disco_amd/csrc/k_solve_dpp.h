@@ -30,23 +30,32 @@ struct DppSolveGeom {
     static constexpr int THREADS = 64, PROBS = 4;
     static constexpr int PW = P | 1;                    // odd row pitch (16-byte words): transposed reads spread over the banks
     static constexpr int WORDS = P * PW + PW;           // + one row of zeros (lanes >= P; the "not part of column j" entries of the parked L)
+    // the same block first holds the staged pencil (group_stage_part): P (P + 1) / 2 + 2 * 36 + 1 float4 (M_loc <= 8), 16 bytes like a c64
+    static constexpr int BLOCK = WORDS > P * (P + 1) / 2 + 73 ? WORDS : P * (P + 1) / 2 + 73;
 };
 
-// Row j of both Hermitian matrices of the group's pencil from the covariance kernels' chunk partials (SolveSrc, k_solve.h), loaded
-// by the GROUP: solve_load_row has every lane walk its own row of the packed triangle -- P entries x chunks dependent 16-byte loads
-// per lane, 1 500 of the 8 000 instructions of a P = 15 solve and its longest stall.  Here the 16 lanes read the pencil's
-// P (P + 1) / 2 entries linearly (lane, lane + 16, ...: 256 contiguous bytes per instruction and group, all chunks of an entry in flight
-// together), combine the chunks in float64, round ONCE to float32 -- the same arithmetic, bit for bit, as solve_load_row -- and
-// leave the triangle in the group's LDS block, from which lane j picks row j.  `stage`: P (P + 1) / 2 + M_loc (M_loc + 1) / 2 + 1 float4
-// (SolveSrc's second source: the leading M_loc x M_loc block from the step-1 partial sums, as the room pass leaves them).
+// The group's pencil from the covariance kernels' chunk partials (SolveSrc, k_solve.h), fetched by the GROUP into its LDS block:
+// solve_load_row has every lane walk its own row of the packed triangle -- P entries x chunks dependent 16-byte loads per lane, 1 500 of
+// the 8 000 instructions of a P = 15 solve and its longest stall.  Here the 16 lanes read the pencil's P (P + 1) / 2 entries linearly
+// (lane, lane + 16, ...: 256 contiguous bytes per instruction and group, all chunks of an entry in flight together) and combine the
+// blocks of an entry in float64.
+//
+// Round 5: nothing is rounded at the solver's door any more.  (Round 4 measured what that rounding costs: the float64 oracle itself moves
+// by 3.7e-5 on C5's worst room when its exact covariances are merely rounded to complex64, profiles/r04_c5_accumulation.txt.)
+//   * The sums are handed over UNSCALED -- w and t1 do not change when Rxx and Rnn are scaled together (d0 is their ratio, q scales with
+//     1 / L, t1 = q L00 conj(v0[0])) -- so an entry that arrives as ONE float32 block (the room pass leaves one block per node) passes
+//     through exactly; the multiplication by 1 / T cost it a rounding.
+//   * The leading M_loc x M_loc block -- the step-1 statistics, which the wide shapes accumulate in float64 and store as (hi, lo) pairs of
+//     blocks (k_cov_loc_f64) -- is staged as (hi, lo) float4 pairs and the float64 rows are formed from both.
+// Main entries that arrive in several blocks are still rounded once (their sum); `stage`: NP + 2 NPL + 1 float4.
 template <int P>
-__device__ __forceinline__ void group_load_rows_part(const SolveSrc& src, long long pid, int j, bool live, float4* stage, c32* rs, c32* rn) {
+__device__ __forceinline__ void group_stage_part(const SolveSrc& src, long long pid, int j, bool live, float4* stage) {
     constexpr int NP = P * (P + 1) / 2, SLOTS = (NP + 15) / 16;
-    const long long pidc = live ? pid : 0;              // a pencil that does not exist reads pencil 0 (its rows are replaced by the caller)
+    const long long pidc = live ? pid : 0;              // a pencil that does not exist reads pencil 0 (and stages zeros)
     const long long g = pidc / src.F;
     const int f = (int)(pidc % src.F);
     const int ML = src.M_loc, NPL = ML * (ML + 1) / 2;
-    const double it = live ? (double)src.inv_T : 0.0;   // a pencil that does not exist: all zeros
+    const double it = live ? 1.0 : 0.0;
     {
         const float4* pb = src.part + ((g * src.chunks) * src.F + f) * (long long)NP;
         const long long cs = (long long)src.F * NP;
@@ -70,7 +79,7 @@ __device__ __forceinline__ void group_load_rows_part(const SolveSrc& src, long l
         for (int s = 0; s < SLOTS; ++s)
             if (16 * s + j < NP) stage[16 * s + j] = make_float4((float)(acc[s][0] * it), (float)(acc[s][1] * it), (float)(acc[s][2] * it), (float)(acc[s][3] * it));
     }
-    if (ML > 0) {                                       // leading M_loc x M_loc block: the step-1 partial sums (room pass, k_room.h)
+    if (ML > 0) {                                       // leading M_loc x M_loc block: the step-1 partial sums, (hi, lo)
         const float4* pl = src.part_loc + ((g * src.chunks_loc) * src.F + f) * (long long)NPL;
         const long long csl = (long long)src.F * NPL;
         for (int q = j; q < NPL; q += 16) {
@@ -82,14 +91,25 @@ __device__ __forceinline__ void group_load_rows_part(const SolveSrc& src, long l
                 a2 += (double)v.z;
                 a3 += (double)v.w;
             }
-            stage[NP + q] = make_float4((float)(a0 * it), (float)(a1 * it), (float)(a2 * it), (float)(a3 * it));
+            a0 *= it, a1 *= it, a2 *= it, a3 *= it;
+            const float4 hi = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+            stage[NP + q] = hi;
+            stage[NP + NPL + q] = make_float4((float)(a0 - (double)hi.x), (float)(a1 - (double)hi.y), (float)(a2 - (double)hi.z), (float)(a3 - (double)hi.w));
         }
     }
-    if (j == 0) stage[NP + NPL] = make_float4(0.f, 0.f, 0.f, 0.f);         // what the lanes >= P read
+    if (j == 0) stage[NP + 2 * NPL] = make_float4(0.f, 0.f, 0.f, 0.f);     // what the lanes >= P read, and the `lo` of every entry outside the leading block
     DISCO_GROUP_SYNC();
-    // row j: entry (j, c) sits at upper-triangle coordinates (lo, hi) = (min, max); lower triangle = conj(upper); the diagonal is
-    // real.  Branch-free on purpose (integer selects as masks, signs as factors): hipcc otherwise wraps every entry in its own
-    // exec-masked block with a wait of its own.
+}
+// Row j of the staged pencil in ONE pass over its entries: Rnn's row in float64 (`b`: the Cholesky takes it at once), Rxx's row as its
+// float32 head `a_hi` (what crosses the squarings for the Rayleigh quotient: d0 only enters through d0 / (d0 + mu)) plus the `lo` halves of
+// its leading-block entries `a_lo` (c < LMAX), from which the caller forms the float64 row when the whitening begins.  Entry (j, c) sits at
+// upper-triangle coordinates (lo, hi) = (min, max); lower triangle = conj(upper); the diagonal is real.  Branch-free on purpose (integer
+// selects as masks, signs as factors): hipcc otherwise wraps every entry in its own exec-masked block with a wait of its own.
+constexpr int DPP_LMAX = 8;         // M_loc <= 8 (mics per node)
+template <int P>
+__device__ __forceinline__ void group_stage_rows(const float4* stage, int ML, int j, c64* b, c32* a_hi, c32* a_lo) {
+    constexpr int NP = P * (P + 1) / 2;
+    const int NPL = ML * (ML + 1) / 2, ZERO = NP + 2 * NPL;
     const auto isel = [](bool c, int x, int y) { return y + ((x - y) & -(int)c); };
     const int base_j = j * P - (j * (j - 1)) / 2 - j;                 // + c for c >= j
     const int base_l = NP + j * ML - (j * (j - 1)) / 2 - j;
@@ -97,19 +117,31 @@ __device__ __forceinline__ void group_load_rows_part(const SolveSrc& src, long l
     for (int c = 0; c < P; ++c) {
         const bool up = c >= j;
         int idx = isel(up, base_j + c, (c * P - (c * (c - 1)) / 2 - c) + j);
+        int idl = ZERO;
         if (ML > 0) {                                   // (uniform)
             const int il = isel(up, base_l + c, NP + (c * ML - (c * (c - 1)) / 2 - c) + j);
-            idx = isel((up ? c : j) < ML, il, idx);
+            const bool loc = (up ? c : j) < ML;
+            idx = isel(loc, il, idx);
+            if (c < DPP_LMAX) idl = isel(loc && j < P, il + NPL, ZERO);
         }
-        idx = isel(j < P, idx, NP + NPL);
+        idx = isel(j < P, idx, ZERO);
         float4 v = stage[idx];
         DISCO_CONSUME(v.y);                             // all four words are read, whatever the selects below keep
         DISCO_CONSUME(v.w);
         const float sg = c == j ? 0.f : (up ? 1.f : -1.f);
-        rs[c] = make_float2(v.x, v.y * sg);
-        rn[c] = make_float2(v.z, v.w * sg);
+        a_hi[c] = make_float2(v.x, v.y * sg);
+        double bx = (double)v.z, by = (double)(v.w * sg);
+        if (c < DPP_LMAX) {                             // entries (j, c) with c >= M_loc read the zero word
+            float4 l = stage[idl];
+            DISCO_CONSUME(l.y);
+            DISCO_CONSUME(l.w);
+            a_lo[c] = make_float2(l.x, l.y * sg);
+            bx += (double)l.z;
+            by += (double)(l.w * sg);
+        }
+        b[c] = make_double2(bx, by);
     }
-    DISCO_GROUP_SYNC();                                 // the block is reused (transposition of Y) once every lane has its row
+    DISCO_GROUP_SYNC();                                 // the block is reused (transposition of Y) once every lane has its rows
 }
 
 template <int P, bool FROM_PART>
@@ -117,7 +149,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(DppSolveGeom<P>::THREADS, 2) voi
                                                                                               c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     using DG = DppSolveGeom<P>;
     constexpr int PW = DG::PW;
-    __shared__ c64 s_M[DG::PROBS][DG::WORDS];
+    __shared__ c64 s_M[DG::PROBS][DG::BLOCK];
     const int j = threadIdx.x & 15;                     // row / column owned by this lane
     const int slot = threadIdx.x >> 4;
     const long long pid = (long long)blockIdx.x * DG::PROBS + slot;
@@ -125,19 +157,27 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(DppSolveGeom<P>::THREADS, 2) voi
     const bool col = live && j < P;
     c64* Mm = s_M[slot];
 
-    c32 rowA[P], rowB[P];                               // row j of Rxx / Rnn
+    c32 rowA[P];                                        // row j of Rxx in float32: all that crosses the squarings (the Rayleigh quotient's)
+    c64 a[P];                                           // row j of Rnn, then of its Cholesky factor
+    c32 rowA_lo[DPP_LMAX];                              // FROM_PART: the `lo` halves of its leading-block entries
     if constexpr (FROM_PART) {
-        group_load_rows_part<P>(src, pid, j, live, reinterpret_cast<float4*>(Mm), rowA, rowB);
+        group_stage_part<P>(src, pid, j, live, reinterpret_cast<float4*>(Mm));
+        group_stage_rows<P>(reinterpret_cast<const float4*>(Mm), src.M_loc, j, a, rowA, rowA_lo);
 #pragma unroll
-        for (int c = 0; c < P; ++c) rowB[c].x = (c == j && !live) ? 1.f : rowB[c].x;      // a pencil that does not exist: Rxx = 0, Rnn = I
-    } else if (col) {
-        solve_load_row<P, false>(src, pid, j, rowA, rowB);
+        for (int c = 0; c < P; ++c) a[c].x = (c == j && !live) ? 1.0 : a[c].x;           // a pencil that does not exist: Rxx = 0, Rnn = I
     } else {
+        c32 rowB[P];
+        if (col) {
+            solve_load_row<P, false>(src, pid, j, rowA, rowB);
+        } else {
 #pragma unroll
-        for (int c = 0; c < P; ++c) {
-            rowA[c] = make_float2(0.f, 0.f);
-            rowB[c] = make_float2(c == j ? 1.f : 0.f, 0.f);
+            for (int c = 0; c < P; ++c) {
+                rowA[c] = make_float2(0.f, 0.f);
+                rowB[c] = make_float2(c == j ? 1.f : 0.f, 0.f);
+            }
         }
+#pragma unroll
+        for (int c = 0; c < P; ++c) a[c] = make_double2((double)rowB[c].x, (double)rowB[c].y);
     }
     DISCO_DPP_SETTLE();
 
@@ -145,9 +185,6 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(DppSolveGeom<P>::THREADS, 2) voi
     // c < j; lane c's own a[c] ends as L[c][c] or 0, lanes above the diagonal carry values nobody reads).  Column c: the pivot is lane
     // c's a[c]; every lane scales its entry; the trailing update A[j][r] -= L[j][c] conj(L[r][c]) reads L[r][c] as lane r's a[c] and
     // touches a different accumulator with every multiply-add.  Pivot floor / zeroed column on breakdown: as group_cholesky_factor.
-    c64 a[P];
-#pragma unroll
-    for (int c = 0; c < P; ++c) a[c] = make_double2((double)rowB[c].x, (double)rowB[c].y);
     double rdj = 1.0, dgj = 1.0;                        // 1 / L[j][j] and L[j][j] of the lane's own row
     {
         double dorig = 0.0;                             // Rnn[j][j]
@@ -176,8 +213,16 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(DppSolveGeom<P>::THREADS, 2) voi
     // ---- column j of Y = L^-1 Rxx (Rxx[i][j] = conj(Rxx[j][i]): row j of Rxx), right-looking: row i is finished by its own
     // diagonal, then every later row r subtracts L[r][i] y[i] -- L[r][i] is lane r's a[i]
     c64 g[P];
+    if constexpr (FROM_PART) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) g[i] = make_double2((double)rowA[i].x, -(double)rowA[i].y);
+        for (int i = 0; i < P; ++i) {                   // row j of Rxx in float64 from (hi, lo)
+            const double lx = i < DPP_LMAX ? (double)rowA_lo[i < DPP_LMAX ? i : 0].x : 0.0, ly = i < DPP_LMAX ? (double)rowA_lo[i < DPP_LMAX ? i : 0].y : 0.0;
+            g[i] = make_double2((double)rowA[i].x + lx, -((double)rowA[i].y + ly));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) g[i] = make_double2((double)rowA[i].x, -(double)rowA[i].y);
+    }
     auto forward = [&]() {
         static_for<0, P>([&](auto I) {
             constexpr int i = decltype(I)::value;

@@ -631,9 +631,11 @@ def check_tango_end_to_end(make_engine, y, s, n, n_fft=512, mask='irm1', tol=1e-
     return errs
 
 
-def check_c5_full_length(make_engine, rooms=(0, 100, 199), K=8, M=8, n_fft=1024, L=160000, iters=2, tol=1e-4):
+def check_c5_full_length(make_engine, rooms=(0, 6, 64, 100, 141, 199), K=8, M=8, n_fft=1024, L=160000, iters=2, tol=1e-4):
     """BASELINE.json configs[4] at its real shape and length -- 8 nodes x 8 mics, 1024-point STFT, 10 s, two step-2 iterations -- on the
-    rooms bench.py samples from its 200-room batch (first, middle, last), against the float64 oracle at the north star's 1e-4.  The
+    first, middle and last room of bench.py's 200-room batch plus the four rooms that the 32-room sweep of round 5 found furthest from the
+    oracle (profiles/r05_b_c5_32rooms_*.json: room 6 was at 1.49e-4 while the solvers rounded the combined sums to float32 at their door,
+    3.5e-5 since they do not), against the float64 oracle at the north star's 1e-4.  The
     launch geometry is pinned to the one the 200-room batch takes (one frame chunk in the step-1 statistics; the room pass has none), so
     that every room goes through exactly the arithmetic it goes through in the bench.  The oracles run in worker processes while the
     GPU computes.  (The iterated scheme is an extension: the reference is strictly two-step, tango.py:1-7; the oracle defines it.)"""

@@ -222,8 +222,8 @@ def test_iterated_danse_extension(make_engine, K, M, L, n_fft, iters):
 
 
 def test_c5_full_length_rooms(make_engine):
-    """BASELINE.json configs[4] at full shape and length (8 x 8, 1024-point, L = 160000, 2 iterations), rooms 0 / 100 / 199 of the
-    bench's batch, 1e-4 against the float64 oracle."""
+    """BASELINE.json configs[4] at full shape and length (8 x 8, 1024-point, L = 160000, 2 iterations), rooms 0 / 6 / 64 / 100 / 141 / 199 of
+    the bench's batch, 1e-4 against the float64 oracle."""
     print(pc.check_c5_full_length(make_engine))
 
 

@@ -4,7 +4,8 @@ GPU lane forms them -- `chunks` time chunks per node, inside a chunk sequential 
 frames that were themselves summed sequentially from zero, chunks combined in float64, rounded to complex64 -- per block class:
     s1     the M x M statistics of step 1 (also the leading block of every step-2 pencil: SKIPLOC)
     cross  the y-z entries of step 2,   zz  the z-z entries of step 2
-Usage: python tools/exp_c5_accum2.py <room> s1=<c>:<b>|x cross=<c>:<b>|x zz=<c>:<b>|x      (x = exact sums rounded to complex64)
+Usage: python tools/exp_c5_accum2.py <room> s1=<c>:<b>[u]|x|d cross=... zz=...      (x = exact sums rounded to complex64; d = exact sums in
+float64, unrounded; a trailing u = the float32 partial sums combined in float64 and handed over unrounded)
 Results: profiles/r04_c5_accumulation.txt"""
 import os
 import sys
@@ -24,7 +25,7 @@ def run():
 ref = run()
 orig = to._cov_mean
 
-def emul(Vt, chunks, block):
+def emul(Vt, chunks, block, rounded=True):
     F, T, P = Vt.shape
     V32 = Vt.astype(np.complex64)
     tot = np.zeros((F, P, P), np.complex128)
@@ -37,26 +38,52 @@ def emul(Vt, chunks, block):
                 blk += V32[:, t, :, None] * np.conjugate(V32[:, t, None, :])
             acc += blk
         tot += acc
-    return (tot / T).astype(np.complex64).astype(np.complex128)
+    return (tot / T).astype(np.complex64).astype(np.complex128) if rounded else tot / T
 
+def emul_sub(Vt, sub, rounded=False):
+    """the room pass's order (k_room.h): `sub` interleaved float32 accumulators (frame t goes to accumulator t % sub, each sums its frames
+    sequentially), combined pairwise in float32 (the lane-level halvings), ONE block: handed to the solver as it is."""
+    F, T, P = Vt.shape
+    V32 = Vt.astype(np.complex64)
+    acc = [np.zeros((F, P, P), np.complex64) for _ in range(sub)]
+    for t in range(T):
+        acc[t % sub] += V32[:, t, :, None] * np.conjugate(V32[:, t, None, :])
+    while len(acc) > 1:
+        h = len(acc) // 2
+        acc = [acc[i] + acc[i + h] for i in range(h)]
+    tot = acc[0].astype(np.complex128) / T
+    return tot.astype(np.complex64).astype(np.complex128) if rounded else tot
+
+
+PERM = int(spec.pop('perm', 0))       # > 0: the frames are summed in a random order (seed): another realisation of the same roundings' statistics
 ROT = int(spec.pop('rot', 0))         # 1: the node's own M rows in the basis of the DFT across its (circular) array
 def cov(V, ref32):
     Vt = np.transpose(V, (1, 2, 0))
     F, T, P = Vt.shape
+    if PERM:
+        Vt = Vt[:, np.random.default_rng(PERM).permutation(T)]
     U = np.eye(P, dtype=np.complex128)
     if ROT:
         U[:M, :M] = np.fft.fft(np.eye(M)) / np.sqrt(M)
         Vt = Vt @ U.T                                      # rows -> U v
     Vx = np.transpose(Vt, (2, 0, 1))
-    exact = orig(Vx, False).astype(np.complex64).astype(np.complex128)
+    exact64 = orig(Vx, False)
+    exact = exact64.astype(np.complex64).astype(np.complex128)
     R = exact.copy()
     cache = {}
     def get(sp):
         if sp == 'x':
             return exact
+        if sp == 'd':                      # round 5: float64 sums handed to the solver UNROUNDED ((hi, lo) at the solver's door)
+            return exact64
+        if sp.startswith('s'):             # "sN": N interleaved accumulators, float32 tree, one block (the room pass)
+            if sp not in cache:
+                cache[sp] = emul_sub(Vt, int(sp[1:]))
+            return cache[sp]
         if sp not in cache:
-            c, b = (int(v) for v in sp.split(':'))
-            cache[sp] = emul(Vt, c, b)
+            unrounded = sp.endswith('u')   # "c:bu": float32 partial sums combined in float64 and NOT rounded to complex64
+            c, b = (int(v) for v in sp.rstrip('u').split(':'))
+            cache[sp] = emul(Vt, c, b, rounded=not unrounded)
         return cache[sp]
     R[:, :M, :M] = get(spec['s1'])[:, :M, :M]
     if P > M:

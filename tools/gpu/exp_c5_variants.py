@@ -1,6 +1,6 @@
 """C5 (200 rooms x 8 x 8, 1024-pt, 2 iterations) on ONE batch under several kernel routes: ms per step, stage times, and the error of sampled
 rooms against the float64 oracle (computed once, in worker processes, while the GPU runs the variants).  Test / measurement tooling.
-Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [variants=room_sub:cov1_mode:cov_chunks:wide,...  wide: -1 = disco_apply + disco_istft, 0 = one-pass filter + iSTFT, n > 0 = that with n frame pairs per run] [sample=0,100,199]"""
+Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [sample=0,100,199 | spread:N] [variants=room_sub:cov1_mode:cov_chunks:wide,...  wide: -1 = disco_apply + disco_istft, 0 = one-pass filter + iSTFT, n > 0 = that with n frame pairs per run] [sample=0,100,199]"""
 import json
 import os
 import sys
@@ -31,12 +31,17 @@ def main():
     R = int(kv.get('rooms', 200))
     K, M, N, L, iters = int(kv.get('nodes', 8)), int(kv.get('mics', 8)), int(kv.get('n_fft', 1024)), 160000, int(kv.get('iters', 2))
     variants = [tuple(int(x) for x in v.split(':')) for v in kv.get('variants', '8:4:0:2,8:4:0:1,4:4:0:2').split(',')]
-    sample = [int(x) for x in kv.get('sample', '0,100,199').split(',') if int(x) < R]
+    sspec = kv.get('sample', '0,100,199')
+    if sspec.startswith('spread:'):            # spread:N = N rooms spread evenly over the batch (first ... last)
+        n_s = int(sspec.split(':')[1])
+        sample = sorted({int(round(i * (R - 1) / max(n_s - 1, 1))) for i in range(n_s)})
+    else:
+        sample = [int(x) for x in sspec.split(',') if int(x) < R]
     steps = int(kv.get('steps', 8))
     dev = torch.device('cuda:0')
     eng = Engine(rooms=R, nodes=K, mics=M, length=L, n_fft=N, device=0)
     y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, L, first_room=0, device=dev, ref_only_sn=True)
-    pool = ProcessPoolExecutor(max_workers=len(sample))
+    pool = ProcessPoolExecutor(max_workers=max(1, min(len(sample), (os.cpu_count() or 8) - 1)))
     futs = {r: pool.submit(oracle_room, (y[r].cpu().numpy(), s_ref[r].cpu().numpy(), n_ref[r].cpu().numpy(), N, iters)) for r in sample}
     T, F = eng.T, eng.F
     mask = torch.empty((R, K, T, F), dtype=torch.float32, device=dev)
@@ -92,7 +97,14 @@ def main():
             res['variants'][name].setdefault('rel_err', {})[str(r)] = e
         json.dump(res, open(out_path, 'w'), indent=1)
     for name, v in res['variants'].items():
-        print(name, v['ms_per_step'], {k_: '%.2e' % e for k_, e in v['rel_err'].items()}, flush=True)
+        errs = sorted(v['rel_err'].values())
+        v['rel_err_summary'] = {'rooms': len(errs), 'worst': errs[-1], 'median': errs[len(errs) // 2],
+                                'histogram_edges': [1e-6, 3e-6, 1e-5, 2e-5, 3e-5, 5e-5, 1e-4],
+                                'histogram': [int(sum(1 for e in errs if lo <= e < hi)) for lo, hi in
+                                              zip([0, 1e-6, 3e-6, 1e-5, 2e-5, 3e-5, 5e-5, 1e-4], [1e-6, 3e-6, 1e-5, 2e-5, 3e-5, 5e-5, 1e-4, 1e9])]}
+        print(name, v['ms_per_step'], 'worst %.2e median %.2e' % (errs[-1], errs[len(errs) // 2]), v['rel_err_summary']['histogram'],
+              {k_: '%.2e' % e for k_, e in v['rel_err'].items()} if len(errs) <= 12 else '', flush=True)
+    json.dump(res, open(out_path, 'w'), indent=1)
 
 
 if __name__ == '__main__':
