@@ -86,13 +86,11 @@ def kernel_alg_bytes(M, K, F, H):
         'apply1': M * F * 8 + F * 8,                          # X in, z out
         'cov2': M * F * 8 + F * 4 + (K - 1) * F * 8,          # X + mask + remote z in
         'room_cov2': M * F * 8 + F * 4 + F * 8,               # X + mask in, z out (all nodes of a room in one workgroup: remote z's stay on chip)
-        'room_cov2_reg': M * F * 8 + F * 4 + F * 8,
         'apply2': M * F * 8 + F * 8 + F * 8,                  # X + z in (every z row once per room: the K - 1 readers of a row share it on chip / in L2), yf out
         'step2_cov': M * F * 8 + F * 4,                       # X + mask in (z stays on chip)
         'step2_apply': M * F * 8 + F * 8,                     # X in, yf out
         'step2_apply_istft': M * F * 8 + H * 4,               # X in, hop samples out (yf stays on chip)
         'stft_apply_istft': M * H * 4 + H * 4,                # samples in, hop samples out (single node, nothing materialised)
-        'step2_stft_apply_istft': M * H * 4 + H * 4,          # samples in, hop samples out (spectra re-transformed, z / yf on chip)
         'istft': F * 8 + H * 4,                               # yf in, hop samples out
         'apply2_istft': M * F * 8 + F * 8 + H * 4,            # X + z in, hop samples out (wide shapes: yf stays on chip)
         'apply_istft': M * F * 8 + H * 4,
@@ -551,7 +549,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                    'ms_min': round(ms_list[0], 4), 'ms_max': round(ms_list[-1], 4)}
             if nm in kab:
                 ent['alg_bytes'] = kab[nm] * rooms_done * K * T        # per step (all launches of the stage)
-                if nm in ('room_cov2', 'room_cov2_reg') and iters > 1:
+                if nm == 'room_cov2' and iters > 1:
                     # only the LAST pass of an iterated run stores z (nobody reads an earlier one): 8 F per node-frame once per step
                     ent['alg_bytes'] -= (rooms_done - R) * K * T * F * 8
                 ent['GBps'] = round(ent['alg_bytes'] / (per_step * 1e-3) / 1e9, 1)

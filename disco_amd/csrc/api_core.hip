@@ -177,8 +177,6 @@ int ensure_halves(disco_ctx* ctx) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        ctx->step_events.resize(64, nullptr);
-        for (auto& e : ctx->step_events) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     return 0;
 }
@@ -191,8 +189,6 @@ extern "C" void disco_destroy(disco_ctx* ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    for (auto& e : ctx->step_events)
-        if (e) (void)hipEventDestroy(e);
     stage_clear(ctx);
     if (ctx->d_win) (void)hipFree(ctx->d_win);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
@@ -289,14 +285,9 @@ extern "C" int disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int co
 namespace disco_host {
 const OptionInfo* option_table() {
     static const OptionInfo t[DISCO_N_OPTIONS] = {
-        {"step2_from_samples", "DISCO_STEP2_FROM_SAMPLES", DISCO_STEP2_FROM_SAMPLES_DEFAULT},
         {"room_cov", "DISCO_ROOM_COV", 1},
-        {"room_dma", "DISCO_ROOM_DMA", 1},
         {"overlap_solves", "DISCO_OVERLAP_SOLVES", 1},
-        {"solve_f32", "DISCO_SOLVE_F32", 0},
         {"solve_dpp", "DISCO_SOLVE_DPP", 1},
-        {"room_sub", "DISCO_ROOM_SUB", 8},
-        {"cov1_mode", "DISCO_COV1_MODE", 64},
         {"solve_thread", "DISCO_SOLVE_THREAD", 1},
         {"fuse_wide_istft", "DISCO_FUSE_WIDE_ISTFT", 1},
         {"online_sq32", "DISCO_ONLINE_SQ32", 1},

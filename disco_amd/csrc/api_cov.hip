@@ -16,8 +16,29 @@ int cov_chunks(const disco_ctx* ctx) {
     return (int)c;
 }
 
+// frame chunks of the float64 step-1 statistics of the wide shapes (k_cov_loc_f64 starts (tiles + 1) workgroups of 4 waves per node and
+// chunk: one chunk as soon as that fills the chip; every chunk leaves a (hi, lo) PAIR of blocks).  ONE definition for the launch and for
+// reserve_scratch (round-4 ADVICE: a node shard or a chip of more than 256 CUs made the launch ask for more than was reserved).
+int cov1_f64_chunks(const disco_ctx* ctx) {
+    if (ctx->tune_cov_chunks > 0) return cov_chunks(ctx);
+    const long long wgs = (long long)ctx->geom_rooms * ctx->Kl * ((ctx->F - 1 + 63) / 64 + 1);
+    return (int)std::max<long long>(1, std::min<long long>(std::min(8, ctx->T), (8LL * ctx->n_cu + wgs - 1) / wgs));
+}
+
+// A block that has to GROW is freed and allocated anew: whatever the context remembered about partial sums sitting in it (step-1 sums a
+// later step 2 would pair with, sums a pending solve would read) is forgotten with it -- a staged-API caller who changes an option or the
+// tuning between a covariance call and its solve gets "no covariance call has left partial sums", not a solve of uninitialised memory.
+static void forget_partials(disco_ctx* ctx) {
+    ctx->loc_M = 0;
+    ctx->loc_X = nullptr;
+    ctx->loc_mask = nullptr;
+    ctx->pending_chunks = 0;
+    ctx->pending_skiploc = 0;
+}
+
 int ensure_scratch(disco_ctx* ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return 0;
+    forget_partials(ctx);
     if (ctx->scratch) {
         HIPCHK(ctx, hipFree(ctx->scratch));
         ctx->scratch = nullptr;
@@ -30,6 +51,7 @@ int ensure_scratch(disco_ctx* ctx, size_t bytes) {
 
 int ensure_scratch2(disco_ctx* ctx, size_t bytes) {
     if (ctx->scratch2_bytes >= bytes) return 0;
+    if (ctx->pending_skiploc) forget_partials(ctx);     // (a pending step-2 solve reads this block)
     if (ctx->scratch2) {
         HIPCHK(ctx, hipFree(ctx->scratch2));
         ctx->scratch2 = nullptr;
@@ -67,14 +89,9 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
     const int NP = P * (P + 1) / 2;
     const bool same = (Zs == Zn);
     const bool split = (KR == 0 || (P > 8 && same && mask_remote && (ctx->F - 1) % 64 == 0)) && cov_split_shape(M, KR);
-    // step-1 shapes of the split kernels (KR = 0, M >= 7; option "cov1_mode"): 64 (default) = float64 accumulators, every frame chunk
-    // leaves a (hi, lo) PAIR of partial blocks; 4 / 8 = float32 with that many time sub-chunks across the lanes; else float32, lanes = bins
-    const int o_mode = ctx->opt[DISCO_OPT_COV1_MODE], sub = (split && KR == 0 && (o_mode == 4 || o_mode == 8 || o_mode == 64)) ? o_mode : 1;
-    // (the float64 kernel starts (tiles + 1) workgroups of 4 waves per node and chunk: one chunk as soon as that fills the chip)
-    if (sub == 64 && ctx->tune_cov_chunks == 0) {
-        const long long wgs = (long long)ctx->geom_rooms * ctx->Kl * ((ctx->F - 1 + 63) / 64 + 1);
-        chunks = (int)std::max<long long>(1, std::min<long long>(std::min(8, ctx->T), (8LL * ctx->n_cu + wgs - 1) / wgs));
-    }
+    // step-1 shapes of the split kernels (KR = 0, M >= 7): float64 accumulators, every frame chunk leaves a (hi, lo) PAIR of partial blocks
+    const int sub = (split && KR == 0) ? 64 : 1;
+    if (sub == 64) chunks = cov1_f64_chunks(ctx);
     const int blocks = sub == 64 ? 2 * chunks : chunks;
     const size_t need = (size_t)G * blocks * ctx->F * NP * sizeof(float4);
     skiploc = skiploc && split && KR > 0 && ctx->loc_M == M && ctx->loc_X == X && ctx->loc_mask == mask;
@@ -99,7 +116,7 @@ int cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const di
     const dim3 grid((unsigned)(G * chunks)), block((unsigned)(ctx->F - 1 + 64));
     bool launched = false;
     if (split) {                // 9 <= P <= 16, one vector for both statistics: one block of pairs per wave
-        const int nbt = (sub == 4 || sub == 8) ? 64 / sub : 64, tiles = (ctx->F - 1 + nbt - 1) / nbt;
+        const int tiles = (ctx->F - 1 + 63) / 64;
         const long long nblk = G * (tiles + 1) * chunks;
         if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_cov_masked: batch too large");
         launched = launch_cov_split_shape(M, KR, skiploc, sub, (unsigned)nblk, (hipStream_t)s, a);

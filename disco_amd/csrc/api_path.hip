@@ -39,13 +39,10 @@ WsLayout ws_layout(const disco_ctx* ctx) {
 //   1 / 2 (default / forced)  child A entirely on the caller's stream, child B entirely on the side stream: the two sequences drift
 //         against each other, so a solve -- a compute kernel that moves almost no data -- mostly meets a streaming kernel of the other
 //         half, and each half's kernel tails are filled by the other half.  Measured on C3: 19.67 -> 19.14 ms.
-//   3     software-pipelined: the streaming kernels one after the other on the caller's stream, only the solves on the side stream,
-//             caller's stream:  stft_cov1(A) stft_cov1(B) step2_cov(A) step2_cov(B) apply(A) apply(B)
-//             side stream    :               solve1(A)    solve1(B)    solve2(A)    solve2(B)
-//         -- kept as the record of it: every solve is hidden, but two half-batch launches of a streaming kernel cost more than one
-//         whole-batch launch (two tails): C3 18.99 -> 19.29 ms, slower than not overlapping at all.
-// A step waits for its own child's previous step through an event when that one ran on the other stream; nothing synchronises with
-// the host, and the side stream is forked from / joined to the caller's, so either sequence can still be captured into one hipGraph.
+// (Round 3 also built a software-pipelined order -- streaming kernels on the caller's stream, only the solves on the side stream: every solve
+// hidden, but two half-batch launches of a streaming kernel cost more than one whole-batch launch, C3 18.99 -> 19.29 ms; removed in round 5.)
+// Nothing synchronises with the host, and the side stream is forked from / joined to the caller's, so the sequence can still be captured
+// into one hipGraph.
 namespace {
 struct Step {
     const char* name;                          // stage name for the timers; nullptr: the callee brackets its own stages
@@ -67,45 +64,22 @@ int run_steps(disco_ctx* ctx, Steps& steps, disco_stream s) {
 int run_pipelined(disco_ctx* ctx, Steps (&steps)[2], disco_stream s) {
     hipStream_t s0 = (hipStream_t)s, s1 = ctx->side_stream;
     const size_t n = steps[0].size();
-    if (steps[1].size() != n || 2 * n > ctx->step_events.size()) return fail(ctx, DISCO_E_ARG, "overlapped call: step lists do not match");
+    if (steps[1].size() != n) return fail(ctx, DISCO_E_ARG, "overlapped call: step lists do not match");
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s0));
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_fork, 0));
     int rc = 0;
-    if (ctx->opt[DISCO_OPT_OVERLAP_SOLVES] != 3) {             // one child per stream
-        for (int h = 0; h < 2 && !rc; ++h)
-            for (size_t i = 0; i < n && !rc; ++i) {
-                rc = run_step(ctx->half[h], steps[h][i], (disco_stream)(h ? s1 : s0));
-                if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", ctx->half[h]->err);
-            }
-        const hipError_t e1 = hipEventRecord(ctx->ev_join, s1), e2 = hipStreamWaitEvent(s0, ctx->ev_join, 0);       // the join, whatever happened above
-        if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) {
-            snprintf(ctx->err, sizeof(ctx->err), "joining the side stream failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-            rc = DISCO_E_HIP_BASE - (int)(e1 != hipSuccess ? e1 : e2);
+    // one child per stream.  A failure inside the loop is collected, not returned: the join below must be reached whatever happened, or the
+    // caller's stream stays forked (and a capture unjoined)
+    for (int h = 0; h < 2 && !rc; ++h)
+        for (size_t i = 0; i < n && !rc; ++i) {
+            rc = run_step(ctx->half[h], steps[h][i], (disco_stream)(h ? s1 : s0));
+            if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", ctx->half[h]->err);
         }
-        return rc;
+    const hipError_t e1 = hipEventRecord(ctx->ev_join, s1), e2 = hipStreamWaitEvent(s0, ctx->ev_join, 0);       // the join, whatever happened above
+    if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) {
+        snprintf(ctx->err, sizeof(ctx->err), "joining the side stream failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        rc = DISCO_E_HIP_BASE - (int)(e1 != hipSuccess ? e1 : e2);
     }
-    // a HIP failure inside the loop is collected, not returned: the join below must be reached whatever happened, or the caller's
-    // stream stays forked (and a capture unjoined)
-    auto hip = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && !rc) {
-            snprintf(ctx->err, sizeof(ctx->err), "%s failed: %s", what, hipGetErrorString(e));
-            rc = DISCO_E_HIP_BASE - (int)e;
-        }
-    };
-    for (size_t i = 0; i < n && !rc; ++i)
-        for (int h = 0; h < 2 && !rc; ++h) {
-            disco_ctx* ch = ctx->half[h];
-            Step& x = steps[h][i];
-            hipStream_t cur = x.side ? s1 : s0;
-            if (i > 0 && steps[h][i - 1].side != x.side) hip(hipStreamWaitEvent(cur, ctx->step_events[2 * (i - 1) + h], 0), "hipStreamWaitEvent");
-            if (rc) break;
-            rc = run_step(ch, x, (disco_stream)cur);
-            if (rc) snprintf(ctx->err, sizeof(ctx->err), "%.500s", ch->err);
-            // the child's next step runs on the other stream: mark the end of this one there
-            if (!rc && i + 1 < n && steps[h][i + 1].side != x.side) hip(hipEventRecord(ctx->step_events[2 * i + h], cur), "hipEventRecord");
-        }
-    hip(hipEventRecord(ctx->ev_join, s1), "hipEventRecord");    // joined even after a failure: the caller's stream must not be left forked
-    hip(hipStreamWaitEvent(s0, ctx->ev_join, 0), "hipStreamWaitEvent");
     return rc;
 }
 
@@ -167,7 +141,8 @@ int reserve_scratch(disco_ctx* ctx) {
     const size_t G = (size_t)c.rooms * ctx->Kl;
     const size_t P = (size_t)std::min(c.mics + c.nodes - 1, 16);
     const size_t NP = P * (P + 1) / 2;
-    int chunks = std::max(2 * cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));        // (2 x: the (hi, lo) pairs of k_cov_loc_f64)
+    int chunks = std::max(cov_chunks(ctx), step2_chunks(ctx, (ctx->F - 1) / 64 + 1));
+    if (c.mics >= 7) chunks = std::max(chunks, 2 * cov1_f64_chunks(ctx));                       // the (hi, lo) pairs of k_cov_loc_f64
     if (c.mics <= 8) chunks = std::max(chunks, stft_cov_chunks(ctx, nullptr));
     if (c.mics + c.nodes - 1 > 8) chunks = std::max(chunks, room_chunks(ctx));
     const size_t need = G * (size_t)chunks * ctx->F * NP * sizeof(float4);
@@ -216,11 +191,6 @@ static void enhance_steps(disco_ctx* ctx, const PathArgs& a, Steps& st) {
             return step2_cov_partials(ctx, X, mask_w, w, z_y, &ch, s);
         }});
         st.push_back({"solve2", true, solve_pending(w2)});
-        const bool from_samples = !yf && c.n_fft == 512 && ctx->opt[DISCO_OPT_STEP2_FROM_SAMPLES] && from_samples_shape(c);
-        if (from_samples) {            // yf not asked for, spectra re-transformed instead of read back
-            st.push_back({"step2_stft_apply_istft", false, [=](disco_stream s) { return step2_stft_apply_istft(ctx, y, w, w2, out, s); }});
-            return;
-        }
         if (!yf && c.n_fft == 512) {   // yf not asked for: filter + iSTFT in one pass, yf stays on chip (shapes the kernel takes)
             if (step2_apply_istft_ok(ctx)) {
                 st.push_back({"step2_apply_istft", false, [=](disco_stream s) { return disco_step2_apply_istft_fused(ctx, X, w, w2, out, s); }});
@@ -251,7 +221,7 @@ static void enhance_steps(disco_ctx* ctx, const PathArgs& a, Steps& st) {
     st.push_back({nullptr, false, [=](disco_stream s) {
         int ch = 1, rc;
         if (c.nodes > 1 && same_mask && room_cov_ok(ctx, X, mask_w))
-            return STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w, z, &ch, s));
+            return STAGE(ctx, s, "room_cov2", room_cov_partials(ctx, X, mask_w, w, z, &ch, s));
         if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w, M, 1, z, s)))) return rc;
         return STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &ch, s, same_mask && c.nodes > 1));
     }});
@@ -511,7 +481,7 @@ static void iterated_steps(disco_ctx* ctx, const PathArgs& a, int iters, Steps& 
         st.push_back({nullptr, false, [=](disco_stream s) {
             int ch = 1, rc;
             if (same_mask && room_cov_ok(ctx, X, mask_w))
-                return STAGE(ctx, s, ctx->opt[DISCO_OPT_ROOM_DMA] ? "room_cov2" : "room_cov2_reg", room_cov_partials(ctx, X, mask_w, w_loc, z, &ch, s, last_pass));
+                return STAGE(ctx, s, "room_cov2", room_cov_partials(ctx, X, mask_w, w_loc, z, &ch, s, last_pass));
             if ((rc = STAGE(ctx, s, "apply1", disco_apply(ctx, X, nullptr, w_loc, M, 1, z, s)))) return rc;
             return STAGE(ctx, s, "cov2", cov_partials(ctx, X, mask_w, c.nodes > 1 ? z : nullptr, c.nodes > 1 ? z : nullptr, 1, P2, &ch, s,
                                                       same_mask && c.nodes > 1));
@@ -549,7 +519,7 @@ extern "C" int disco_tango_enhance_iterated(disco_ctx* ctx, const float* y, cons
     // The overlapped form on the wide shapes: with the LDS group solver it lost (C5: 46.4 ms plain, 48.0 / 48.4 ms overlapped -- the room
     // pass takes a whole CU per workgroup and the solver's LDS blocks compete with it); with the register / DPP solver (k_solve_dpp.h:
     // 15 KB of LDS per wave, float64 VALU only) it pays: 38.40 -> 37.88 ms (profiles/r03_o_C5_overlap*.json).  Default like the fused route.
-    if (overlap_applies(ctx) && ctx->half[0] && ctx->half[1] && 2 * (size_t)(4 + 2 * iters) <= ctx->step_events.size()) {
+    if (overlap_applies(ctx) && ctx->half[0] && ctx->half[1]) {
         Steps st[2];
         for (int h = 0; h < 2; ++h) iterated_steps(ctx->half[h], child_args(ctx, a, h), iters, st[h]);
         return run_pipelined(ctx, st, s);

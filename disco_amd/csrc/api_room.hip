@@ -21,23 +21,15 @@ bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     return (long long)K * ctx->T * ctx->F * M <= 0x0fffffffLL;                               // 32-bit BYTE offsets inside a room (8 B per element)
 }
 
-// time sub-chunks per workgroup of the persistent pass (option "room_sub": 4 or 8; anything else: 8)
-static int room_sub(const disco_ctx* ctx) {
-    const int s = ctx->opt[DISCO_OPT_ROOM_SUB];
-    return s == 4 ? 4 : 8;
-}
-
-// The persistent pass forms ONE partial block per node: its workgroups walk items (room, tile of 32 / SUB bins, all frames), the time
-// axis is split INSIDE the workgroup (SUB sub-chunks across the lanes).  The register-staged kernel keeps the chunked geometry.
-int room_chunks(const disco_ctx* ctx) { return ctx->opt[DISCO_OPT_ROOM_DMA] != 0 ? 1 : cov_chunks(ctx); }
+// The persistent pass forms ONE partial block per node: its workgroups walk items (room, tile of 4 bins, all frames), the time axis is
+// split INSIDE the workgroup (8 sub-chunks across the lanes).
+int room_chunks(const disco_ctx*) { return 1; }
 
 int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
                              int* chunks_out, disco_stream s, bool store_z) {
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics, K = c.nodes, P = M + K - 1;
     if (!w_loc || !z || !room_cov_ok(ctx, X, mask)) return fail(ctx, DISCO_E_ARG, "room covariance: shape / state does not qualify");
-    const bool dma = ctx->opt[DISCO_OPT_ROOM_DMA] != 0;
-    // the persistent LDS-DMA pass (default), or the register-staged kernel one frame ahead (DISCO_ROOM_DMA=0; k_room.h)
     const int chunks = room_chunks(ctx);
     const long long G = (long long)c.rooms * K;
     const int NP = P * (P + 1) / 2;
@@ -54,8 +46,8 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
     a.chunks = chunks;
     a.R = c.rooms;
     a.store_z = store_z ? 1 : 0;
-    if (dma) {
-        const int sub = room_sub(ctx), nb = 32 / sub;
+    {
+        constexpr int nb = 32 / 8;             // bins per workgroup (k_room.h RoomGeomS<M, K, 8>)
         a.tiles = (ctx->F + nb - 1) / nb;
         const long long items = (long long)c.rooms * a.tiles;
         if (items > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
@@ -63,17 +55,7 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
         // tiles on one XCD); a workgroup whose first item lies beyond the batch simply returns
         unsigned nwg = (unsigned)std::min<long long>(items, ctx->n_cu);
         if (items >= 64) nwg = std::max(64u, nwg / 64 * 64);
-        const hipStream_t st = (hipStream_t)s;
-        const bool ok = sub == 4 ? launch_room_s4(M, K, nwg, st, a) : launch_room_s8(M, K, nwg, st, a);
-        if (!ok) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: shape not instantiated");
-    } else {
-        a.tiles = (ctx->F + 31) / 32;
-        const long long nblk = (long long)c.rooms * a.tiles * chunks;
-        if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: batch too large for one launch");
-#define X_(M_, K_) \
-        if (M == M_ && K == K_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_room_cov<M_, K_>), dim3((unsigned)nblk), dim3(RoomGeom<M_, K_>::NT), 0, (hipStream_t)s, a);
-        DISCO_FOR_ROOM(X_)
-#undef X_
+        if (!launch_room_s8(M, K, nwg, (hipStream_t)s, a)) return fail(ctx, DISCO_E_UNSUPPORTED, "room covariance: shape not instantiated");
     }
     *chunks_out = chunks;
     ctx->pending_chunks = chunks;

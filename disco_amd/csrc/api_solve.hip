@@ -12,7 +12,7 @@ void launch_solve_dpp(int P, const SolveSrc& src, long long n_prob, double mu, c
 }
 
 template <int P>
-static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s, bool mixed, bool thread) {
+static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* w, c32* t1, hipStream_t s, bool thread) {
     if (P <= 4 || (P <= 8 && thread)) {             // one thread per pencil (k_solve_small.h)
         if constexpr (P <= 8) {
         constexpr int SOLVE_SMALL_THREADS = solve_small_threads<P>();
@@ -29,15 +29,6 @@ static void launch_solve(const SolveSrc& src, long long n_prob, double mu, c32* 
     if constexpr (P >= 5) {
     const int probs = SolveGeom<P>::PROBS;
     const long long grid = (n_prob + probs - 1) / probs;
-    if (mixed) {            // float32 squarings + float64 Rayleigh-quotient finish (option "solve_f32")
-        if (src.part)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1<P, true, true>), dim3((unsigned)grid), dim3(SolveGeom<P>::THREADS), 0, s, src,
-                               n_prob, mu, w, t1);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1<P, false, true>), dim3((unsigned)grid), dim3(SolveGeom<P>::THREADS), 0, s, src,
-                               n_prob, mu, w, t1);
-        return;
-    }
     if (src.part)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gevd_mwf_r1<P, true>), dim3((unsigned)grid), dim3(SolveGeom<P>::THREADS), 0, s, src,
                            n_prob, mu, w, t1);
@@ -52,12 +43,12 @@ static int solve_dispatch(disco_ctx* ctx, const SolveSrc& src, int64_t n_prob, i
     if (P < 1 || P > 16) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: P must be in 1..16");
     if (n_prob / 4 > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_gevd_mwf_r1: batch too large");
     hipStream_t st = (hipStream_t)s;
-    if (P >= 9 && ctx->opt[DISCO_OPT_SOLVE_DPP] != 0 && ctx->opt[DISCO_OPT_SOLVE_F32] == 0) {
+    if (P >= 9 && ctx->opt[DISCO_OPT_SOLVE_DPP] != 0) {
         launch_solve_dpp(P, src, n_prob, (double)mu, (c32*)w, (c32*)t1, st);
         return check_launch(ctx, "k_gevd_mwf_r1_dpp");
     }
     switch (P) {
-#define C_(P_) case P_: launch_solve<P_>(src, n_prob, (double)mu, (c32*)w, (c32*)t1, st, P_ >= 5 && ctx->opt[DISCO_OPT_SOLVE_F32] != 0, ctx->opt[DISCO_OPT_SOLVE_THREAD] != 0); break;
+#define C_(P_) case P_: launch_solve<P_>(src, n_prob, (double)mu, (c32*)w, (c32*)t1, st, ctx->opt[DISCO_OPT_SOLVE_THREAD] != 0); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
 #undef C_
     }

@@ -72,37 +72,7 @@ extern "C" int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X,
     return check_launch(ctx, "k_step2_apply_istft");
 }
 
-// the same pass from the samples (k_step2_stft_apply_istft): 512-point STFT, M <= 4, 2 <= K <= 4
 namespace disco_host {
-bool from_samples_shape(const disco_cfg& c) { return c.n_fft == 512 && c.mics <= 4 && c.nodes >= 2 && c.nodes <= 4; }
-
-int step2_stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w_loc, const disco_c32* w_glo, float* out,
-                                  disco_stream s) {
-    const disco_cfg& c = ctx->cfg;
-    const int M = c.mics, K = c.nodes;
-    if (!from_samples_shape(c)) return DISCO_E_UNSUPPORTED;
-    const int n_seg = (c.length + c.hop - 1) / c.hop;
-    const long long units = (long long)ctx->geom_rooms * K;
-    const long long bpr_wanted = std::max<long long>(1, (8192 + units - 1) / units);
-    int pairs = (int)(((n_seg + bpr_wanted - 1) / bpr_wanted + 2) / 2);
-    pairs = std::min(64, std::max(4, pairs));
-    if (ctx->tune_pairs > 0) pairs = ctx->tune_pairs;
-    const int bpr = (n_seg + 2 * pairs - 2) / (2 * pairs - 1);
-    const long long nblk = (long long)c.rooms * bpr;
-    if (nblk > 0x7fffffffLL) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_tango_enhance: batch too large for one launch");
-    bool launched = false;
-#define X_(M_, K_)                                                                                                        \
-    if (!launched && M == M_ && K == K_) {                                                                                \
-        launched = true;                                                                                                  \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step2_stft_apply_istft<512, M_, K_>), dim3((unsigned)nblk), dim3(64 * K_), 0,   \
-                           (hipStream_t)s, y, (const c32*)w_loc, (const c32*)w_glo, out, ctx->d_win, ctx->d_tw, c.length, ctx->T, \
-                           c.pad_mode, bpr, pairs);                                                                       \
-    }
-    X_(1, 2) X_(1, 3) X_(1, 4) X_(2, 2) X_(2, 3) X_(2, 4) X_(3, 2) X_(3, 3) X_(3, 4) X_(4, 2) X_(4, 3) X_(4, 4)
-#undef X_
-    if (!launched) return DISCO_E_UNSUPPORTED;
-    return check_launch(ctx, "k_step2_stft_apply_istft");
-}
 // Single node, enhanced output only: iSTFT(w^H STFT(y)) straight from the samples (k_stft_apply_istft), 512-point STFT, M <= 4
 int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, float* out, disco_stream s) {
     const disco_cfg& c = ctx->cfg;

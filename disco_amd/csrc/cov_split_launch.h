@@ -8,8 +8,9 @@ namespace disco_host {
 using namespace disco;
 
 
-// sub (step-1 shapes, KR = 0; option "cov1_mode"): 64 = float64 accumulators (k_cov_loc_f64: 2 * chunks partial blocks), 4 / 8 = float32 with
-// that many time sub-chunks across the lanes of a wave (the grid then counts tiles of 64 / sub bins), else float32, lanes are bins
+// Step-1 shapes (KR = 0, M >= 7) run k_cov_loc_f64: float64 accumulators, 2 * chunks partial blocks.  (Their float32 forms -- lanes = bins,
+// or 4 / 8 time sub-chunks across the lanes, option "cov1_mode" of round 4 -- were what C5's distance from the float64 oracle followed and
+// were removed in round 5: profiles/r04_c_c5_variants_cov1_f64.json.)
 template <int M, int KR>
 static void launch_cov_split(bool skiploc, int sub, unsigned nblk, hipStream_t st, const CovArgs& a) {
     // even M (every shape with remote rows, and the step-1 shape M = 8) with F - 1 a multiple of 64 (both FFT sizes of this library): frames
@@ -27,11 +28,9 @@ static void launch_cov_split(bool skiploc, int sub, unsigned nblk, hipStream_t s
             return;
         }
     }
-    if constexpr (KR == 0) {
-        if (sub == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_loc_f64<M>), dim3(nblk), dim3(256), 0, st, a);
-        else if (sub == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false, 4>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
-        else if (sub == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false, 8>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_split<M, KR, false>), dim3(nblk), dim3(64 * cov_split_waves<KR, false>()), 0, st, a);
+    if constexpr (KR == 0) {        // step-1 statistics of the wide shapes: float64 accumulators, (hi, lo) pairs of partial blocks
+        (void)sub;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_loc_f64<M>), dim3(nblk), dim3(256), 0, st, a);
     }
 }
 

@@ -15,28 +15,15 @@
 #include "../../include/disco_hip.h"
 #include "common.h"
 
-// Step 2 of the whole-path entry point (512-point STFT, <= 4 mics, <= 4 nodes): 1 = the filter + iSTFT pass re-transforms the
-// samples (k_step2_stft_apply_istft) instead of reading the stored spectra back; the environment variable
-// DISCO_STEP2_FROM_SAMPLES overrides it per context (A/B runs, tests of both paths).  Measured on C3: 5.9 ms from the
-// samples against 4.5-4.8 ms from the spectra (two more forward transforms per node-frame cost more LDS-write time than
-// the 10 GB of HBM reads they save) -> default 0.
-#ifndef DISCO_STEP2_FROM_SAMPLES_DEFAULT
-#define DISCO_STEP2_FROM_SAMPLES_DEFAULT 0
-#endif
 
 using disco::c32;
 
 // per-context options (disco_set_option / disco_get_option); the environment variable of the same meaning presets the value at
 // disco_create and is never looked at again
 enum {
-    DISCO_OPT_STEP2_FROM_SAMPLES = 0,   // "step2_from_samples": the fused filter + iSTFT pass re-transforms the samples
-    DISCO_OPT_ROOM_COV,                 // "room_cov": one-pass room kernel for the wide shapes (0: apply + staged covariance)
-    DISCO_OPT_ROOM_DMA,                 // "room_dma": its LDS-DMA ring (0: register-staged variant)
+    DISCO_OPT_ROOM_COV = 0,               // "room_cov": one-pass room kernel for the wide shapes (0: apply + staged covariance)
     DISCO_OPT_OVERLAP_SOLVES,           // "overlap_solves": whole-path calls run the batch as two halves on two streams
-    DISCO_OPT_SOLVE_F32,                // "solve_f32": float32 squarings + float64 Rayleigh-quotient finish in the group solver (default 0: all float64)
     DISCO_OPT_SOLVE_DPP,                // "solve_dpp": 9 <= P <= 16 solved in registers with DPP row broadcasts (k_solve_dpp.h; 0: the LDS group solver)
-    DISCO_OPT_ROOM_SUB,                 // "room_sub": time sub-chunks per workgroup of the persistent room pass (4 or 8 -> 8 or 4 bins per workgroup)
-    DISCO_OPT_COV1_MODE,                // "cov1_mode": step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (default), 4 / 8 = float32 with time sub-chunks across the lanes, else float32
     DISCO_OPT_SOLVE_THREAD,             // "solve_thread": 5 <= P <= 8 solved one THREAD per pencil (k_solve_small.h at one wave per SIMD, AGPRs as the second register file) instead of the LDS group solver
     DISCO_OPT_FUSE_WIDE_ISTFT,          // "fuse_wide_istft": whole-path calls of the wide shapes (P > 8) end in ONE filter + iSTFT pass (k_apply_istft_wide) instead of disco_apply + disco_istft
     DISCO_OPT_ONLINE_SQ32,              // "online_sq32": the online mode's thread solves (P <= 7) square in packed float32 (k_solve_small.h); 0: float64 throughout
@@ -82,7 +69,6 @@ struct disco_ctx {
     disco_ctx* parent;               // set in a child
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
-    std::vector<hipEvent_t> step_events;   // (step, child) hand-over events of the pipelined form
     // per-stage hipEvent timers of the whole-path entry points (disco_stage_timing / disco_stage_report)
     struct StageRec {
         char name[32];
@@ -210,6 +196,7 @@ RefLayout ref_layout(const disco_ctx* ctx);
 // launch geometry (batch-size heuristics / disco_set_tuning)
 int cov_chunks(const disco_ctx* ctx);
 int room_chunks(const disco_ctx* ctx);
+int cov1_f64_chunks(const disco_ctx* ctx);
 int step2_chunks(const disco_ctx* ctx, int tiles_plus_1);
 int stft_cov_chunks(const disco_ctx* ctx, int* runw_out);
 
@@ -238,9 +225,7 @@ int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco
 int step2_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask_w, const disco_c32* w_loc, disco_c32* z_out, int* chunks_out,
                        disco_stream s, bool skiploc = false);
 int stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w, float* out, disco_stream s);
-bool from_samples_shape(const disco_cfg& c);
 bool step2_apply_istft_ok(const disco_ctx* ctx);
 bool apply_istft_wide_ok(const disco_ctx* ctx);
 int apply_istft_wide(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, disco_c32* yf, float* out, disco_stream s);
-int step2_stft_apply_istft(disco_ctx* ctx, const float* y, const disco_c32* w_loc, const disco_c32* w_glo, float* out, disco_stream s);
 }  // namespace disco_host

@@ -804,25 +804,6 @@ __device__ __forceinline__ void cov_split_roles(const int role, Fn&& fn) {
     }
 }
 
-// grid = R*Kl * (tiles + 1) * chunks blocks of 64 * cov_split_waves() threads, tiles = ceil((F - 1) / (64 / S)); Zs == Zn and
-// mask_remote != 0 are the caller's contract
-template <int M, int KR, bool SKIPLOC, int S = 1>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__((64 * cov_split_waves<KR, SKIPLOC>())) void k_cov_split(CovArgs a) {
-    static_assert(KR > 0 || !SKIPLOC, "nothing to compute");
-    const int nbin = a.F - 1, tiles = (nbin + 64 / S - 1) / (64 / S);
-    int bid = blockIdx.x;
-    const int c = bid % a.chunks;
-    bid /= a.chunks;
-    const int tile = bid % (tiles + 1);
-    const long long g = bid / (tiles + 1);
-    const int lane = threadIdx.x & 63;
-    const int role = wave_id() + (KR > 0 ? 0 : 6);
-    cov_split_roles<M, KR, SKIPLOC>(role, [&](auto tag) {
-        using R_ = decltype(tag);
-        cov_split_wave<M, KR, R_::x0, R_::x1, R_::y0, R_::y1, R_::tri, S>(a, g, c, tile, lane);
-    });
-}
-
 // ---- the same partition with the frames staged through LDS ---------------------------------------------------------------------
 // In k_cov_split every wave fetches the (up to two) half-groups of v its block of pairs touches: 2.9 x the tile's bytes leave
 // L1/L2, and because the waves of a workgroup drift apart, 1.36 x reach the fabric (PMC, C5).  Here the workgroup's waves share

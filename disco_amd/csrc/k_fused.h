@@ -724,142 +724,6 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * (N / 128 + N / 256), 1) voi
     }
 }
 
-// ---- step-2 filter + iSTFT straight from the SAMPLES (tango.py:335 + 445 + 528) ---------------------------------------
-// k_step2_apply_istft with the read of X (8 M F bytes per node-frame) replaced by the 4 M H bytes of samples the spectra came
-// from: wave k streams node k's frames two at a time -- M/2 forward transforms per frame on the packed butterflies of pk.h,
-// the half-window shared by consecutive frames recycled in registers as in k_stft -- and filters every channel pair as it
-// leaves the untangle (z_k and the local part of yf_k accumulate over the pairs).  z exchange, remote rows, the inverse
-// transform of the frame pair and the overlap-add are k_step2_apply_istft's.  SURVEY 8d prices the path this way
-// ("16 M H": every pass over the signals re-transforms the samples); it pays once a transform costs ~140 instructions.
-template <int N, int M, int K>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * K, (M <= 4 && K <= 4) ? 2 : 1) void k_step2_stft_apply_istft(
-    const float* __restrict__ y, const c32* __restrict__ w_loc_g, const c32* __restrict__ w_glo_g, float* __restrict__ out,
-    const float* __restrict__ win, const c32* __restrict__ tw, int L, int T, int pad_mode, int blocks_per_room, int pairs) {
-    constexpr int E = FftPlan<N>::E, F = N / 2 + 1, EH = E / 2, NJ = EH + 1, P = M + K - 1, CHP = (M + 1) / 2;
-    static_assert(K > 1, "single node: k_stft_apply_istft");
-    __shared__ ApplyIstftShared<N, M, K> sh;
-    const int k = wave_id(), lane = threadIdx.x & 63;
-    const long long r = blockIdx.x / blocks_per_room;
-    const int s0 = (int)(blockIdx.x % blocks_per_room) * (2 * pairs - 1);       // first hop segment == first frame
-    const long long g = r * K + k;
-    {
-        const c32* src = w_loc_g + (r * K) * (long long)F * M;
-        c32* dst = &sh.wl[0][0][0];
-        for (int i = threadIdx.x; i < K * F * M; i += 64 * K) dst[i] = src[i];
-    }
-    c32 wg[NJ][P];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int f = (j < EH) ? lane + 64 * j : F - 1;
-#pragma unroll
-        for (int i = 0; i < P; ++i) wg[j][i] = w_glo_g[(g * F + f) * P + i];
-    }
-    WaveTw<N> wtw;
-    wtw.init(tw, lane);
-    float w[E];
-    load_window_half<N>(w, win, lane);
-    OlaWeights<N> ow;
-    ow.init(win, lane);
-    const float* xa[CHP];
-    const float* xb[CHP];
-#pragma unroll
-    for (int p = 0; p < CHP; ++p) {
-        xa[p] = y + (g * M + 2 * p) * (long long)L;
-        xb[p] = (2 * p + 1 < M) ? y + (g * M + 2 * p + 1) * (long long)L : xa[p];
-    }
-    c32 raw[CHP][E];
-#pragma unroll
-    for (int p = 0; p < CHP; ++p) load_frame_slots<N, 0, E>(raw[p], xa[p], xb[p], min(s0, T - 1), L, pad_mode, lane);
-    float carry[EH];
-#pragma unroll
-    for (int e = 0; e < EH; ++e) carry[e] = 0.f;
-    float* og = out + g * (long long)L;
-    c32* buf = sh.buf[k];
-    __syncthreads();
-    for (int pr = 0; pr < pairs; ++pr) {
-        const int tA = s0 + 2 * pr;
-        c32 yf[2][NJ];
-        // ---- transform, local part of yf and z for both frames
-#pragma unroll
-        for (int fr = 0; fr < 2; ++fr) {
-            const int t = tA + fr;
-            c32 nxt[CHP][EH];                        // the next frame's new half-window, in flight under this frame's transforms
-#pragma unroll
-            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], min(t + 1, T - 1), L, pad_mode, lane);
-            c32 zl[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) yf[fr][j] = zl[j] = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int p = 0; p < CHP; ++p) {
-                c32 v[E];
-                apply_window<N>(v, raw[p], w, 2 * p + 1 < M);
-                fft_wave<N>(v, wtw, buf, lane);
-                rfft_pair_untangle<N>(v, buf, lane, [&](int j, int f, c32 a, c32 b) {
-                    c32 wla, wlb = make_float2(0.f, 0.f);
-                    if constexpr (M % 2 == 0) {        // (w_loc[2p], w_loc[2p+1]) as one 16-byte LDS read
-                        const float4 q4 = *reinterpret_cast<const float4*>(&sh.wl[k][f][2 * p]);
-                        wla = make_float2(q4.x, q4.y);
-                        wlb = make_float2(q4.z, q4.w);
-                    } else {
-                        wla = sh.wl[k][f][2 * p];
-                        if (2 * p + 1 < M) wlb = sh.wl[k][f][2 * p + 1];
-                    }
-                    c32 za = cfma_conj(wla, a, zl[j]);
-                    c32 ya = cfma_conj(wg[j][2 * p], a, yf[fr][j]);
-                    if (2 * p + 1 < M) {
-                        za = cfma_conj(wlb, b, za);
-                        ya = cfma_conj(wg[j][2 * p + 1], b, ya);
-                    }
-                    zl[j] = za;
-                    yf[fr][j] = ya;
-                });
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int f = (j < EH) ? lane + 64 * j : F - 1;
-                if (j < EH || lane == 0) sh.zbuf[fr][k][f] = zl[j];
-            }
-#pragma unroll
-            for (int p = 0; p < CHP; ++p)
-#pragma unroll
-                for (int e = 0; e < EH; ++e) {
-                    DISCO_CONSUME(nxt[p][e].x);
-                    DISCO_CONSUME(nxt[p][e].y);
-                    raw[p][e] = raw[p][e + EH];
-                    raw[p][e + EH] = nxt[p][e];
-                }
-        }
-        __syncthreads();
-        // ---- remote rows: yf += sum_jj conj(wg[M+jj]) z_j   (concatenate_signals order)
-#pragma unroll
-        for (int fr = 0; fr < 2; ++fr) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int f = (j < EH) ? lane + 64 * j : F - 1;
-#pragma unroll
-                for (int jj = 0; jj < K - 1; ++jj) {
-                    const int jn = jj < k ? jj : jj + 1;
-                    yf[fr][j] = cfma_conj(wg[j][M + jj], sh.zbuf[fr][jn][f], yf[fr][j]);
-                }
-            }
-        }
-        if (tA + 1 >= T) {                           // wave-uniform, last pair of a signal only: frames past the end contribute nothing
-#pragma unroll
-            for (int fr = 0; fr < 2; ++fr)
-                if (tA + fr >= T) {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) yf[fr][j] = make_float2(0.f, 0.f);
-                }
-        }
-        // ---- V = A~ + i B~ (Hermitian extensions of the two frames), conjugated for the inverse-by-forward trick
-        c32 v[E];
-        irfft_pair_pack<N>(yf[0], yf[1], v, lane);       // cross-lane, no LDS round trip (fft.h)
-        fft_wave<N>(v, wtw, buf, lane);
-        ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, L, lane);
-        __syncthreads();                             // zbuf is rewritten by the next pair
-    }
-}
-
 // ---- single node: STFT -> filter -> iSTFT in one pass over the SAMPLES (config C2; get_z_signals.py:274-315 + tango.py:528) ------
 // With one node there is no exchange and step 2 repeats step 1, so after the statistics pass (k_stft_cov<.., STORE = false>)
 // and the solve, the output is iSTFT(w^H STFT(y)).  Reading the spectra back would move 8 M F bytes per node-frame; recomputing

@@ -88,11 +88,6 @@ struct SolveGeom {
     // (+1 where that count is even: the per-problem stride in 16-byte words is then odd, so the 4 / 8 / 16 problems a wave serves
     // start on distinct bank groups and a broadcast read of "the same entry of every problem" is conflict-free)
     static constexpr int LSZ = (DISCO_SOLVE_PACKED ? P * (P + 1) / 2 : P * (P + 1)) | 1;
-    // mixed-precision route (gevd_solve_group_mixed): the second LDS region holds, in turn, the float32 hand-off matrix of the
-    // squarings (c32 [P][YW32]) and the factor of the Rayleigh-quotient step (c64 lower triangle): BW c64 words, odd as well
-    static constexpr int YW32 = P;
-    static constexpr int BW = ((P * YW32 + 1) / 2 > LSZ ? (P * YW32 + 1) / 2 : LSZ) | 1;
-    static constexpr int BWV = (BW + P) | 1;                // ... plus one vector (the Householder data of that step) behind it
     __host__ __device__ static constexpr int lt(int i, int k) { return DISCO_SOLVE_PACKED ? i * (i + 1) / 2 + k : i * (P + 1) + k; }
 };
 
@@ -466,379 +461,16 @@ __device__ __forceinline__ void gevd_solve_group(const c32* rowA, const c32* row
     gain_out = gain;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Mixed-precision route (option "solve_f32"; NOT the default: measured on the MI355X it is slower than the all-float64 route
-// above -- 1.26 vs 1.07 ms per C3 launch at P = 7, 16.2 vs 14.4 ms per C5 step at P = 15 -- because with the power-step finish only
-// 3-4 squarings are left to speed up and the Rayleigh-quotient finish costs about as much as it saves; kept, tested, as the record
-// of it).  The idea: the covariances arrive as
-// float32, and the squarings are P^2 complex float64 multiply-adds per lane each.  Here
-//   * the whitening stays float64 (Cholesky of Rnn, the two substitutions: cond(Rnn) reaches 1e5 on real rooms);
-//   * the SQUARINGS run in float32 on packed instructions (v_pk_fma_f32: 2 per complex multiply-add instead of 4 v_fma_f64,
-//     half the LDS bytes, half the registers).  Rounding at 6e-8 per squaring moves the dominant vector by ~ 2 eps / (1 - d1/d0)
-//     in total (the early squarings, where B still has a small gap, are the sensitive ones): 1e-6 ... 1e-3;
-//   * ONE float64 Rayleigh-quotient step (two more while the residual says so) recovers every digit: with theta = v^H C v the
-//     system (theta I - C) x = v is solved in a basis rotated by the Householder reflector that sends v to the LAST coordinate.
-//     The near-null direction of theta I - C is then the last one, every pivot before it is bounded below by the eigenvalue gap,
-//     the right-hand side is e_last, and the solve collapses to ONE back substitution that never divides by the last pivot.
-//     Cubic convergence: 1e-4 -> 1e-12 / (1 - d1/d0).
-// Cost per pencil in units of one float64 squaring: 1.3 (whitening) + ~0.28 per float32 squaring + ~0.9 per Rayleigh-quotient step,
-// against 1.3 + 1 per float64 squaring.
-#ifndef DISCO_RQI_MAX
-#define DISCO_RQI_MAX 3
-#endif
-#ifndef DISCO_RQI_TOL
-#define DISCO_RQI_TOL 1e-9
-#endif
+// (A mixed-precision form of this solve -- float32 squarings on packed instructions and a float64 Rayleigh-quotient finish, option
+// "solve_f32" of rounds 2-4 -- measured slower than the all-float64 route, 1.26 against 1.07 ms per C3 launch at P = 7 and 16.2 against
+// 14.4 ms per C5 step at P = 15, and was removed in round 5: profiles/r03_design_and_experiment_log.md, git history.)
 
-// float32 twin of group_dominant: g = column j of the trace-normalised Hermitian matrix (destroyed), Bm = the group's float32
-// hand-off matrix [P][YW32].  v0: unit vector, every lane gets all of it.
-template <int P>
-__device__ __forceinline__ bool group_dominant32(c32* g, c32* Bm, const int j, c32* v0) {
-    constexpr int G = SolveGeom<P>::G, YW = SolveGeom<P>::YW32;
-    bool done;
-    {
-        float ssq = 0.f;
-#pragma unroll
-        for (int i = 0; i < P; ++i) ssq += g[i].x * g[i].x + g[i].y * g[i].y;
-        done = !(ssq > 0.f && ssq < 3.0e38f);                  // zero / not finite: nothing to iterate on
-    }
-    for (int it = 0; it < DISCO_SQUARINGS_MAX; ++it) {
-        DISCO_GROUP_SYNC();
-        if (j < P) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) Bm[i * YW + j] = g[i];
-        }
-        DISCO_GROUP_SYNC();
-        c32 nn[P];
-        c32 tc = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            if (i % DISCO_SQ_ROWS == 0) DISCO_SCHED_FENCE();
-            c32 a = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < P; ++k) a = cfma_pk(Bm[i * YW + k], g[k], a);
-            nn[i] = a;
-            if (i == j) tc = a;
-        }
-        DISCO_SCHED_FENCE();
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) {
-            tc.x += __shfl_xor(tc.x, off, G);
-            tc.y += __shfl_xor(tc.y, off, G);
-        }
-        const float den = tc.x * tc.x + tc.y * tc.y;
-        const float rden = den > 0.f ? 1.0f / den : 0.f;
-        const c32 itau = make_float2(tc.x * rden, -tc.y * rden);       // 1 / tau as a complex number (see group_dominant)
-        if (!done) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) g[i] = cmul_pk(nn[i], itau);
-        }
-        done = done || (1.0f - tc.x < (float)DISCO_SQUARING_DONE) || !(den > 0.f);
-        if (!__any(!done)) break;
-    }
-    asm volatile("" ::: "memory");
-    float nrm = 0.f;
-#pragma unroll
-    for (int i = 0; i < P; ++i) nrm += g[i].x * g[i].x + g[i].y * g[i].y;
-    float best = nrm;
-    int bj = j;
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, G);
-        const int oj = __shfl_xor(bj, off, G);
-        if (ob > best || (ob == best && oj < bj)) {
-            best = ob;
-            bj = oj;
-        }
-    }
-    const bool have = best > 0.f && best < 3.0e38f;
-    const float rb = have ? rsqrtf(best) : 0.f;
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        v0[i].x = __shfl(g[i].x, bj, G);
-        v0[i].y = __shfl(g[i].y, bj, G);
-        if (have) v0[i] = make_float2(v0[i].x * rb, v0[i].y * rb);
-        else v0[i] = make_float2(i == 0 ? 1.f : 0.f, 0.f);
-    }
-    // power steps on the kept square (B Hermitian: (B v)[j] = sum_i conj(B[i][j]) v[i], lane j from its own column)
-#pragma unroll 1
-    for (int s = 0; s < DISCO_POWER_STEPS; ++s) {
-        c32 u = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < P; ++i) u = cfma_conj(g[i], v0[i], u);
-        DISCO_GROUP_SYNC();
-        if (j < P) Bm[j] = u;
-        DISCO_GROUP_SYNC();
-        if (have) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) v0[i] = Bm[i];
-        }
-    }
-    if (DISCO_POWER_STEPS > 0 && have) {
-        float n2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < P; ++i) n2 += v0[i].x * v0[i].x + v0[i].y * v0[i].y;
-        const float rn = rsqrtf(n2);
-#pragma unroll
-        for (int i = 0; i < P; ++i) v0[i] = make_float2(v0[i].x * rn, v0[i].y * rn);
-    }
-    return have;
-}
-
-// theta = v^H C v and the relative residual |C v - theta v| / |theta| of the unit vector v (all of it in every lane), lane j
-// holding column j of the Hermitian C.  cvj: this lane's (C v)_j.
-template <int P>
-__device__ __forceinline__ void group_rayleigh(const c64* gC, const c64* v, const int j, double& theta, double& rel, c64& cvj) {
-    constexpr int G = SolveGeom<P>::G;
-    c64 a = make_double2(0.0, 0.0), vj = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int i = 0; i < P; ++i) {                              // (C v)_j = sum_i conj(C[i][j]) v_i
-        a.x = fma(gC[i].x, v[i].x, fma(gC[i].y, v[i].y, a.x));
-        a.y = fma(gC[i].x, v[i].y, fma(-gC[i].y, v[i].x, a.y));
-        if (i == j) vj = v[i];
-    }
-    if (j >= P) a = make_double2(0.0, 0.0);
-    double th = vj.x * a.x + vj.y * a.y;                       // Re(conj(v_j) (C v)_j)
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) th += __shfl_xor(th, off, G);
-    const double rx = a.x - th * vj.x, ry = a.y - th * vj.y;
-    double r2 = rx * rx + ry * ry;
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) r2 += __shfl_xor(r2, off, G);
-    theta = th;
-    rel = th > 0.0 ? sqrt(r2) * rcp64(th) : 0.0;
-    cvj = a;
-}
-
-// One Rayleigh-quotient step on the unit vector v (all of it in every lane; replaced by the new unit vector where `go`): lane j
-// holds column j of C, cvj = (C v)_j and theta come from group_rayleigh.  Fm: LDS, SolveGeom<P>::BWV c64 words (the factor, and
-// one vector behind it).  Register diet: the Householder vector u = v - alpha e_t differs from v in one entry and is never
-// formed, w lives in LDS, the right-hand side e_t is folded into the substitution.
-template <int P>
-__device__ __forceinline__ void group_rqi_step(const c64* gC, c64* v, const double theta, const c64 cvj, c64* Fm, const int j, const bool go) {
-    using SG = SolveGeom<P>;
-    constexpr int t = P - 1;
-    c64* Wv = Fm + SG::BW;
-    // Householder u = v - alpha e_t with alpha = -phase(v_t): H = I - beta u u^H sends v to alpha e_t, beta = 1 / (1 + |v_t|)
-    const double at = sqrt(v[t].x * v[t].x + v[t].y * v[t].y);
-    const double rat = at > 0.0 ? rcp64(at) : 0.0;
-    const c64 alpha = at > 0.0 ? make_double2(-v[t].x * rat, -v[t].y * rat) : make_double2(-1.0, 0.0);
-    const double beta = rcp64(1.0 + at);
-    const c64 ut = zsub(v[t], alpha);                          // u_t; u_i = v_i otherwise
-    // p = C u = C v - alpha C e_t: lane j has (C v)_j and C[j][t] = conj(C[t][j]) (its own column)
-    const c64 pj = zsub(cvj, zmul(alpha, make_double2(gC[t].x, -gC[t].y)));
-    c64 uj = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-        if (i == j) uj = i == t ? ut : v[i];
-    // u^H p is real (C Hermitian): sum over the lanes of Re(conj(u_j) p_j)
-    constexpr int G = SG::G;
-    double up = j < P ? uj.x * pj.x + uj.y * pj.y : 0.0;
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) up += __shfl_xor(up, off, G);
-    const double c2 = 0.5 * beta * beta * up;
-    const c64 wj = make_double2(beta * pj.x - c2 * uj.x, beta * pj.y - c2 * uj.y);      // w = beta p - (beta^2 / 2)(u^H p) u
-    DISCO_GROUP_SYNC();
-    if (j < P) Wv[j] = wj;
-    DISCO_GROUP_SYNC();
-    // row j (lower part) of M = theta I - H C H,  (H C H)[c][j] = C[c][j] - u_c conj(w_j) - w_c conj(u_j); M[j][c] = conj(M[c][j])
-    if (j < P) {
-#pragma unroll
-        for (int c = 0; c < P; ++c) {
-            if (c <= j) {
-                const c64 uc = c == t ? ut : v[c];
-                c64 m = zadd(zmulc(uc, wj), zmulc(Wv[c], uj));
-                m = zsub(m, gC[c]);
-                if (c == j) m.x += theta;
-                Fm[SG::lt(j, c)] = make_double2(m.x, -m.y);
-            }
-        }
-    }
-    DISCO_GROUP_SYNC();
-    (void)group_cholesky_factor<P>(Fm, j);
-    // (theta I - H C H) y = e_t up to scale: L L^H y = e_t  ->  L^H y ~ e_t; the last pivot only scales y and is never divided by:
-    // y_t = 1, y_i = -(sum_{k > i} conj(L[k][i]) y_k) / L[i][i]
-    c64 yv[P];
-    yv[t] = make_double2(1.0, 0.0);
-#pragma unroll
-    for (int i = P - 2; i >= 0; --i) {
-        DISCO_SCHED_FENCE();
-        c64 a = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int k = i + 1; k < P; ++k) a = zsub(a, zmul(make_double2(Fm[SG::lt(k, i)].x, -Fm[SG::lt(k, i)].y), yv[k]));
-        yv[i] = zscale(a, Fm[SG::lt(i, i)].x);
-        DISCO_CONSUME(yv[i].x);
-        DISCO_CONSUME(yv[i].y);
-    }
-    // x = H y = y - beta u (u^H y), normalised
-    c64 uy = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const c64 ui = i == t ? ut : v[i];
-        uy = zadd(uy, zmul(make_double2(ui.x, -ui.y), yv[i]));
-    }
-    uy = zscale(uy, beta);
-    double n2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const c64 ui = i == t ? ut : v[i];
-        yv[i] = zsub(yv[i], zmul(ui, uy));
-        n2 = fma(yv[i].x, yv[i].x, fma(yv[i].y, yv[i].y, n2));
-    }
-    const bool ok = go && n2 > 0.0 && n2 < 1.7e308;
-    const double rn = ok ? rsqrt64(n2) : 0.0;
-#pragma unroll
-    for (int i = 0; i < P; ++i) v[i] = ok ? zscale(yv[i], rn) : v[i];
-}
-
-// gevd_solve_group with float32 squarings and a float64 Rayleigh-quotient finish.  Lm: SolveGeom<P>::LSZ c64 words, Bm:
-// SolveGeom<P>::BWV c64 words of LDS per group.  load_rows(rowA, rowB) fills row j of Rxx / Rnn: it is called at the start and
-// AGAIN for the closing Rayleigh quotient, so that the 4 P registers of the two rows are free during the iterations.
-template <int P, bool REENTER, class LoadRows>
-__device__ __forceinline__ void gevd_solve_group_mixed(LoadRows&& load_rows, c64* Lm, c64* Bm, const int j, const double mu,
-                                                       c64& t1_j, double& gain_out) {
-    constexpr int G = SolveGeom<P>::G, YW = SolveGeom<P>::YW32;
-    using SG = SolveGeom<P>;
-    c32* B32 = reinterpret_cast<c32*>(Bm);
-    if constexpr (REENTER) DISCO_GROUP_SYNC();
-    c64 gC[P];                                                 // first: conj(row j of Y), the right-hand side of the second substitution
-    {
-    c32 rowA[P], rowB[P];
-    load_rows(rowA, rowB);
-    group_cholesky<P>(rowB, Lm, j);
-
-    // ---- column j of Y = L^-1 Rxx; lane j needs ROW j of it next.  The transposition goes through the float32 matrix in two
-    // passes, the float32 head of every entry and then the float32 head of what that left (48 bits together): the matrix C
-    // below is the one the Rayleigh-quotient finish works on, so the hand-over must not cost it its float64 accuracy, and a
-    // float64 hand-off matrix is exactly the LDS footprint this route exists to avoid.
-    {
-        c64 y[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            DISCO_SCHED_FENCE();
-            c64 a = make_double2((double)rowA[i].x, -(double)rowA[i].y);
-#pragma unroll
-            for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], y[k]));
-            y[i] = zscale(a, Lm[SG::lt(i, i)].x);
-            DISCO_CONSUME(y[i].x);
-            DISCO_CONSUME(y[i].y);
-        }
-        if (j < P) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) B32[i * YW + j] = make_float2((float)y[i].x, (float)y[i].y);
-        }
-        DISCO_GROUP_SYNC();
-#pragma unroll
-        for (int i = 0; i < P; ++i) gC[i] = j < P ? make_double2((double)B32[j * YW + i].x, -(double)B32[j * YW + i].y) : make_double2(0.0, 0.0);
-        DISCO_GROUP_SYNC();
-        if (j < P) {
-#pragma unroll
-            for (int i = 0; i < P; ++i)
-                B32[i * YW + j] = make_float2((float)(y[i].x - (double)(float)y[i].x), (float)(y[i].y - (double)(float)y[i].y));
-        }
-        DISCO_GROUP_SYNC();
-        if (j < P) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                gC[i].x += (double)B32[j * YW + i].x;
-                gC[i].y -= (double)B32[j * YW + i].y;
-            }
-        }
-    }
-    }
-    // ---- column j of C = L^-1 Y^H in float64 (kept for the Rayleigh-quotient step), trace-normalised
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        DISCO_SCHED_FENCE();
-        c64 a = gC[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) a = zsub(a, zmul(Lm[SG::lt(i, k)], gC[k]));
-        gC[i] = zscale(a, Lm[SG::lt(i, i)].x);
-        DISCO_CONSUME(gC[i].x);
-        DISCO_CONSUME(gC[i].y);
-    }
-    asm volatile("" ::: "memory");
-    bool ok;
-    {
-        double trl = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-            if (i == j) trl = gC[i].x;
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) trl += __shfl_xor(trl, off, G);
-        ok = trl > 0.0 && trl < 1.7e308;
-        const double rt = ok ? rcp64(trl) : 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) gC[i] = ok ? zscale(gC[i], rt) : make_double2(0.0, 0.0);
-    }
-    // ---- dominant vector in float32
-    c64 v0[P];
-    bool have;
-    {
-        c32 g32[P], v32[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) g32[i] = make_float2((float)gC[i].x, (float)gC[i].y);
-        have = group_dominant32<P>(g32, B32, j, v32) && ok;
-#pragma unroll
-        for (int i = 0; i < P; ++i) v0[i] = make_double2((double)v32[i].x, (double)v32[i].y);
-        if (have) {                                            // unit length in float64
-            double n2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < P; ++i) n2 = fma(v0[i].x, v0[i].x, fma(v0[i].y, v0[i].y, n2));
-            const double rn = rsqrt64(n2);
-#pragma unroll
-            for (int i = 0; i < P; ++i) v0[i] = zscale(v0[i], rn);
-        }
-    }
-    // ---- float64 finish: Rayleigh-quotient steps until the residual of every pencil of the wave is down (wave-uniform loop)
-    for (int it = 0; it < DISCO_RQI_MAX; ++it) {
-        double theta, rel;
-        c64 cvj;
-        group_rayleigh<P>(gC, v0, j, theta, rel, cvj);
-        const bool go = have && theta > 0.0 && rel > DISCO_RQI_TOL;
-        if (!__any(go)) break;
-        group_rqi_step<P>(gC, v0, theta, cvj, Bm, j, go);
-    }
-
-    asm volatile("" ::: "memory");
-    c64 q[P];
-    group_back_substitute<P>(v0, Lm, q);
-    const double l00 = Lm[SG::lt(0, 0)].y;
-    const c64 gsc = make_double2(l00 * v0[0].x, -l00 * v0[0].y);
-    double d0;
-    {
-        DISCO_SCHED_FENCE();                                   // the rows are fetched AFTER the substitution, not hoisted above it
-        c32 rowA[P], rowB[P];
-        load_rows(rowA, rowB);
-        c64 sj = make_double2(0.0, 0.0), qj = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int c = 0; c < P; ++c) {
-            sj.x = fma((double)rowA[c].x, q[c].x, fma(-(double)rowA[c].y, q[c].y, sj.x));
-            sj.y = fma((double)rowA[c].x, q[c].y, fma((double)rowA[c].y, q[c].x, sj.y));
-            if (c == j) qj = q[c];
-        }
-        double e = j < P ? qj.x * sj.x + qj.y * sj.y : 0.0;
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) e += __shfl_xor(e, off, G);
-        d0 = have ? e : 0.0;
-    }
-    const double dcl = fmin(fmax(d0, SOLVE_EPS), SOLVE_ETA);
-    const double gain = dcl / (dcl + mu);
-    t1_j = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        if (i == j) t1_j = zmul(q[i], gsc);
-    }
-    gain_out = gain;
-}
-
-template <int P, bool FROM_PART, bool MIXED = false>
+template <int P, bool FROM_PART>
 __global__ DISCO_KERNEL_ALIGN __launch_bounds__(SolveGeom<P>::THREADS, SolveGeom<P>::WPE) void k_gevd_mwf_r1(SolveSrc src, long long n_prob, double mu,
                                                                         c32* __restrict__ w_out, c32* __restrict__ t1_out) {
     constexpr int G = SolveGeom<P>::G, PROBS = SolveGeom<P>::PROBS;
     __shared__ c64 s_L[PROBS][SolveGeom<P>::LSZ];       // lower triangle: L (strict) ; diagonal keeps Rnn[c][c]
-    // second region: the float64 matrix Y (all-float64 route), or the float32 hand-off matrix / Rayleigh-quotient factor (mixed route)
-    __shared__ c64 s_Y[PROBS][MIXED ? SolveGeom<P>::BWV : P * SolveGeom<P>::YW];
+    __shared__ c64 s_Y[PROBS][P * SolveGeom<P>::YW];      // second region: the float64 matrix Y
     const int j = threadIdx.x % G;             // column owned by this lane
     const int slot = threadIdx.x / G;
     const long long pid = (long long)blockIdx.x * PROBS + slot;
@@ -846,26 +478,19 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(SolveGeom<P>::THREADS, SolveGeom
     const bool col = live && j < P;
 
     // ---- row j of both matrices
-    auto load_rows = [&](c32* rowA, c32* rowB) {
-        if (col) {
-            solve_load_row<P, FROM_PART>(src, pid, j, rowA, rowB);
-        } else {
+    c32 rowA[P], rowB[P];
+    if (col) {
+        solve_load_row<P, FROM_PART>(src, pid, j, rowA, rowB);
+    } else {
 #pragma unroll
-            for (int c = 0; c < P; ++c) {
-                rowA[c] = make_float2(0.f, 0.f);
-                rowB[c] = make_float2(c == j ? 1.f : 0.f, 0.f);
-            }
+        for (int c = 0; c < P; ++c) {
+            rowA[c] = make_float2(0.f, 0.f);
+            rowB[c] = make_float2(c == j ? 1.f : 0.f, 0.f);
         }
-    };
+    }
     c64 t1;
     double gain;
-    if constexpr (MIXED) {
-        gevd_solve_group_mixed<P, false>(load_rows, s_L[slot], s_Y[slot], j, mu, t1, gain);
-    } else {
-        c32 rowA[P], rowB[P];
-        load_rows(rowA, rowB);
-        gevd_solve_group<P, false>(rowA, rowB, s_L[slot], reinterpret_cast<c64(*)[SolveGeom<P>::YW]>(s_Y[slot]), j, mu, t1, gain);
-    }
+    gevd_solve_group<P, false>(rowA, rowB, s_L[slot], reinterpret_cast<c64(*)[SolveGeom<P>::YW]>(s_Y[slot]), j, mu, t1, gain);
     if (col) {
         if (t1_out) t1_out[pid * P + j] = make_float2((float)t1.x, (float)t1.y);
         w_out[pid * P + j] = make_float2((float)(t1.x * gain), (float)(t1.y * gain));

@@ -557,6 +557,9 @@ class _OnlineStream:
         return n_hops + (1 if last else 0)
 
     def push(self, y_new, mask_z, mask_w=None, last=False):
+        """The next n_hops >= 1 hops of every channel (the first push: >= 2) -> the samples that became final.  last=True also completes the
+        frame centred at the end of the signal; it needs new samples in the same call (the stream cannot be flushed empty-handed: the
+        caller marks its last chunk)."""
         e = self.eng
         R, K, M, n = y_new.shape
         H = (e.F - 1)                                        # hop = n_fft / 2 = F - 1
@@ -564,6 +567,11 @@ class _OnlineStream:
         n_hops = n // H
         n_new = n_hops + (1 if last else 0)
         n_out = H * (n_new - (1 if self.hops == 0 else 0))
+        # the C entry point receives bare pointers and reads n_new mask rows per (room, node): a mask that is one frame short (the extra
+        # frame of the LAST chunk forgotten) would be an out-of-bounds device read -- checked here
+        for nm, mk in (('mask_z', mask_z), ('mask_w', mask_w)):
+            if mk is not None and hasattr(mk, 'shape'):
+                assert tuple(mk.shape) == (R, K, n_new, e.F), f'{nm}: expected {(R, K, n_new, e.F)} (n_hops + 1 frames with last=True), got {tuple(mk.shape)}'
         py, ky = e.to_device(np.ascontiguousarray(y_new) if isinstance(y_new, np.ndarray) else y_new, np.float32)
         pmz, kmz = e.to_device(mask_z, np.float32)
         if mask_w is None or mask_w is mask_z:

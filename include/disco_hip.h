@@ -134,41 +134,32 @@ int  disco_set_tuning(disco_ctx* ctx, int stft_frames_per_wave, int cov_chunks, 
  * Two contexts of one process may differ; nothing is read from the environment inside a compute call -- an environment variable
  * (named below) only PRESETS the option when disco_create runs.  The route a whole-path call took shows in the stage names of
  * disco_stage_report.  Keys:
- *   "step2_from_samples" (DISCO_STEP2_FROM_SAMPLES, default 0)  fused filter + iSTFT pass re-transforms the samples (stage
- *                         "step2_stft_apply_istft") instead of reading the stored spectra ("step2_apply_istft")
- *   "room_cov"           (DISCO_ROOM_COV, 1)   wide shapes: z + step-2 statistics of a whole room in one pass ("room_cov2") instead of
- *                         disco_apply + disco_cov_masked ("apply1" + "cov2")
- *   "room_dma"           (DISCO_ROOM_DMA, 1)   that pass as ONE PERSISTENT workgroup per CU on an LDS-DMA ring ("room_cov2"); 0: register-staged, one
- *                         workgroup per (room, tile, chunk) ("room_cov2_reg")
+ *   "room_cov"           (DISCO_ROOM_COV, default 1)   wide shapes (M + K - 1 > 8): z + step-2 statistics of a whole room in one persistent pass
+ *                         ("room_cov2", csrc/k_room.h) instead of disco_apply + disco_cov_masked ("apply1" + "cov2": the staged route,
+ *                         which a node shard takes in any case)
  *   "overlap_solves"     (DISCO_OVERLAP_SOLVES, 1)  disco_tango_enhance / _iterated on batches of rooms x nodes >= 1024 run as two
  *                         half-batches, the second on an internal stream forked from / joined to the caller's with events (still one
  *                         capturable launch sequence): one half's solves overlap the other half's streaming kernels.  Each stage
- *                         then shows 2 launches of R/2 rooms.  2: force it for any batch of >= 2 rooms (tests); 3: forced, and only
- *                         the solves go to the side stream (software-pipelined; measured slower, kept as a record); 0: off.  The
+ *                         then shows 2 launches of R/2 rooms.  2: force it for any batch of >= 2 rooms (tests); 0: off.  The
  *                         half-batch contexts (own partial-sum blocks) are created by disco_create / disco_set_option
- *   "solve_f32"          (DISCO_SOLVE_F32, 0)  1: group solver (P >= 5) with float32 squarings on packed instructions and a float64
- *                         Rayleigh-quotient finish (same accuracy; measured SLOWER than the all-float64 default on the MI355X: 1.26 vs
- *                         1.07 ms at P = 7, 16.2 vs 14.4 ms at P = 15 -- after round 2 only 3-4 squarings are left to speed up)
- *   "room_sub"           (DISCO_ROOM_SUB, 8)    time sub-chunks per workgroup of the persistent room pass ("room_dma" = 1): a workgroup owns 32 / n bins and n
- *                         consecutive frames at a time, a lane's float32 sums are n times shorter and meet inside the wave (csrc/k_room.h).  8 or 4
- *   "cov1_mode"          (DISCO_COV1_MODE, 64)  step-1 statistics of the wide shapes (M >= 7): 64 = float64 accumulators (k_cov_loc_f64: their float32
- *                         summation was what C5's distance from the float64 oracle followed); 4 / 8 = float32 with that many time sub-chunks across
- *                         the lanes of a wave; anything else = float32, lanes are bins
  *   "solve_thread"       (DISCO_SOLVE_THREAD, 1) rank-1 GEVD-MWF solves with 5 <= P <= 8 (and the online mode with 5 <= P <= 7) run one THREAD per
  *                         pencil (csrc/k_solve_small.h: Hermitian halves in registers, AGPRs as the second register file at P = 8): 0.26 against
- *                         0.61 ms per 1 028 000 P = 7 pencils, 0.39 against 0.81 at P = 8; 0: the LDS group solver.  P <= 4 always runs per thread
+ *                         0.61 ms per 1 028 000 P = 7 pencils, 0.39 against 0.81 at P = 8; 0: the LDS group solver (csrc/k_solve.h), the
+ *                         cross-check route of the solver tests.  P <= 4 always runs per thread
+ *   "solve_dpp"          (DISCO_SOLVE_DPP, 1)  rank-1 GEVD-MWF solves with 9 <= P <= 16 run in registers, other lanes' entries read through
+ *                         DPP row broadcasts (csrc/k_solve_dpp.h: 3.7 instead of 7.2 ms per C5 launch); 0: the LDS group solver.  Same
+ *                         algorithm and breakdown rules; the two are tested against each other (check_solver_routes)
  *   "online_sq32"        (DISCO_ONLINE_SQ32, 1) online mode, thread solves (P <= 7): the repeated squarings on packed float32 (v_pk_fma_f32), Cholesky,
  *                         whitening, back substitution and the Rayleigh quotient in float64 (csrc/k_solve_small.h): 193 instead of 240 ms per
  *                         C3-shaped 1000-room step (52x instead of 42x real-time), the same 2.0e-6 from the oracle; 0: float64 squarings.  The
  *                         offline solves always square in float64
  *   "fuse_wide_istft"    (DISCO_FUSE_WIDE_ISTFT, 1) disco_tango_enhance / _iterated on the wide shapes (M + K - 1 > 8; 512 / 1024-point STFT) end in ONE
  *                         filter + iSTFT pass (csrc/k_fused.h k_apply_istft_wide, stage "apply2_istft": the filtered spectra stay on chip, and are
- *                         written only when the caller asks for yf) instead of disco_apply + disco_istft ("apply2" + "istft"): 4.0-4.6 against 5.5 ms
- *                         per C5 step
- *   "solve_dpp"          (DISCO_SOLVE_DPP, 1)  rank-1 GEVD-MWF solves with 9 <= P <= 16 run in registers, other lanes' entries read through
- *                         DPP row broadcasts (csrc/k_solve_dpp.h: 3.7 instead of 7.2 ms per C5 launch); 0: the LDS group solver, which P <= 8,
- *                         the online mode and "solve_f32" use in any case.  Same algorithm and breakdown rules; the two are tested against
- *                         each other (check_solver_routes)
+ *                         written only when the caller asks for yf) instead of disco_apply + disco_istft ("apply2" + "istft": what the ABI's
+ *                         stage calls and a node shard run)
+ * Routes that earlier rounds measured slower or less accurate and kept "as a record" are gone from the library (round 5): the filter +
+ * iSTFT pass from the samples, the register-staged room pass, the mixed-precision group solver, 4 time sub-chunks in the room pass, the
+ * float32 step-1 statistics of the wide shapes, the solves-only side stream.  Their measurements are in profiles/.
  * Unknown key: DISCO_E_ARG. */
 int  disco_set_option(disco_ctx* ctx, const char* key, int value);
 int  disco_get_option(const disco_ctx* ctx, const char* key, int* value);

@@ -144,6 +144,15 @@ def test_solver_routes_dpp_vs_lds(make_engine):
     print(pc.check_solver_routes(make_engine, sizes=(9, 10, 11, 12, 13, 14, 15, 16), n=4099))
 
 
+def test_solver_routes_thread_vs_group(make_engine):
+    """5 <= P <= 8: one thread per pencil (default) against the LDS group solver (option "solve_thread" 0): full matrices, and both loaders
+    through the partial sums of a covariance call."""
+    print(pc.check_solver_routes(make_engine, sizes=(5, 6, 7, 8), option='solve_thread'))
+    for M in (5, 6, 7, 8):
+        for thread in (0, 1):
+            print(M, thread, pc.check_cov_solve_apply(make_engine, R=2, K=1, M=M, L=16384, options={'solve_thread': thread}))
+
+
 def test_solver_degenerate_inputs(make_engine):
     pc.check_solver_degenerate(make_engine)
 
@@ -172,14 +181,13 @@ def test_tango_bench_geometry(make_engine, R, K, M, L, n_fft, tuning):
     print(errs)
 
 
-@pytest.mark.parametrize('from_samples', [0, 1])
 @pytest.mark.parametrize('R,K,M,L,tuning', [(2, 4, 4, 160000, (80, 1, 1, 64)), (2, 2, 3, 41000, None), (1, 3, 2, 25700, (80, 1, 1, 5)),
                                             (2, 4, 1, 30000, None)])
-def test_step2_from_samples_and_from_spectra(make_engine, R, K, M, L, tuning, from_samples):
-    """Both step-2 filter + iSTFT kernels of the enhanced-only call: reading the stored spectra back (0) and re-transforming
-    the samples (1), at the bench geometry and at ragged ones."""
+def test_enhanced_only_geometries(make_engine, R, K, M, L, tuning):
+    """The step-2 filter + iSTFT kernel of the enhanced-only call (the spectra read back, yf on chip) at the bench geometry and at
+    ragged ones: odd and even mic counts, signals that end inside a frame pair, one-pair workgroups."""
     y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
-    errs = pc.check_tango_end_to_end(make_engine, y, s, n, tol=1e-4, tuning=tuning, from_samples=from_samples)
+    errs = pc.check_tango_end_to_end(make_engine, y, s, n, tol=1e-4, tuning=tuning)
     print(errs)
 
 
@@ -283,7 +291,7 @@ def test_apply_istft_wide(make_engine, K, M, n_fft, L, pairs, R):
     print(pc.check_apply_istft_wide(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=R, pairs=pairs, oracle=L > 1000))
 
 
-@pytest.mark.parametrize('mode', [2, 3])
+@pytest.mark.parametrize('mode', [2])
 @pytest.mark.parametrize('K,M,n_fft,iters,R', [(4, 4, 512, 1, 5), (1, 4, 512, 1, 4), (8, 8, 1024, 2, 2), (2, 8, 512, 2, 3)])
 def test_overlapped_halves(make_engine, K, M, n_fft, iters, R, mode):
     """disco_set_option("overlap_solves"): the whole-path calls as two half-batch children, the second on the context's side stream

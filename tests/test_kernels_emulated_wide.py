@@ -109,7 +109,7 @@ def test_emu_room_cov(make_engine, K, M, n_fft, L, tuning):
     """k_room_cov (z of every node + step-2 statistics of every node of a room in one pass over X) against the route it
     replaces and against the oracle; several frame chunks (down to chunks of one or two frames: shorter than the three-frame
     look-ahead of the LDS-DMA ring), a last tile with one live bin (the Nyquist bin)."""
-    print(pc.check_room_cov(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M >= 32 else 2, tuning=tuning, subs=(4,)))
+    print(pc.check_room_cov(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=1 if K * M >= 32 else 2, tuning=tuning))
 
 
 @pytest.mark.parametrize('K,M,n_fft,L,pairs', [(2, 8, 1024, 9000, 0), (8, 8, 1024, 24000, 2), (6, 4, 512, 5000, 0), (4, 8, 512, 7000, 3),

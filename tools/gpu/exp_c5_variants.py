@@ -1,6 +1,6 @@
 """C5 (200 rooms x 8 x 8, 1024-pt, 2 iterations) on ONE batch under several kernel routes: ms per step, stage times, and the error of sampled
 rooms against the float64 oracle (computed once, in worker processes, while the GPU runs the variants).  Test / measurement tooling.
-Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [sample=0,100,199 | spread:N] [variants=room_sub:cov1_mode:cov_chunks:wide,...  wide: -1 = disco_apply + disco_istft, 0 = one-pass filter + iSTFT, n > 0 = that with n frame pairs per run] [sample=0,100,199]"""
+Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [sample=0,100,199 | spread:N] [variants=_:_:cov_chunks:wide,... (the first two fields named round 4's room_sub / cov1_mode options, removed in round 5)  wide: -1 = disco_apply + disco_istft, 0 = one-pass filter + iSTFT, n > 0 = that with n frame pairs per run] [sample=0,100,199]"""
 import json
 import os
 import sys
@@ -61,8 +61,6 @@ def main():
     for rs, cs, ch, nf in variants:
         name = f'room_sub={rs},cov1_mode={cs},cov_chunks={ch},wide={nf}'
         eng.set_option('fuse_wide_istft', 0 if nf < 0 else 1)
-        eng.set_option('room_sub', rs)
-        eng.set_option('cov1_mode', cs)
         eng.set_tuning(0, ch, 0, max(nf, 0))
         if eng.workspace_bytes() > ws.numel():
             ws = torch.empty(eng.workspace_bytes(), dtype=torch.uint8, device=dev)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 4, FINAL-state pass on the committed sources: GPU suite, the plain bench line, kernel stats + HBM counters (+ calibration) of
-# C3 / C5 / C2 / C2x4000, SQ / LDS counters of C3 / C5, side lines (overlap off, node-sharded, online every 8).   Usage: r4_final.sh <tag>
-TAG=${1:-r04_m}
+# FINAL-state pass of a round on the committed sources (round 4: r4_final.sh): GPU suite, the plain bench line, kernel stats + HBM counters (+ calibration) of
+# C3 / C5 / C2 / C2x4000, SQ / LDS counters of C3 / C5, side lines (overlap off, node-sharded, online every 8).   Usage: final_pass.sh <tag>
+TAG=${1:-r05_zz}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 mkdir -p gpurun_out
 T0=$(date +%s)
