@@ -57,12 +57,12 @@ CONFIGS = {
 EXTRAS = {
     # (the launch-bound C2 first, right behind the headline: a 0.9 ms step does not survive the host being shared with the oracle
     # workers of a wide-shape workload -- 2.8 instead of 0.87 ms behind C5's three 8 x 8 rooms)
-    'C2': (dict(CONFIGS['C2']), 30, 3, 4),
+    'C2': (dict(CONFIGS['C2'], also_graph=True), 30, 3, 4),
     'C2x4000': (dict(CONFIGS['C2'], rooms=4000), 5, 2, 4),
+    'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 3),
     'C5': (dict(CONFIGS['C5']), 5, 2, 8),       # round 5: 8 of the 200 rooms (an 8 x 8 room costs the oracle ~11 s on one core)
     'C4': (dict(CONFIGS['C4']), 3, 1, 4),
     'C4_bf16': (dict(CONFIGS['C4'], dnn_dtype='bf16'), 3, 1, 2),      # the networks' convolutions / GEMMs on bf16 operands (explicit switch)
-    'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 3),
 }
 
 
@@ -444,11 +444,13 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
         torch.cuda.synchronize()
 
     eager_step = step
-    if args.graph and headline:
+
+    def capture_graph():
+        """The whole step (mask + path: a fixed launch sequence once the context has reserved its blocks) as ONE hipGraph -> its replay."""
         if mask_kind != 'oracle' or node_sharded or online_every:
-            raise SystemExit('--graph captures the room-sharded batch path with oracle masks')
+            raise SystemExit('a graph captures the room-sharded batch path with oracle masks')
         eng.reserve(0)
-        step()                              # nothing is left to allocate inside the captured calls
+        eager_step()                        # nothing is left to allocate inside the captured calls
         torch.cuda.synchronize()
         side = torch.cuda.Stream(device=dev)
         hip_graph = torch.cuda.CUDAGraph()
@@ -462,7 +464,10 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                 eng._chk(lib.disco_tango_enhance(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), out.data_ptr(),
                                                  None, None, ws.data_ptr(), ws.numel(), h))
         torch.cuda.synchronize()
-        step = hip_graph.replay             # replays on the current (null) stream, the one the barriers drain
+        return hip_graph.replay             # replays on the current (null) stream, the one the barriers drain
+
+    if args.graph and headline:
+        step = capture_graph()
 
     if args.pmc_calibrate and headline:
         src = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
@@ -485,6 +490,26 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
         value, dt = dd.whole_job_throughput(units_per_step * steps, dt_local, world, device=env['cdev'])
     else:
         value, dt = units_per_step * steps / dt_local, dt_local       # merged over the ranks at the end (merge_extras)
+    graph_res = None
+    if w.get('also_graph') and not (args.graph and headline):
+        # launch-bound small batches (C2 at 256 rooms: four launches of 0.05-0.35 ms): the same step as one hipGraph replay, reported BESIDE
+        # the eager figure (which stays the workload's ms_per_step)
+        try:
+            replay = capture_graph()
+            for _ in range(warmup):
+                replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(steps):
+                replay()
+            torch.cuda.synchronize()
+            dtg = (time.perf_counter() - tg) / steps
+            graph_res = {'launch': 'one hipGraph replay per step', 'ms_per_step': round(1e3 * dtg, 4), 'x_realtime': round((Ls / 16000.0) / dtg, 1),
+                         'value': units_per_step / dtg,
+                         'pipeline_frac': round(units_per_step / dtg * b_alg(M, K, F, H, iters) / HBM_PEAK, 4)}
+            del replay
+        except Exception as e:
+            graph_res = {'error': repr(e)}
     finite = bool(torch.isfinite(out).all())
     gather_ms = [a_.elapsed_time(b_) for a_, b_ in gather_events[-steps * iters:]] if gather_events else []
     ms_per_step = 1e3 * dt / steps
@@ -602,6 +627,24 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
             if online_every > 0:
                 roofline['note'] = ('the online kernels re-solve a P x P GEVD per (bin, frame): float64-issue-bound, not HBM-bound; the '
                                     'fraction says how far they are from the streaming bound of their inputs')
+                # the bound that applies: VALU issue.  SQ_INSTS_VALU of the dominant online kernel (profiles/pmc_alu_<name>.json, taken with
+                # tools/gpu/pmc_alu.sh on these sources) against the issue slots of its launch: 1024 SIMDs x 2.4 GHz, one wave64
+                # instruction per 4 cycles (float32 / packed) or 8 (float64 multiply-adds: half rate) -- the truth lies between the two
+                afile = os.path.join(REPO, 'profiles', f'pmc_alu_{name}.json')
+                if os.path.exists(afile):
+                    try:
+                        aj = json.load(open(afile))
+                        kk = [k_ for k_ in aj if 'k_online_mwf' in k_ and f'<{M + K - 1},' in k_]
+                        if kk:
+                            insts = aj[kk[0]]['SQ_INSTS_VALU']['per_dispatch']
+                            slots = 1024 * 2.4e9 * (launch_ms * 1e-3)
+                            roofline['valu_issue'] = {'kernel': kk[0][:60], 'valu_insts_per_launch': insts,
+                                                      'frac_of_issue_slots_at_4_cycles': round(insts * 4 / slots, 3),
+                                                      'frac_of_issue_slots_at_8_cycles': round(insts * 8 / slots, 3),
+                                                      'stale': aj.get('_csrc_digest') != csrc_digest(),
+                                                      'what': 'SQ_INSTS_VALU x cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x launch time)'}
+                    except Exception:
+                        pass
             if traffic_note:
                 roofline['traffic_note'] = traffic_note
             elif traffic is not None and traffic < 0.9 * launch_bytes:
@@ -654,6 +697,8 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
     }
     if stream:
         res['stream'] = stream
+    if graph_res:
+        res['graph'] = graph_res
     if exchange:
         res['exchange'] = exchange
     if mask_error:
@@ -753,9 +798,11 @@ def summary_rows(head_name, head, head_parity, extras):
         out = [round(r['ms_per_step'], 3), round(r['x_realtime'], 1), (rf.get('pipeline') or {}).get('frac'), kern, rf.get('frac'), tr,
                None if ps is None else float('%.3g' % ps.get('worst_rel_all_ranks', float('nan')))]
         if 'stream' in r:       # the streaming entry point: x real-time at chunks of 1 / 4 / 16 hops
-            out.append({k: v.get('x_realtime') for k, v in r['stream'].get('chunks', {}).items()})
+            out.append({'stream_x_realtime_by_hops': {k: v.get('x_realtime') for k, v in r['stream'].get('chunks', {}).items()}})
+        if 'graph' in r:        # the same step as one hipGraph replay: [ms_per_step, pipeline_frac]
+            out.append({'hipgraph': [r['graph'].get('ms_per_step'), r['graph'].get('pipeline_frac')]})
         return out
-    rows = {'_cols': 'ms_per_step, x_realtime, pipeline_frac, dominant_kernel, dominant_frac_of_peak, traffic/alg_bytes, parity_worst_rel[, stream x_realtime by hops]',
+    rows = {'_cols': 'ms_per_step, x_realtime, pipeline_frac, dominant_kernel, dominant_frac_of_peak, traffic/alg_bytes, parity_worst_rel[, {stream x_realtime by chunk hops}][, {hipgraph: [ms_per_step, pipeline_frac]}]',
             head_name: row(head, head_parity)}
     for nm, r in extras.items():
         rows[nm] = row(r, r.get('parity_sample')) if 'error' not in r else 'error'
@@ -886,8 +933,9 @@ def main(argv=None):
             'config': head['config'],
             'roofline': head['roofline'], 'cpu_baseline': cpu, 'parity_sample': parity, 'stages': head['stages'],
         }
-        if 'exchange' in head:
-            line['exchange'] = head['exchange']
+        for extra_key in ('exchange', 'stream', 'graph'):
+            if extra_key in head:
+                line[extra_key] = head[extra_key]
         if args.extra_names:
             line['configs'] = extras
         # LAST key, < 1.5 KB: the five numbers of every workload where a record that keeps only the tail of the line still has them

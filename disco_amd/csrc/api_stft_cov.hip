@@ -51,7 +51,7 @@ int stft_cov_chunks(const disco_ctx* ctx, int* runw_out) {
 // store = false (internal, single-node path): the spectra are not written (X may be NULL); only for shapes the fused kernel takes
 int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco_c32* X, int* chunks_out, disco_stream s, bool store) {
     if (!y || !mask_z || (store && !X)) return fail(ctx, DISCO_E_ARG, "disco_stft_cov_fused: null argument");
-    if (sharded(ctx)) return fail(ctx, DISCO_E_UNSUPPORTED, "fused kernels need every node of a room on this GPU (node shard active)");
+    // (works on a node shard too: nothing in this pass looks beyond one node -- X, masks and partial sums then hold the shard's Kl nodes per room)
     const disco_cfg& c = ctx->cfg;
     const int M = c.mics;
     if (M > 8) return fail(ctx, DISCO_E_UNSUPPORTED, "disco_stft_cov_fused: more than 8 mics per node");
@@ -61,11 +61,11 @@ int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco
         // The 144 accumulator registers per bin force 12 waves and 100 KiB of LDS into one workgroup, i.e. ONE workgroup and four
         // transform waves per CU where k_stft_pairs keeps eight; the transforms set the pace.  Dropped, see DESIGN.md.)
         if (!store) return fail(ctx, DISCO_E_UNSUPPORTED, "stft_cov without store: shape needs the staged kernels");
-        int rc0 = STAGE(ctx, s, "stft", disco_stft(ctx, y, (int64_t)c.rooms * c.nodes, M, X, s));
+        int rc0 = STAGE(ctx, s, "stft", disco_stft(ctx, y, (int64_t)c.rooms * ctx->Kl, M, X, s));
         if (rc0) return rc0;
         return STAGE(ctx, s, "cov1", cov_partials(ctx, X, mask_z, nullptr, nullptr, 0, M, chunks_out, s));
     }
-    const long long G = (long long)c.rooms * c.nodes;
+    const long long G = (long long)c.rooms * ctx->Kl;
     int runw = 0;
     const int chunks = stft_cov_chunks(ctx, &runw);
     const int NP = M * (M + 1) / 2;
@@ -93,7 +93,7 @@ int stft_cov_partials(disco_ctx* ctx, const float* y, const float* mask_z, disco
     ctx->loc_M = M;
     ctx->loc_X = X;
     ctx->loc_mask = mask_z;
-    if (!store) ctx->loc_M = 0;       // nothing to pair these partial sums with later
+    if (!store || sharded(ctx)) ctx->loc_M = 0;       // nothing to pair these partial sums with later (a shard runs the staged step 2)
     return check_launch(ctx, "k_stft_cov");
 }
 

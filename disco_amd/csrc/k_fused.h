@@ -731,13 +731,31 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * (N / 128 + N / 256), 1) voi
 // pass is pure wave-local arithmetic (M/2 forward transforms per frame, one inverse per frame pair, no workgroup barrier).
 // A wave owns `pairs` frame pairs of one node (2 pairs - 1 hop segments; consecutive waves overlap by one frame, as in
 // k_step2_apply_istft); the half-window shared by consecutive frames is recycled in registers as in k_stft.
+// DISCO_SAI_EXP (default 0): TIMING-ONLY builds of k_stft_apply_istft -- bit 0 no forward transforms (the filter takes the windowed samples),
+// 1 no inverse transform, 2 no output stores, 3 no sample loads; results are garbage (profiles/r05_h_stft_parts.txt)
+#ifndef DISCO_SAI_EXP
+#define DISCO_SAI_EXP 0
+#endif
+// DISCO_SAI_TAPS_LDS (default 1): the node's filter -- (N/2 + 1) x M taps, 40 registers per lane for a 512-point, 4-mic node -- sits in a
+// wave-private LDS block [pair][bin] (one conflict-free ds_read_b128 per channel pair and bin) instead of registers: 198 -> under 168 registers,
+// THREE waves per SIMD instead of two.  The pass is bound by the latency of its loads and of its transforms at two waves per SIMD
+// (profiles/r05_h_stft_parts.txt), so the third wave is what pays.
+#ifndef DISCO_SAI_TAPS_LDS
+#define DISCO_SAI_TAPS_LDS 1
+#endif
+template <int N, int CHP>
+struct alignas(16) StftApplyShared {
+    c32 buf[STFT_WAVES][fft_buf_len<N>()];
+    float4 taps[DISCO_SAI_TAPS_LDS ? STFT_WAVES : 1][DISCO_SAI_TAPS_LDS ? CHP : 1][DISCO_SAI_TAPS_LDS ? N / 2 + 1 : 1];
+};
 template <int N, int M>
-__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1) void k_stft_apply_istft(const float* __restrict__ x, const c32* __restrict__ wf,
+__global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, M <= 4 ? (DISCO_SAI_TAPS_LDS ? 3 : 2) : 1) void k_stft_apply_istft(const float* __restrict__ x, const c32* __restrict__ wf,
                                                                                     float* __restrict__ out, const float* __restrict__ win,
                                                                                     const c32* __restrict__ tw, int L, int T, int pad_mode,
                                                                                     int runs_per_node, int pairs, long long n_witems) {
     constexpr int E = FftPlan<N>::E, F = N / 2 + 1, H = N / 2, EH = E / 2, NJ = EH + 1, CHP = (M + 1) / 2;
-    __shared__ StftShared<N> sh;
+    constexpr bool TL = DISCO_SAI_TAPS_LDS != 0;
+    __shared__ StftApplyShared<N, CHP> sh;
     const int wave = wave_id(), lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * STFT_WAVES + wave;
     if (item >= n_witems) return;                  // no block-level synchronisation anywhere below
@@ -748,16 +766,27 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1)
     wtw.init(tw, lane);
     float w[E];
     load_window<N>(w, win, lane);
-    c32 wg[NJ][M];                                  // the node's filter at this lane's bins (f = lane + 64 j; lane 0: Nyquist too)
+    // the node's filter at this lane's bins (f = lane + 64 j; lane 0: Nyquist too), at half weight: the forward transforms below run on
+    // the full-weight window (it is the synthesis window too), so the untangled spectra are 2 X (fft.h: rfft_pair_untangle leaves the
+    // division by two to its caller); exact
+    c32 wg[TL ? 1 : NJ][TL ? 1 : M];
+    if constexpr (TL) {
+        for (int f = lane; f < F; f += 64)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int f = (j < EH) ? lane + 64 * j : F - 1;
+            for (int p = 0; p < CHP; ++p) {
+                const c32 a = wf[(g * F + f) * M + 2 * p], b = (2 * p + 1 < M) ? wf[(g * F + f) * M + 2 * p + 1] : make_float2(0.f, 0.f);
+                sh.taps[wave][p][f] = make_float4(0.5f * a.x, 0.5f * a.y, 0.5f * b.x, 0.5f * b.y);
+            }
+        DISCO_LDS_RAW();                             // wave-private block: the wave's own writes are in place
+    } else {
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            // at half weight: the forward transforms below run on the full-weight window (it is the synthesis window too), so
-            // the untangled spectra are 2 X (fft.h: rfft_pair_untangle leaves the division by two to its caller); exact
-            const c32 wv = wf[(g * F + f) * M + i];
-            wg[j][i] = make_float2(0.5f * wv.x, 0.5f * wv.y);
+        for (int j = 0; j < NJ; ++j) {
+            const int f = (j < EH) ? lane + 64 * j : F - 1;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const c32 wv = wf[(g * F + f) * M + i];
+                wg[j][i] = make_float2(0.5f * wv.x, 0.5f * wv.y);
+            }
         }
     }
     const float* xa[CHP];
@@ -784,18 +813,34 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1)
             const int t = tA + fr;
             c32 nxt[CHP][EH];                        // the next frame's new half-window, in flight under this frame's transforms
 #pragma unroll
-            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], min(t + 1, T - 1), L, pad_mode, lane);
+            for (int p = 0; p < CHP; ++p) {
+                if (DISCO_SAI_EXP & 8) {
+#pragma unroll
+                    for (int e = 0; e < EH; ++e) nxt[p][e] = make_float2(0.25f * e + lane, 1.f);
+                } else {
+                    load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], min(t + 1, T - 1), L, pad_mode, lane);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) yf[fr][j] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int p = 0; p < CHP; ++p) {
                 c32 v[E];
                 apply_window<N>(v, raw[p], w, 2 * p + 1 < M);
-                fft_wave<N>(v, wtw, buf, lane);
-                rfft_pair_untangle<N>(v, buf, lane, [&](int j, int, c32 a, c32 b) {
+                if (!(DISCO_SAI_EXP & 1)) fft_wave<N>(v, wtw, buf, lane);
+                rfft_pair_untangle<N>(v, buf, lane, [&](int j, int f, c32 a, c32 b) {
                     // yf += conj(w_2p) X_2p + conj(w_2p+1) X_2p+1
-                    c32 acc = cfma_conj(wg[j][2 * p], a, yf[fr][j]);
-                    if (2 * p + 1 < M) acc = cfma_conj(wg[j][2 * p + 1], b, acc);
+                    c32 wa, wb;
+                    if constexpr (TL) {
+                        const float4 t4 = sh.taps[wave][p][f];
+                        wa = make_float2(t4.x, t4.y);
+                        wb = make_float2(t4.z, t4.w);
+                    } else {
+                        wa = wg[j][2 * p];
+                        wb = wg[j][2 * p + 1 < M ? 2 * p + 1 : 2 * p];
+                    }
+                    c32 acc = cfma_conj(wa, a, yf[fr][j]);
+                    if (2 * p + 1 < M) acc = cfma_conj(wb, b, acc);
                     yf[fr][j] = acc;
                 });
             }
@@ -816,9 +861,10 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, M <= 4 ? 2 : 1)
         // ---- V = A~ + i B~ (Hermitian extensions of the two filtered frames), conjugated for the inverse-by-forward trick
         c32 v[E];
         irfft_pair_pack<N>(yf[0], yf[1], v, lane);       // cross-lane, no LDS round trip (fft.h)
-        fft_wave<N>(v, wtw, buf, lane);
+        if (!(DISCO_SAI_EXP & 2)) fft_wave<N>(v, wtw, buf, lane);
         // ---- window, overlap-add: segment (tA-1) = carry + A[lo], segment tA = A[hi] + B[lo], carry <- B[hi]
-        ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, L, lane);
+        if (!(DISCO_SAI_EXP & 4)) ola_emit_pair<N>(v, carry, ow, og, win, tA, pr == 0, T, L, lane);
+        else if (v[0].x == 123456.f) og[lane] = v[1].y;     // (keeps the arithmetic alive)
     }
 }
 

@@ -442,7 +442,7 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
     int rp = rd, fp = fd;                               // the item whose last groups were folded in the previous iteration (pending)
     bool pending = false;
     // DISCO_ROOM_EXP (default 0): TIMING-ONLY builds with parts of the loop body removed -- bit 0 the folds, 1 the z formation, 2 the loads,
-    // 3 the barrier; the results are garbage (tools/gpu/mk_variant.sh roomexp1 "-DDISCO_ROOM_EXP=1" api_room_s8; profiles/r04_u_room_parts.txt)
+    // 3 the barrier, 4 the wait for the loads (raw s_barrier); the results are garbage (tools/gpu/mk_variant.sh roomexp1 "-DDISCO_ROOM_EXP=1" api_room_s8; profiles/r04_u_room_parts.txt)
     while (true) {
         if (vi && !(DISCO_ROOM_EXP & 4)) {
             if (ji == 0) issue_taps(ri, fi, ni & 1);    // (the form position left that buffer's item an iteration ago)
@@ -460,8 +460,12 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
         }
         pending = jd == J - 1;
         rp = rd, fp = fd;
+#if DISCO_ROOM_EXP & 16
+        __builtin_amdgcn_s_barrier();                  // (bit 4: the loads are never waited for, raw barrier: is the loop waiting for them?)
+#else
         vm_wait_all();
         if (!(DISCO_ROOM_EXP & 8)) __syncthreads();
+#endif
         if (!vf) break;                                 // the fold position was this workgroup's last iteration
         s0 = (s0 + 2) % D;
         zb0 ^= 2;

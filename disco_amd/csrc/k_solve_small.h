@@ -214,6 +214,13 @@ __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, cons
         for (int q = 0; q < NO; ++q) B.o[q] = ok ? zscale(B.o[q], rt) : make_double2(0.0, 0.0);
     }
     bool done = !ok || P == 1;
+    // SQ32 (round 5): the choice of the start vector and all but the LAST power step on packed float32 as well -- 2 P^2 v_pk_fma_f32 per
+    // step where the float64 form issues 4 P^2 half-rate v_fma_f64.  A power step is self-correcting (its result is the dominant vector
+    // of the matrix it multiplies by, to that multiplication's rounding over the gap of the SQUARED matrix, < 0.01 here), and the closing
+    // float64 step removes the float32 rounding of the steps before it: the vector that enters the back substitution is as accurate as before.
+    constexpr int STEPS32 = (SQ32 && P > 1 && DISCO_POWER_STEPS > 1) ? DISCO_POWER_STEPS - 1 : 0;
+    c32 vf[SQ32 ? P : 1];
+    bool have32 = false;
     if constexpr (SQ32 && P > 1) {
         HermPk<P> Bf;
 #pragma unroll
@@ -233,6 +240,58 @@ __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, cons
                 for (int q = 0; q < NO; ++q) Bf.o[q] = scale_by_half<0>(S.o[q], rr);
             }
             done = done || (1.0f - tau < (float)DISCO_SQUARING_DONE) || !(tau > 0.f);
+        }
+        // the longest column of the kept square and STEPS32 power steps, still in float32 (B comes back to float64 only afterwards: the
+        // two copies never live together)
+        {
+            auto atf = [&](int i, int k) {               // B[i][k] of the float32 half-storage (i, k compile-time after unrolling)
+                if (i == k) return make_float2((i & 1) ? Bf.dp[i / 2].y : Bf.dp[i / 2].x, 0.f);
+                if (i > k) return Bf.o[lo(i, k)];
+                const c32 v = Bf.o[lo(k, i)];
+                return make_float2(v.x, -v.y);
+            };
+            float best = -1.f;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                float nj = 0.f;
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const c32 b = atf(i, j);
+                    nj += b.x * b.x + b.y * b.y;
+                }
+                if (nj > best) {
+                    best = nj;
+#pragma unroll
+                    for (int i = 0; i < P; ++i) vf[i] = atf(i, j);
+                }
+            }
+            have32 = best > 0.f;
+            const float rb = have32 ? rsqrtf(best) : 0.f;
+#pragma unroll
+            for (int i = 0; i < P; ++i) vf[i] = have32 ? make_float2(vf[i].x * rb, vf[i].y * rb) : make_float2(i == 0 ? 1.f : 0.f, 0.f);
+#pragma unroll 1
+            for (int s = 0; s < STEPS32; ++s) {
+                c32 u[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) u[i] = (i & 1) ? scale_by_half<1>(vf[i], Bf.dp[i / 2]) : scale_by_half<0>(vf[i], Bf.dp[i / 2]);
+                // the two halves of every complex multiply-add apart, the sums advancing together (see herm_square_pk)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int k = 0; k < P; ++k)
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+                            if (i == k) continue;
+                            const c32 b = i > k ? Bf.o[lo(i, k)] : Bf.o[lo(k, i)];   // B[i][k] = conj of the stored entry above the diagonal
+                            if (half == 0) u[i] = PkD::cfma_lo(b, vf[k], u[i]);
+                            else if (i > k) u[i] = PkD::cfma_hi(b, vf[k], u[i]);
+                            else u[i] = PkD::cfma_hi_conj(b, vf[k], u[i]);
+                        }
+                if (have32) {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) vf[i] = u[i];
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < P; ++i) B.d[i] = (double)((i & 1) ? Bf.dp[i / 2].y : Bf.dp[i / 2].x);
@@ -277,29 +336,40 @@ __device__ __forceinline__ void gevd_solve_thread_acc(LA load_a, LB load_b, cons
     }
     // ---- B = v0 v0^H: the longest column (ties: lowest index), normalised
     c64 v0[P];
-    double best = -1.0;
+    bool have;
+    if constexpr (SQ32 && P > 1) {
+        have = have32;
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-        double nj = 0.0;
+        for (int i = 0; i < P; ++i) v0[i] = make_double2((double)vf[i].x, (double)vf[i].y);
+    } else {
+        double best = -1.0;
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const c64 b = B.at(i, j);
-            nj += b.x * b.x + b.y * b.y;
+        for (int j = 0; j < P; ++j) {
+            double nj = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const c64 b = B.at(i, j);
+                nj += b.x * b.x + b.y * b.y;
+            }
+            if (nj > best) {
+                best = nj;
+#pragma unroll
+                for (int i = 0; i < P; ++i) v0[i] = B.at(i, j);
+            }
         }
-        if (nj > best) {
-            best = nj;
+        have = best > 0.0;
+        const double rb = have ? rsqrt64(best) : 0.0;
 #pragma unroll
-            for (int i = 0; i < P; ++i) v0[i] = B.at(i, j);
-        }
+        for (int i = 0; i < P; ++i) v0[i] = have ? zscale(v0[i], rb) : make_double2(i == 0 ? 1.0 : 0.0, 0.0);
     }
-    const bool have = best > 0.0;
-    const double rb = have ? rsqrt64(best) : 0.0;
-#pragma unroll
-    for (int i = 0; i < P; ++i) v0[i] = have ? zscale(v0[i], rb) : make_double2(i == 0 ? 1.0 : 0.0, 0.0);
     // ---- power steps v <- B v on the kept square (k_solve.h: DISCO_POWER_STEPS), then unit length
+    // SQ32 (round 5): all but the LAST step on packed float32 as well -- 2 P^2 v_pk_fma_f32 per step where the float64 form issues 4 P^2
+    // half-rate v_fma_f64.  A power step is self-correcting (its result is the dominant vector of the matrix it multiplies by, to that
+    // multiplication's rounding over the gap of the SQUARED matrix, < 0.01 here), and the closing float64 step removes the float32
+    // rounding of the steps before it: the vector that goes into the back substitution is as accurate as before.
     if (P > 1) {
 #pragma unroll 1
-        for (int s = 0; s < DISCO_POWER_STEPS; ++s) {
+        for (int s = STEPS32; s < DISCO_POWER_STEPS; ++s) {
             c64 u[P];
 #pragma unroll
             for (int i = 0; i < P; ++i) {

@@ -460,6 +460,12 @@ struct alignas(16) StftCovShared {
 #ifndef DISCO_ZTILE
 #define DISCO_ZTILE 1
 #endif
+// DISCO_SC_EXP (default 0): TIMING-ONLY builds of k_stft_cov with parts of the frame loop removed -- bit 0 the transforms (window, FFT, tile
+// write), 1 the covariance fold, 2 the X store, 3 the sample and mask loads; results are garbage, only the time counts
+// (tools/gpu/mk_variant.sh scexp<N> "-DDISCO_SC_EXP=<N>" api_stft_cov; profiles/r05_h_stft_parts.txt)
+#ifndef DISCO_SC_EXP
+#define DISCO_SC_EXP 0
+#endif
 // STORE = false: the spectra are reduced into the covariances and dropped (single-node path: the filter pass recomputes them
 // from the samples, k_stft_apply_istft, instead of reading 8 M F bytes per node-frame back)
 template <int N, int M, bool STORE = true>
@@ -530,16 +536,23 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
         for (int ww = 0; ww < STFT_WAVES; ++ww) {
             const int t2 = min(tb + ww * runw + it, T - 1);          // clamped: unconditional loads, used only when valid
 #pragma unroll
-            for (int b = 0; b < BPT; ++b) mv[ww][b] = mg[(long long)t2 * F + tid + 256 * b];
-            mny[ww] = mg[(long long)t2 * F + F - 1];
+            for (int b = 0; b < BPT; ++b) mv[ww][b] = (DISCO_SC_EXP & 8) ? 0.5f : mg[(long long)t2 * F + tid + 256 * b];
+            mny[ww] = (DISCO_SC_EXP & 8) ? 0.5f : mg[(long long)t2 * F + F - 1];
         }
         c32 nxt[CHP][EH];
         {
             const int tn = min(t + 1, T - 1);              // clamped: harmless reload at the end of a run
 #pragma unroll
-            for (int p = 0; p < CHP; ++p) load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], tn, L, pad_mode, lane);
+            for (int p = 0; p < CHP; ++p) {
+                if (DISCO_SC_EXP & 8) {
+#pragma unroll
+                    for (int e = 0; e < EH; ++e) nxt[p][e] = make_float2(0.25f * e + lane, 1.f);
+                } else {
+                    load_frame_slots<N, EH, E>(nxt[p], xa[p], xb[p], tn, L, pad_mode, lane);
+                }
+            }
         }
-        if (valid) {
+        if (valid && !(DISCO_SC_EXP & 1)) {
 #pragma unroll
             for (int p = 0; p < CHP; ++p) {
                 c32 v[E];
@@ -574,7 +587,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
             const int t2 = tb + ww * runw + it;
             if (t2 < min(T, tb + (ww + 1) * runw)) {          // workgroup-uniform
                 c32* Xo = STORE ? X + ((g * T + t2) * (long long)F) * M : nullptr;
-                if (STORE && (M & 1) == 0) {
+                if (STORE && (M & 1) == 0 && !(DISCO_SC_EXP & 4)) {
                     // even M: the tile row IS the X row (F*M complex, contiguous) -> straight 16-B-per-lane copy, every
                     // wave store covers 1 KiB of consecutive bytes (a per-bin store would touch each 128-B line twice)
                     // The rows are 8 * M * F bytes long (8224 for M = 4), so they start 0 / 32 / 64 / 96 bytes into a 128-byte line: the
@@ -619,7 +632,8 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * STFT_WAVES, (N == 512 && M 
                         for (int i = 0; i < M; ++i) Xo[(long long)f * M + i] = xv[i];
                     }
                     const float m = mv[ww][b], mc = 1.f - m;
-                    cov_accumulate_shared<M>(xv, m * m, mc * mc, acc_s[b], acc_n[b]);
+                    if (!(DISCO_SC_EXP & 2)) cov_accumulate_shared<M>(xv, m * m, mc * mc, acc_s[b], acc_n[b]);
+                    else acc_s[b][0].x += xv[0].x * m;           // (keeps the tile reads alive)
                 }
                 // Nyquist bin
                 if (STORE && (M & 1) != 0 && tid < M) {

@@ -77,6 +77,7 @@ class Engine:
         if rc != 0:
             raise DiscoError(f'disco_create failed ({rc}): {self.lib.disco_last_error(None).decode()}')
         self.R, self.K, self.M, self.Lsamp = rooms, nodes, mics, length
+        self.n_fft, self.device, self.pad_mode = n_fft, device, pad_mode
         self.Kl, self.k0 = nodes, 0                     # node shard held by this engine (all nodes by default)
         self.zblk = nodes                               # layout of exchanged-signal arguments (set_z_blocks)
         self.T = self.lib.disco_n_frames(self.ctx)
@@ -437,14 +438,22 @@ class Engine:
         self._chk(self.lib.disco_noise_residual(self.ctx, px, pz, zn.ptr, self.stream))
         return zn
 
-    def stft_cov_fused(self, y, mask_z):
-        """y (R,K,M,L), mask_z (R,K,T,F) -> X (R,K,T,F,M), Rss, Rnn (R,K,F,M,M) in one pass over the samples."""
+    def stft_cov_fused(self, y, mask_z, X_out=None, want_cov=True):
+        """y (R,Kl,M,L), mask_z (R,Kl,T,F) -> X (R,Kl,T,F,M), Rss, Rnn (R,Kl,F,M,M) in one pass over the samples (Kl = K unless a node
+        shard is active).  want_cov=False: the covariances stay in the context as partial sums for gevd_mwf_r1_pending (Rss = Rnn = None).
+        X_out: caller-owned device array for the spectra."""
         py, ky = self.to_device(y, np.float32)
         pm, km = self.to_device(mask_z, np.float32)
-        X = self.empty((self.R, self.K, self.T, self.F, self.M), np.complex64)
-        Rss = self.empty((self.R, self.K, self.F, self.M, self.M), np.complex64)
-        Rnn = self.empty((self.R, self.K, self.F, self.M, self.M), np.complex64)
-        self._chk(self.lib.disco_stft_cov_fused(self.ctx, py, pm, X.ptr, Rss.ptr, Rnn.ptr, self.stream))
+        Kl = self.Kl
+        if X_out is None:
+            X = self.empty((self.R, Kl, self.T, self.F, self.M), np.complex64)
+            px = X.ptr
+        else:
+            X = X_out
+            px, kx = self.to_device(X_out, np.complex64)
+        Rss = self.empty((self.R, Kl, self.F, self.M, self.M), np.complex64) if want_cov else None
+        Rnn = self.empty((self.R, Kl, self.F, self.M, self.M), np.complex64) if want_cov else None
+        self._chk(self.lib.disco_stft_cov_fused(self.ctx, py, pm, px, Rss.ptr if want_cov else None, Rnn.ptr if want_cov else None, self.stream))
         return X, Rss, Rnn
 
     def step2_cov_fused(self, X, mask_w, w_loc, want_z=True):

@@ -21,26 +21,32 @@ def node_range(rank, world, K):
     return rank * kl, kl
 
 
-def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=None, out=None, z_shape=None, X_out=None):
-    """Shared data flow.  z_out / yf_out: caller-owned device arrays for this rank's z / yf (or None: DevBuf);
-    gather(z_local) -> z of ALL nodes (R, K, T, F), numpy or device array."""
+def _steps(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather_begin, gather_end, yf_out=None, out=None, z_shape=None, X_out=None):
+    """The data flow of one (half-)batch as a GENERATOR: it yields right after every all-gather has been STARTED (gather_begin(z_local) ->
+    handle) and finishes it (gather_end(handle) -> z of ALL nodes) when resumed -- so a driver that holds two half-batches can run one
+    half's local kernels while the other half's exchange is on the links (tango_enhance_node_sharded_torch).  Returns, through
+    StopIteration.value, (out, yf, z_all of the last exchange).
+    z_out / yf_out / X_out: caller-owned device arrays for this rank's z / yf / spectra (or None: DevBuf)."""
     if iters < 1:
         raise ValueError('iters must be >= 1')
     R, Kl, M = eng.R, eng.Kl, eng.M
     if hasattr(y_local, 'data_ptr'):
-        y_sig = y_local.reshape(R * Kl, M, eng.Lsamp)
-        assert y_sig.is_contiguous()
+        assert y_local.is_contiguous()
     else:
-        y_sig = np.ascontiguousarray(y_local, dtype=np.float32).reshape(R * Kl, M, eng.Lsamp)
-    X = eng.stft(y_sig, out=X_out).reshape(R, Kl, eng.T, eng.F, M)
-    # step 1, local (tango.py:326-376)
-    eng.cov_masked(X, mask_z_local, Rss_out=False)
+        y_local = np.ascontiguousarray(y_local, dtype=np.float32)
+    # step 1, local (tango.py:326-376): STFT + local statistics in ONE pass over the samples (k_stft_cov works node by node, so it serves a
+    # shard as it serves a whole room; round 4 ran disco_stft + disco_cov_masked here: two passes and the staged covariance kernel)
+    X, _, _ = eng.stft_cov_fused(y_local, mask_z_local, X_out=X_out, want_cov=False)
+    if hasattr(X, 'reshape'):
+        X = X.reshape(R, Kl, eng.T, eng.F, M)
     w_loc, _ = eng.gevd_mwf_r1_pending(M)
     z_all = w_glo = None
     for it in range(iters):
         z_loc = eng.apply(X, w_loc, out=z_out)
         # the exchange (tango.py:378-386): one all-gather of the compressed signals
-        z_all = gather(z_loc)
+        handle = gather_begin(z_loc)
+        yield
+        z_all = gather_end(handle)
         assert tuple(z_all.shape) == (z_shape or (R, eng.K, eng.T, eng.F))
         # step 2, local again (tango.py:411-450)
         if eng.K > 1:
@@ -56,6 +62,20 @@ def _run(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather, yf_out=
     return out, yf, z_all
 
 
+def _drive(gens):
+    """Round-robin over the generators of _steps until all are done -> their return values, in order."""
+    res = [None] * len(gens)
+    live = list(range(len(gens)))
+    while live:
+        for i in list(live):
+            try:
+                next(gens[i])
+            except StopIteration as fin:
+                res[i] = fin.value
+                live.remove(i)
+    return res
+
+
 def tango_enhance_node_sharded(eng, y_local, mask_z_local, mask_w_local, all_gather_z, iters=1):
     """eng: Engine(rooms=R, nodes=K, ...) on which `set_node_shard(k0, Kl)` has been called.
     y_local (R, Kl, M, L), masks (R, Kl, T, F) -- this rank's nodes.
@@ -63,17 +83,41 @@ def tango_enhance_node_sharded(eng, y_local, mask_z_local, mask_w_local, all_gat
     (R, K, T, F), in global node order (torch.distributed all_gather over RCCL in production, gloo in the CPU test).
     iters > 1: the iterated scheme of disco_tango_enhance_iterated, one all-gather per iteration.
     Returns (out_local (R, Kl, L) DevBuf, yf_local DevBuf, z_all numpy -- the LAST exchanged z)."""
-    def gather(z_loc):
+    def begin(z_loc):
         return np.ascontiguousarray(all_gather_z(z_loc.numpy()), dtype=np.complex64)
-    return _run(eng, y_local, mask_z_local, mask_w_local, iters, None, gather)
+    return _drive([_steps(eng, y_local, mask_z_local, mask_w_local, iters, None, begin, lambda h: h)])[0]
 
 
-def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, group=None, iters=1, out=None, gather_events=None):
+def _half_engines(eng, n_halves):
+    """Child engines of `eng` for the rooms [0, R0) and [R0, R) (same shape, options, tuning-free geometry and node shard), kept on the parent."""
+    from .engine import Engine
+    key = (n_halves, eng.k0, eng.Kl)
+    cache = getattr(eng, '_ns_halves', None)
+    if cache is None or cache[0] != key:
+        R0 = (eng.R + 1) // 2
+        kids = []
+        for rooms in (R0, eng.R - R0):
+            kid = Engine(rooms=rooms, nodes=eng.K, mics=eng.M, length=eng.Lsamp, n_fft=eng.n_fft, device=eng.device, lib=eng.lib,
+                         pad_mode=eng.pad_mode)
+            kid.set_node_shard(eng.k0, eng.Kl)
+            kids.append(kid)
+        eng._ns_halves = cache = (key, kids)
+    return cache[1]
+
+
+def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, group=None, iters=1, out=None, gather_events=None, overlap=None):
     """Device-resident variant: y_local (R, Kl, M, L) float32 and the masks (R, Kl, T, F) float32 are contiguous torch tensors
     on this rank's GPU; z stays on the GPUs and is all-gathered by torch.distributed over `group` (RCCL over xGMI; every
     rank holds the same number of nodes, rank order == node order).  The library launches on the null stream, which is
     torch's default stream, so the collective is ordered after the kernels that produce z and before those that read it.
     Per all-gather a rank sends R * Kl * T * F * 8 bytes to each peer (1.29 MB per (room, node) at C3).
+
+    overlap (default: True when the group has more than one rank and the batch at least 2 rooms): the batch runs as TWO HALF-BATCHES
+    whose all-gathers are started asynchronously -- half A's exchange is on the links while half B's step 1 (or step 2) runs, and vice
+    versa: at C3 an exchange is ~1.3 GB per peer link and gather (>= 8 ms at 153 GB/s per xGMI link) against ~6 ms of local kernels
+    per 250 rooms, so without the overlap the links and the CUs would take turns idling.  Results are those of the plain call, room by
+    room (rooms are independent; every kernel's per-room arithmetic is the same in a half batch).
+
     out: optional (R, Kl, L) float32 torch tensor to receive the time signals.  gather_events: optional list that receives a
     (start, stop) pair of torch.cuda events per all-gather (recorded on the current stream; the caller synchronises and reads).
     Returns (out_local (R, Kl, L) DevBuf or `out`, yf_local torch (R, Kl, T, F) complex64, z_all torch (R, K, T, F) complex64)."""
@@ -84,40 +128,79 @@ def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, g
     if Kl * W != K:
         raise ValueError(f'{W} ranks x {Kl} nodes per rank != {K} nodes')
     dev = y_local.device
-    shape = (R, Kl, eng.T, eng.F)
-    z_loc = torch.empty(shape, dtype=torch.complex64, device=dev)
-    yf = torch.empty(shape, dtype=torch.complex64, device=dev)
-    parts = torch.empty((W,) + shape, dtype=torch.complex64, device=dev)
-    # the spectra as a torch tensor too: torch's caching allocator hands the same block back every call, while a DevBuf is a
-    # hipMalloc + hipFree of several GB per call (measured: 100 ms of a 113 ms step at 250 rooms)
-    X = torch.empty((R * Kl, eng.T, eng.F, eng.M), dtype=torch.complex64, device=dev)
-
+    if overlap is None:
+        overlap = W > 1 and R >= 2
     timed = gather_events is not None and dev.type == 'cuda'
+    gloo_staged = dist.get_backend(group) == 'gloo' and dev.type == 'cuda'
 
-    def gather(z):
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        # concatenated-along-dim-0 form: the one every backend (RCCL, gloo) accepts
-        if z.is_cuda and dist.get_backend(group) == 'gloo':
-            # functional tests of the N-rank data flow on a box with ONE GPU (bench.py --dist-backend gloo --single-device): gloo gathers
-            # host tensors only, so this path -- never the measured one -- stages the blocks through the host
-            host = torch.empty((W * R, Kl, eng.T, eng.F, 2), dtype=torch.float32)
-            dist.all_gather_into_tensor(host, torch.view_as_real(z).cpu(), group=group)
-            torch.view_as_real(parts).view(W * R, Kl, eng.T, eng.F, 2).copy_(host)
-        else:
-            dist.all_gather_into_tensor(torch.view_as_real(parts).view(W * R, Kl, eng.T, eng.F, 2), torch.view_as_real(z), group=group)
-        if timed:
-            e1.record()
-            gather_events.append((e0, e1))
-        return parts              # rank-major [W][R][Kl][T][F]: consumed as it arrives (Engine.set_z_blocks), no transposing copy
-    eng.set_z_blocks(Kl)
+    def make_gather(rooms, parts):
+        def begin(z):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            # concatenated-along-dim-0 form: the one every backend (RCCL, gloo) accepts
+            if gloo_staged:
+                # functional tests of the N-rank data flow on a box with ONE GPU (bench.py --dist-backend gloo --single-device): gloo gathers
+                # host tensors only, so this path -- never the measured one -- stages the blocks through the host
+                host = torch.empty((W * rooms, Kl, eng.T, eng.F, 2), dtype=torch.float32)
+                dist.all_gather_into_tensor(host, torch.view_as_real(z).cpu(), group=group)
+                torch.view_as_real(parts).view(W * rooms, Kl, eng.T, eng.F, 2).copy_(host)
+                work = None
+            else:
+                work = dist.all_gather_into_tensor(torch.view_as_real(parts).view(W * rooms, Kl, eng.T, eng.F, 2), torch.view_as_real(z),
+                                                   group=group, async_op=bool(overlap))
+            return (work, (e0, e1) if timed else None)
+
+        def end(handle):
+            work, evs = handle
+            if work is not None:
+                work.wait()           # the current (null) stream waits for the collective; the host does not
+            if evs is not None:
+                evs[1].record()
+                gather_events.append(evs)
+            return parts              # rank-major [W][rooms][Kl][T][F]: consumed as it arrives (Engine.set_z_blocks), no transposing copy
+        return begin, end
+
+    # the spectra as torch tensors too: torch's caching allocator hands the same block back every call, while a DevBuf is a
+    # hipMalloc + hipFree of several GB per call (measured: 100 ms of a 113 ms step at 250 rooms)
+    def buffers(rooms):
+        shape = (rooms, Kl, eng.T, eng.F)
+        return dict(z=torch.empty(shape, dtype=torch.complex64, device=dev), yf=torch.empty(shape, dtype=torch.complex64, device=dev),
+                    parts=torch.empty((W,) + shape, dtype=torch.complex64, device=dev),
+                    X=torch.empty((rooms * Kl, eng.T, eng.F, eng.M), dtype=torch.complex64, device=dev))
+
+    if out is None:
+        out = torch.empty((R, Kl, eng.Lsamp), dtype=torch.float32, device=dev)
+    if not overlap:
+        b = buffers(R)
+        begin, end = make_gather(R, b['parts'])
+        eng.set_z_blocks(Kl)
+        try:
+            _, yf_, zrm = _drive([_steps(eng, y_local, mask_z_local, mask_w_local, iters, b['z'], begin, end, yf_out=b['yf'], out=out,
+                                         z_shape=(W, R, Kl, eng.T, eng.F), X_out=b['X'])])[0]
+        finally:
+            eng.set_z_blocks(K)
+        return out, yf_, zrm.permute(1, 0, 2, 3, 4).reshape(R, K, eng.T, eng.F)
+    kids = _half_engines(eng, 2)
+    R0 = kids[0].R
+    gens, bufs = [], []
+    for h, kid in enumerate(kids):
+        r0, r1 = (0, R0) if h == 0 else (R0, R)
+        b = buffers(r1 - r0)
+        bufs.append(b)
+        begin, end = make_gather(r1 - r0, b['parts'])
+        kid.set_z_blocks(Kl)
+        gens.append(_steps(kid, y_local[r0:r1], mask_z_local[r0:r1], mask_w_local[r0:r1], iters, b['z'], begin, end, yf_out=b['yf'],
+                           out=out[r0:r1], z_shape=(W, r1 - r0, Kl, eng.T, eng.F), X_out=b['X']))
     try:
-        out_, yf_, z_rank_major = _run(eng, y_local, mask_z_local, mask_w_local, iters, z_loc, gather, yf_out=yf, out=out, z_shape=(W, R, Kl, eng.T, eng.F), X_out=X)
+        res = _drive(gens)
     finally:
-        eng.set_z_blocks(K)
+        for kid in kids:
+            kid.set_z_blocks(K)
+    yf_ = torch.cat([bufs[0]['yf'], bufs[1]['yf']], dim=0)
+    z_all = torch.cat([r_[2].permute(1, 0, 2, 3, 4).reshape(-1, K, eng.T, eng.F) for r_ in res], dim=0)
     # the documented return value keeps global node order (R, K, T, F): a view-free copy made only for the caller's benefit
-    return out_, yf_, z_rank_major.permute(1, 0, 2, 3, 4).reshape(R, K, eng.T, eng.F)
+    return out, yf_, z_all
 
 
 def torch_all_gather(world):

@@ -34,7 +34,8 @@ def build_emu():
 
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         objs = list(ex.map(compile_unit, units))
-    subprocess.check_call(['g++', '-shared', '-pthread', '-o', OUT] + objs)
+    # a sanitizer build (DISCO_CXXFLAGS='-fsanitize=address,undefined ...', tests/run_sanitized.sh) links its runtimes too
+    subprocess.check_call(['g++', '-shared', '-pthread', '-o', OUT] + [f for f in _EXTRA if f.startswith('-fsanitize')] + objs)
     return OUT
 
 

@@ -759,10 +759,12 @@ def check_node_sharded_torch_one_rank(make_engine, device, backend, K=3, M=2, L=
             eng.set_node_shard(0, K)
             yt = torch.from_numpy(y).to(device)
             mt = torch.from_numpy(mask).to(device)
-            out, yf, z_all = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=it)
-            assert yf.device.type == torch.device(device).type and tuple(z_all.shape) == (R, K, eng.T, eng.F)
-            errs[it] = (relerr(yf.cpu().numpy(), yf_ref.numpy()), relerr(out.numpy(), out_ref.numpy()))
-            assert max(errs[it]) < 1e-5, errs
+            for overlap in (False, True):               # the plain call, and two half-batches with asynchronous all-gathers
+                out, yf, z_all = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=it, overlap=overlap)
+                assert yf.device.type == torch.device(device).type and tuple(z_all.shape) == (R, K, eng.T, eng.F)
+                out_np = out.cpu().numpy() if hasattr(out, 'cpu') else out.numpy()
+                errs[(it, overlap)] = (relerr(yf.cpu().numpy(), yf_ref.numpy()), relerr(out_np, out_ref.numpy()))
+                assert max(errs[(it, overlap)]) < 1e-5, errs
     finally:
         if own_group:
             dist.destroy_process_group()
