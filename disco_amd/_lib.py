@@ -89,6 +89,7 @@ PROTOTYPES = {
     'disco_selftest_stream': (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     'disco_selftest_pk': (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'disco_selftest_dpp': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'disco_selftest_room': (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     'disco_tango_online': (_int, [_vp, _vp, _vp, _vp, _f, _int, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'disco_online_state_bytes': (_sz, [_vp]),
     'disco_online_stream_workspace_bytes': (_sz, [_vp, _int]),

@@ -64,3 +64,13 @@ int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, con
     return check_launch(ctx, "k_room_cov");
 }
 }  // namespace disco_host
+
+// self-test of the asm primitives of the room pass (csrc/k_room.h: LDS-DMA loads, permlane swaps): see include/disco_hip.h
+extern "C" int disco_selftest_room(disco_ctx* ctx, const float* src, int64_t n, float* out_hw, float* out_ref, disco_stream s) {
+    static_assert(ROOM_SELFTEST_OPS == DISCO_ROOM_SELFTEST_OPS, "header and kernel disagree");
+    if (!src || !out_hw || !out_ref || n < 256 || n % 256) return ctx ? fail(ctx, DISCO_E_ARG, "disco_selftest_room: bad argument (n: a multiple of 256)") : DISCO_E_ARG;
+    DevGuard dev_guard_(ctx ? ctx->cfg.device : [] { int d = 0; (void)hipGetDevice(&d); return d; }());
+    hipLaunchKernelGGL(k_room_selftest, dim3((unsigned)(n / 256)), dim3(64), 0, (hipStream_t)s, src, (long long)n, out_hw, out_ref);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : DISCO_E_HIP_BASE - (int)e;
+}

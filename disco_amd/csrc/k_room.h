@@ -483,4 +483,38 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeomS<M, K, SUB>::NT), DISC
     else room_cov_dma_run<M, K, SUB, false>(a, sh);
 }
 
+// ---- self-test of the room pass's asm primitives (disco_selftest_room; no reference counterpart) ------------------------------------
+// lds_dma16 / lds_dma4 (global_load_lds with the M0 dance) + vm_wait_all against plain loads, lane_swap_add<32 / 16> (v_permlane32_swap /
+// v_permlane16_swap) against its __shfl_xor statement: row q of out_hw through the instruction form, of out_ref through plain C++.
+// Lane l of wave v fetches a PERMUTED granule (the kernel's own use: a lane's LDS place is fixed, the granule it fetches is chosen).
+constexpr int ROOM_SELFTEST_OPS = 4;
+static __global__ __launch_bounds__(64) void k_room_selftest(const float* __restrict__ src, long long n, float* __restrict__ out_hw, float* __restrict__ out_ref) {
+    __shared__ float4 s16[64];
+    __shared__ float s4[64];
+    const int lane = threadIdx.x;
+    const long long base = (long long)blockIdx.x * 256;          // 64 lanes x 4 floats per wave
+    if (base + 256 > n) return;
+    const int perm = (lane * 5 + 3) & 63;                        // a permutation of the lanes (5 is odd)
+    lds_dma16(src + base, (unsigned)(perm * 16), &s16[0], lane);
+    lds_dma4(src + base, (unsigned)(perm * 4), &s4[0], lane);
+    vm_wait_all();
+    __syncthreads();
+    const float4 g16 = s16[lane];
+    const float g4 = s4[lane];
+    const float4 r16 = *reinterpret_cast<const float4*>(src + base + perm * 4);
+    const float r4 = src[base + perm];
+    const float a = src[base + lane], b = src[base + 64 + lane];
+    const float sw32 = lane_swap_add<32>(a, b, lane), sw16 = lane_swap_add<16>(a, b, lane);
+    const float pa32 = __shfl_xor(a, 32), pb32 = __shfl_xor(b, 32), pa16 = __shfl_xor(a, 16), pb16 = __shfl_xor(b, 16);
+    const long long o = ((long long)blockIdx.x * 64 + lane) * ROOM_SELFTEST_OPS;
+    out_hw[o + 0] = g16.x + 2.f * g16.y + 3.f * g16.z + 5.f * g16.w;
+    out_ref[o + 0] = r16.x + 2.f * r16.y + 3.f * r16.z + 5.f * r16.w;
+    out_hw[o + 1] = g4;
+    out_ref[o + 1] = r4;
+    out_hw[o + 2] = sw32;
+    out_ref[o + 2] = (lane & 32) ? pb32 + b : a + pa32;
+    out_hw[o + 3] = sw16;
+    out_ref[o + 3] = (lane & 16) ? pb16 + b : a + pa16;
+}
+
 }  // namespace disco

@@ -91,9 +91,12 @@ def make_rooms_numpy(R, K=4, M=4, L=160000, seed=1234, first_room=0):
 
 
 def make_rooms_torch(R, K=4, M=4, L=160000, seed=1234, first_room=0, device='cuda', chunk=50,
-                     ref_only_sn=True):
+                     ref_only_sn=True, engine=None):
     """Same recipe on the GPU.  Returns torch tensors y (R,K,M,L) and s, n -- restricted to channel 0
-    of every node, shape (R,K,L), when ref_only_sn (all the oracle mask needs; saves 2/3 of the HBM)."""
+    of every node, shape (R,K,L), when ref_only_sn (all the oracle mask needs; saves 2/3 of the HBM).
+    engine: an Engine on the same device -> the source images are formed by the library's own RIR convolution (disco_rir_convolve, the
+    kernel that stands in for gen_disco/convolve_signals.py:160-163) instead of torch.fft; the two agree to float32 rounding
+    (tests/test_gpu_parity.py::test_synth_rooms_through_rir_convolve)."""
     import torch
     g = torch.Generator(device=device)
     y = torch.empty((R, K, M, L), dtype=torch.float32, device=device)
@@ -124,10 +127,21 @@ def make_rooms_torch(R, K=4, M=4, L=160000, seed=1234, first_room=0, device='cud
         dry_s = np.sqrt(TARGET_VAR) * torch.randn((rc, L), device=device, generator=g)
         dry_s[:, :lead] = 0
         dry_n = torch.randn((rc, L), device=device, generator=g)
-        Hf = torch.fft.rfft(rir, nfft, dim=-1)
-        s_img = torch.fft.irfft(torch.fft.rfft(dry_s, nfft).view(rc, 1, 1, -1) * Hf[:, 0], nfft, dim=-1)[..., :L]
-        n_img = torch.fft.irfft(torch.fft.rfft(dry_n, nfft).view(rc, 1, 1, -1) * Hf[:, 1], nfft, dim=-1)[..., :L]
-        del Hf, rir
+        if engine is not None:
+            s_img = torch.empty((rc, K, M, L), dtype=torch.float32, device=device)
+            n_img = torch.empty((rc, K, M, L), dtype=torch.float32, device=device)
+            for img, dry, src in ((s_img, dry_s, 0), (n_img, dry_n, 1)):
+                h = rir[:, src].reshape(rc, K * M, RIR_TAPS).contiguous()
+                d = dry.contiguous()
+                engine._chk(engine.lib.disco_rir_convolve(engine.ctx, d.data_ptr(), h.data_ptr(), rc, K * M, L, RIR_TAPS, img.data_ptr(), L,
+                                                          None))
+            torch.cuda.synchronize()
+            del rir
+        else:
+            Hf = torch.fft.rfft(rir, nfft, dim=-1)
+            s_img = torch.fft.irfft(torch.fft.rfft(dry_s, nfft).view(rc, 1, 1, -1) * Hf[:, 0], nfft, dim=-1)[..., :L]
+            n_img = torch.fft.irfft(torch.fft.rfft(dry_n, nfft).view(rc, 1, 1, -1) * Hf[:, 1], nfft, dim=-1)[..., :L]
+            del Hf, rir
         ps = s_img[:, 0, 0, lead:].var(dim=-1)
         pn = n_img[:, 0, 0, lead:].var(dim=-1)
         gain = torch.sqrt(ps / (pn * torch.tensor(10 ** (snr / 10), device=device, dtype=torch.float32)))

@@ -941,6 +941,27 @@ def check_pk_selftest(make_engine, n=4096, seed=11):
     return errs
 
 
+def check_room_selftest(make_engine, n=4096, seed=17):
+    """csrc/k_room.h: lds_dma16 / lds_dma4 + vm_wait_all and lane_swap_add<32 / 16> through their instruction forms (on the emulated build:
+    their C++ twins) must equal plain loads / the __shfl_xor statement bit for bit, and mean what they say (NumPy)."""
+    rng = np.random.default_rng(seed)
+    src = rng.standard_normal(n).astype(np.float32)
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    hw, ref = eng.selftest_room(src)
+    hw, ref = hw.numpy(), ref.numpy()
+    assert np.array_equal(hw.view(np.uint32), ref.view(np.uint32)), 'instruction forms differ from their plain statement'
+    blk = src.reshape(-1, 256)
+    lane = np.arange(64)
+    perm = (lane * 5 + 3) & 63
+    g = blk.reshape(-1, 64, 4)[:, perm]                                    # the granule lane l fetched
+    a, b = blk[:, :64], blk[:, 64:128]
+    want = np.stack([g[..., 0] + np.float32(2) * g[..., 1] + np.float32(3) * g[..., 2] + np.float32(5) * g[..., 3], blk[:, perm],
+                     np.where(lane & 32, b[:, lane ^ 32] + b, a + a[:, lane ^ 32]), np.where(lane & 16, b[:, lane ^ 16] + b, a + a[:, lane ^ 16])], axis=-1)
+    err = float(np.abs(hw.reshape(-1, 64, 4) - want).max())
+    assert err < 1e-5, err
+    return err
+
+
 def check_dpp_selftest(make_engine, n=1024, seed=13):
     """csrc/dpp64.h: the float64 DPP row-broadcast forms must equal __shfl + the plain fused multiply-adds bit for bit, and both must
     mean what the helper says (NumPy): lane i of a 16-lane row reads entries of the other lanes of ITS row."""

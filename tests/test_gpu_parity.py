@@ -36,6 +36,11 @@ def test_pk_instruction_forms(make_engine):
 
 
 @pytest.mark.gpu
+def test_room_pass_instruction_forms(make_engine):
+    """LDS-DMA loads and permlane swaps of csrc/k_room.h against plain statements, bit for bit (round-4 VERDICT weak 7)."""
+    print(pc.check_room_selftest(make_engine))
+
+
 def test_dpp_instruction_forms(make_engine):
     print(pc.check_dpp_selftest(make_engine, n=4096))
 
@@ -90,6 +95,19 @@ def test_metrics(make_engine, golden_dir, start):
                                                       (1, 1, 700, 100, 513), (5, 3, 9000, 5000, 9000)])
 def test_rir_convolve(make_engine, n_sig, n_ch, Ld, Lh, out_len):
     pc.check_rir_convolve(make_engine, n_sig=n_sig, n_ch=n_ch, Ld=Ld, Lh=Lh, out_len=out_len)
+
+
+def test_synth_rooms_through_rir_convolve(make_engine):
+    """The bench's room generator with its source images formed by the library's own RIR convolution (disco_rir_convolve)
+    against the same generator on torch.fft: the same rooms to float32 rounding, at the bench's clip length and RIR length."""
+    import torch
+    from disco_amd import synth
+    eng = make_engine(rooms=1, nodes=1, mics=1, length=1024)
+    a = synth.make_rooms_torch(2, K=2, M=4, L=160000, device='cuda:0', ref_only_sn=False)
+    b = synth.make_rooms_torch(2, K=2, M=4, L=160000, device='cuda:0', ref_only_sn=False, engine=eng)
+    for x, y_ in zip(a, b):
+        e = float((x - y_).norm() / x.norm())
+        assert e < 2e-6, e
 
 
 @pytest.mark.parametrize('max_order,rir_len', [(6, 4096), (20, 8192)])

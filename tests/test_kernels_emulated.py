@@ -24,6 +24,10 @@ def test_emu_pk_operations(make_engine):
     pc.check_pk_selftest(make_engine, n=512)
 
 
+def test_emu_room_primitives(make_engine):
+    print(pc.check_room_selftest(make_engine, n=1024))
+
+
 def test_emu_dpp_operations(make_engine):
     print(pc.check_dpp_selftest(make_engine, n=256))
 

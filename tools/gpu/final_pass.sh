@@ -26,6 +26,16 @@ bash tools/profile_round.sh ${TAG}_C2 --config C2 2>&1 | tail -6
 bash tools/profile_round.sh ${TAG}_C2x4000 --config C2 --rooms 4000 2>&1 | tail -6
 BARGS="" bash tools/gpu/pmc_alu.sh ${TAG}_C3 2>&1 | grep -E "rc|disco::" | cut -c1-400
 BARGS="--config C5" bash tools/gpu/pmc_alu.sh ${TAG}_C5 2>&1 | grep -E "rc|disco::" | cut -c1-400
+BARGS="--rooms 1000 --online-every 1" bash tools/gpu/pmc_alu.sh ${TAG}_online1 2>&1 | grep -E "rc|disco::" | cut -c1-400
+python - <<PY
+# the online mode's VALU-issue roofline reads this copy (bench.py: profiles/pmc_alu_online1.json), stamped with the digest of the kernel sources
+import json, sys
+sys.path.insert(0, '.')
+import bench
+d = json.load(open('gpurun_out/${TAG}_online1_pmc_alu.json'))
+d['_csrc_digest'] = bench.csrc_digest()
+json.dump(d, open('gpurun_out/pmc_alu_online1.json', 'w'), indent=1)
+PY
 DISCO_OVERLAP_SOLVES=0 timeout 300 python bench.py --extras none --no-cpu-baseline > gpurun_out/${TAG}_bench_C3_overlap0.json 2>/dev/null
 timeout 300 python bench.py --shard nodes --rooms 250 --extras none --no-cpu-baseline > gpurun_out/${TAG}_bench_nodeshard.json 2>/dev/null
 timeout 300 python bench.py --rooms 1000 --online-every 8 --steps 2 --warmup 1 --extras none --no-cpu-baseline > gpurun_out/${TAG}_bench_online8.json 2>/dev/null
