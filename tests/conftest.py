@@ -10,6 +10,7 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: takes the better part of an hour (the sanitizer leg); runs only with DISCO_RUN_SLOW=1')
 
 
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
