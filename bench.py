@@ -675,7 +675,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
                       'mask_w_max_abs': float((dnn['mw'] - mw32).abs().max()), 'mask_w_mean_abs': float((dnn['mw'] - mw32).abs().mean())}
         del mz32, mw32
     stream = None
-    if online_every > 0 and rank == 0 and not node_sharded:
+    if online_every > 0 and rank == 0 and not node_sharded and not args.no_stage_timing:      # (counter passes run the whole-clip launch alone)
         try:
             stream = stream_bench(eng, lib, torch, y, mask, online_every, H, F)
         except Exception as e:                              # reported, never fatal: the whole-clip numbers above stand on their own
