@@ -21,9 +21,9 @@ bool room_cov_ok(const disco_ctx* ctx, const disco_c32* X, const float* mask) {
     return (long long)K * ctx->T * ctx->F * M <= 0x0fffffffLL;                               // 32-bit BYTE offsets inside a room (8 B per element)
 }
 
-// The persistent pass forms ONE partial block per node: its workgroups walk items (room, tile of 4 bins, all frames), the time axis is
-// split INSIDE the workgroup (8 sub-chunks across the lanes).
-int room_chunks(const disco_ctx*) { return 1; }
+// The persistent pass forms ONE total per node -- its workgroups walk items (room, tile of 4 bins, all frames), the time axis is split INSIDE
+// the workgroup (8 sub-chunks across the lanes), the sub-chunks meet in float64 -- and hands it over as TWO float32 blocks (hi, lo).
+int room_chunks(const disco_ctx*) { return 2; }
 
 int room_cov_partials(disco_ctx* ctx, const disco_c32* X, const float* mask, const disco_c32* w_loc, disco_c32* z,
                              int* chunks_out, disco_stream s, bool store_z) {

@@ -11,7 +11,8 @@
 //     the node's own mask (mask_for_z = 'local'): 112 accumulator registers per lane.
 // The leading M x M block of every node is the step-1 covariance (same mask, same X): it is NOT formed here -- the solver
 // takes it from the step-1 partial sums (SolveSrc::part_loc), exactly as after k_cov_split_lds<.., SKIPLOC = true>.
-// Output: partial sums in the layout of every other covariance kernel, part[g * F + f][tri(i, j)] for the entries with j >= M.
+// Output: partial sums in the layout of every other covariance kernel, TWO blocks per node -- the float32 head and the remainder of totals
+// formed in float64 --, part[(g * 2 + {0, 1}) * F + f][tri(i, j)] for the entries with j >= M.
 // (Round 3's register-staged form of this pass -- one frame in flight per workgroup, one workgroup per (room, tile, chunk): 7.6 against
 // 6.4 ms per C5 launch -- was removed in round 5; git history and profiles/r03_design_and_experiment_log.md have it.)
 #pragma once
@@ -30,7 +31,7 @@ struct RoomArgs {
     const float* mask;   // [R][K][T][F]
     const c32* w;        // [R][K][F][M]   step-1 filters (or the local part of the previous iteration's)
     c32* z;              // [R][K][T][F]   out
-    float4* part;        // [R*K][F][NP]
+    float4* part;        // [R*K][2][F][NP]   (hi, lo)
     int T, F, chunks, tiles;
     long long R;
     int store_z;         // 0: z is only formed on chip (an iteration whose z nobody reads: the next pass re-compresses with new filters)
@@ -48,7 +49,7 @@ struct RoomArgs {
 // shorter, the bytes per barrier, the ring, the loader rounds and the arithmetic per lane are exactly what they were, and the SUB
 // partial sums of an entry meet INSIDE the wave at the end (v_permlane32_swap / v_permlane16_swap: the two halves swap one register
 // each and add, so every level also halves the entries a lane is left to store).  SUB = 8 sums 20 frames per accumulator where
-// round 3 summed 157, and ONE partial block per node reaches HBM instead of two.
+// round 3 summed 157, and one TOTAL per node reaches HBM (as a (hi, lo) pair of blocks since the end of round 5: `finish` below).
 // Shorter items would pay the per-workgroup prologue / epilogue (about 20 us of a 250 us item in round 3: dispatch, taps, ring fill,
 // first z, 28 uncoalesced 16-byte stores per lane) four to eight times as often, so the workgroup is PERSISTENT: it walks items
 // blockIdx.x, blockIdx.x + gridDim.x, ... (an item: a room's tile, all its frames) and the ring never drains -- the loads of the next item's first frames (and its taps, into
@@ -162,19 +163,29 @@ __device__ __forceinline__ float lane_swap_add(float a, float b, int lane) {
     return (lane & BIT) ? pb + b : a + pa;
 #endif
 }
-// entries [0, N) of (es, en) -> [0, N / 2): entry e meets entry e + N / 2; lanes with the bit set keep the upper half's totals
-template <int BIT, int N>
-__device__ __forceinline__ void room_halve(c32* es, c32* en, int lane) {
-    static_assert(N % 2 == 0, "pairs of entries");
-#pragma unroll
-    for (int e = 0; e < N / 2; ++e) {
-        es[e].x = lane_swap_add<BIT>(es[e].x, es[e + N / 2].x, lane);
-        es[e].y = lane_swap_add<BIT>(es[e].y, es[e + N / 2].y, lane);
-        en[e].x = lane_swap_add<BIT>(en[e].x, en[e + N / 2].x, lane);
-        en[e].y = lane_swap_add<BIT>(en[e].y, en[e + N / 2].y, lane);
+// the same for a float64 value: its two words are swapped separately
+template <int BIT>
+__device__ __forceinline__ double lane_swap_add64(double a, double b, int lane) {
+#if defined(__clang__)
+    (void)lane;
+    static_assert(BIT == 32 || BIT == 16, "permlane swaps");
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    unsigned l0, l1, h0, h1;
+    if constexpr (BIT == 32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+        l0 = lo[0], l1 = lo[1], h0 = hi[0], h1 = hi[1];
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+        l0 = lo[0], l1 = lo[1], h0 = hi[0], h1 = hi[1];
     }
+    return __longlong_as_double((long long)((unsigned long long)h0 << 32 | l0)) + __longlong_as_double((long long)((unsigned long long)h1 << 32 | l1));
+#else
+    const double pa = __shfl_xor(a, BIT), pb = __shfl_xor(b, BIT);
+    return (lane & BIT) ? pb + b : a + pa;
+#endif
 }
-
 template <int M, int K, int SUB, bool IS_A>
 __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M, K, SUB>& sh) {
     using Gm = RoomGeomS<M, K, SUB>;
@@ -337,30 +348,19 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
         }
     };
 
-    // The SUB partial sums of every entry meet inside the wave: lane bit 5, then bit 4, by swap-and-add (every level leaves a lane
-    // half of its entries: the upper half's totals go to the lanes with the bit set), a third sub-chunk bit (SUB = 8, lane bit 3) by a plain
-    // add.  A lane then stores whole 16-byte entries -- for A slots one row of KR contiguous ones -- and clears its sums.
+    // The SUB partial sums of every entry meet inside the wave IN FLOAT64 and leave as a (hi, lo) pair of float32 blocks (round 5, late).
+    // A lane's float32 sums run over T / SUB frames; what the solve cannot take is their TOTAL rounded to float32 -- an entry of a pencil
+    // with cond(Rnn) ~ 1e5 rounded at 6e-8 (profiles/r05_c5_accumulation.txt: the same sums combined in float64 and handed over unrounded
+    // put C5's worst room at 1.3 - 3.2e-5 over the summation orders where the float32 tree put it at 2.3 - 8.4e-5).  So: lane bit 5, then
+    // bit 4, by swap-and-add on float64 values (every level leaves a lane half of its entries: the upper half's totals go to the lanes with
+    // the bit set), the third sub-chunk bit (lane bit 3) by a plain add; four entries at a time (32 registers; the float32 sums they came
+    // from are dead by then).  A lane then stores whole 16-byte entries -- for A slots one row of KR contiguous ones -- twice: the float32
+    // head of the total into block 0, the remainder into block 1 (the solvers add the blocks of an entry in float64), and clears its sums.
     // Entries are numbered q = i KR + jj (A: rows 4 h + i against the remote columns) / the upper triangle of the remote block
     // row by row (B): in both cases consecutive q of a row are consecutive in the packed triangle, and for B so is the whole run.
     auto finish = [&](int room, int f0) {
-        constexpr int NACCP = (NACC + (1 << LH) - 1) >> LH << LH, EPL = NACCP >> LH;
-        c32 es[NACCP], en[NACCP];
-#pragma unroll
-        for (int q = 0; q < NACCP; ++q) {
-            es[q] = q < NACC ? acc_s[q] : make_float2(0.f, 0.f);
-            en[q] = q < NACC ? acc_n[q] : make_float2(0.f, 0.f);
-        }
-        if constexpr (LH >= 1) room_halve<32, NACCP>(es, en, lane);
-        if constexpr (LH >= 2) room_halve<16, NACCP / 2>(es, en, lane);
-        if constexpr (SUB == 8) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                es[e].x += __shfl_xor(es[e].x, 8);
-                es[e].y += __shfl_xor(es[e].y, 8);
-                en[e].x += __shfl_xor(en[e].x, 8);
-                en[e].y += __shfl_xor(en[e].y, 8);
-            }
-        }
+        static_assert(SUB == 8 && LH == 2, "three sub-chunk bits: lane bits 5, 4 (swaps) and 3 (add)");
+        constexpr int NACCP = (NACC + 3) / 4 * 4, EPL = NACCP / 4;
         // Where the lane's entries go is recomputed here from an OPAQUE copy of the thread index: derived once before the loop, these
         // values would be carried through it in registers the fold needs (hipcc hoists them out and then spills them).
         int tid_ = tid;
@@ -369,19 +369,41 @@ __device__ __forceinline__ void room_cov_dma_run(const RoomArgs& a, RoomRingS<M,
 #endif
         const int lane_ = tid_ & 63, bin_ = lane_ & (NB - 1), sub_ = (lane_ / NB) & 1;
         const int k_ = is_a ? (2 * wr + sub_) / NA : 2 * wr + sub_, h_ = is_a ? sub_ % NA : 0;
-        const int g = LH == 2 ? ((lane_ >> 5) & 1) * 2 + ((lane_ >> 4) & 1) : (LH == 1 ? (lane_ >> 5) & 1 : 0);
-        const bool writer = f0 + bin_ < F && (SUB != 8 || (lane_ & 8) == 0);
-        if (writer) {
-            float4* o = a.part + (((long long)room * K + k_) * F + f0 + bin_) * (long long)NP;
+        const int g = ((lane_ >> 5) & 1) * 2 + ((lane_ >> 4) & 1);
+        const bool writer = f0 + bin_ < F && (lane_ & 8) == 0;
+        float4* o = a.part + ((((long long)room * K + k_) * 2) * F + min(f0 + bin_, F - 1)) * (long long)NP;
+        const long long lo_block = (long long)F * NP;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int q = g * EPL + e;
-                if constexpr (is_a) {
-                    const int r = 4 * h_ + q / KR, jj = q % KR;           // row of the node's own mic, remote column
-                    o[r * P - (r * (r - 1)) / 2 + (M - r) + jj] = make_float4(es[e].x, es[e].y, en[e].x, en[e].y);
-                } else {
-                    if (q < NACC) o[tri_index<P>(M, M) + q] = make_float4(es[e].x, es[e].y, en[e].x, en[e].y);
+        for (int e = 0; e < EPL; ++e) {
+            double tot[4];                              // Rss.re, Rss.im, Rnn.re, Rnn.im of the entry this lane is left with
+#pragma unroll
+            for (int comp = 0; comp < 4; ++comp) {
+                double v[4];                            // entries e + {0, 1, 2, 3} EPL: level 1 pairs (0, 2) and (1, 3), level 2 their results
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int q = e + x * EPL;
+                    const c32 src_ = q < NACC ? (comp < 2 ? acc_s[q < NACC ? q : 0] : acc_n[q < NACC ? q : 0]) : make_float2(0.f, 0.f);
+                    v[x] = (double)((comp & 1) ? src_.y : src_.x);
                 }
+                const double l0 = lane_swap_add64<32>(v[0], v[2], lane), l1 = lane_swap_add64<32>(v[1], v[3], lane);
+                double t = lane_swap_add64<16>(l0, l1, lane);
+                t += __shfl_xor(t, 8);
+                tot[comp] = t;
+            }
+            const float4 hi = make_float4((float)tot[0], (float)tot[1], (float)tot[2], (float)tot[3]);
+            const float4 lo = make_float4((float)(tot[0] - (double)hi.x), (float)(tot[1] - (double)hi.y), (float)(tot[2] - (double)hi.z),
+                                          (float)(tot[3] - (double)hi.w));
+            const int q = g * EPL + e;
+            long long at = -1;
+            if constexpr (is_a) {
+                const int r = 4 * h_ + q / KR, jj = q % KR;               // row of the node's own mic, remote column
+                at = r * P - (r * (r - 1)) / 2 + (M - r) + jj;
+            } else {
+                if (q < NACC) at = tri_index<P>(M, M) + q;
+            }
+            if (writer && at >= 0) {
+                o[at] = hi;
+                o[lo_block + at] = lo;
             }
         }
 #pragma unroll
@@ -484,10 +506,10 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__((RoomGeomS<M, K, SUB>::NT), DISC
 }
 
 // ---- self-test of the room pass's asm primitives (disco_selftest_room; no reference counterpart) ------------------------------------
-// lds_dma16 / lds_dma4 (global_load_lds with the M0 dance) + vm_wait_all against plain loads, lane_swap_add<32 / 16> (v_permlane32_swap /
-// v_permlane16_swap) against its __shfl_xor statement: row q of out_hw through the instruction form, of out_ref through plain C++.
+// lds_dma16 / lds_dma4 (global_load_lds with the M0 dance) + vm_wait_all against plain loads, lane_swap_add<32 / 16> and lane_swap_add64 (v_permlane32_swap /
+// v_permlane16_swap) against their __shfl_xor statements: row q of out_hw through the instruction form, of out_ref through plain C++.
 // Lane l of wave v fetches a PERMUTED granule (the kernel's own use: a lane's LDS place is fixed, the granule it fetches is chosen).
-constexpr int ROOM_SELFTEST_OPS = 4;
+constexpr int ROOM_SELFTEST_OPS = 6;
 static __global__ __launch_bounds__(64) void k_room_selftest(const float* __restrict__ src, long long n, float* __restrict__ out_hw, float* __restrict__ out_ref) {
     __shared__ float4 s16[64];
     __shared__ float s4[64];
@@ -515,6 +537,15 @@ static __global__ __launch_bounds__(64) void k_room_selftest(const float* __rest
     out_ref[o + 2] = (lane & 32) ? pb32 + b : a + pa32;
     out_hw[o + 3] = sw16;
     out_ref[o + 3] = (lane & 16) ? pb16 + b : a + pa16;
+    // the float64 form (`finish`): operands whose low words matter, the result's two float32 halves' sum is compared (both words took part)
+    const double da = (double)a * 1.0000001192092896 + (double)b * 1e-9, db = (double)b * 0.9999998807907104 - (double)a * 1e-9;
+    const double dw32 = lane_swap_add64<32>(da, db, lane), dw16 = lane_swap_add64<16>(da, db, lane);
+    const double qa32 = __shfl_xor(da, 32), qb32 = __shfl_xor(db, 32), qa16 = __shfl_xor(da, 16), qb16 = __shfl_xor(db, 16);
+    const double dr32 = (lane & 32) ? qb32 + db : da + qa32, dr16 = (lane & 16) ? qb16 + db : da + qa16;
+    out_hw[o + 4] = (float)(dw32 - (double)(float)dw32) * 1e6f + (float)dw32;
+    out_ref[o + 4] = (float)(dr32 - (double)(float)dr32) * 1e6f + (float)dr32;
+    out_hw[o + 5] = (float)(dw16 - (double)(float)dw16) * 1e6f + (float)dw16;
+    out_ref[o + 5] = (float)(dr16 - (double)(float)dr16) * 1e6f + (float)dr16;
 }
 
 }  // namespace disco

@@ -30,8 +30,8 @@ struct DppSolveGeom {
     static constexpr int THREADS = 64, PROBS = 4;
     static constexpr int PW = P | 1;                    // odd row pitch (16-byte words): transposed reads spread over the banks
     static constexpr int WORDS = P * PW + PW;           // + one row of zeros (lanes >= P; the "not part of column j" entries of the parked L)
-    // the same block first holds the staged pencil (group_stage_part): P (P + 1) / 2 + 2 * 36 + 1 float4 (M_loc <= 8), 16 bytes like a c64
-    static constexpr int BLOCK = WORDS > P * (P + 1) / 2 + 73 ? WORDS : P * (P + 1) / 2 + 73;
+    // the same block first holds the staged pencil (group_stage_part): (hi, lo) of P (P + 1) / 2 entries + 1 float4, 16 bytes like a c64
+    static constexpr int BLOCK = WORDS > P * (P + 1) + 1 ? WORDS : P * (P + 1) + 1;
 };
 
 // The group's pencil from the covariance kernels' chunk partials (SolveSrc, k_solve.h), fetched by the GROUP into its LDS block:
@@ -43,11 +43,11 @@ struct DppSolveGeom {
 // Round 5: nothing is rounded at the solver's door any more.  (Round 4 measured what that rounding costs: the float64 oracle itself moves
 // by 3.7e-5 on C5's worst room when its exact covariances are merely rounded to complex64, profiles/r04_c5_accumulation.txt.)
 //   * The sums are handed over UNSCALED -- w and t1 do not change when Rxx and Rnn are scaled together (d0 is their ratio, q scales with
-//     1 / L, t1 = q L00 conj(v0[0])) -- so an entry that arrives as ONE float32 block (the room pass leaves one block per node) passes
-//     through exactly; the multiplication by 1 / T cost it a rounding.
-//   * The leading M_loc x M_loc block -- the step-1 statistics, which the wide shapes accumulate in float64 and store as (hi, lo) pairs of
-//     blocks (k_cov_loc_f64) -- is staged as (hi, lo) float4 pairs and the float64 rows are formed from both.
-// Main entries that arrive in several blocks are still rounded once (their sum); `stage`: NP + 2 NPL + 1 float4.
+//     1 / L, t1 = q L00 conj(v0[0])) -- the multiplication by 1 / T cost every entry a rounding.
+//   * EVERY entry is staged as a (hi, lo) pair of float4: the float64 total of its blocks, split.  The leading M_loc x M_loc block is the
+//     step-1 statistics, which the wide shapes accumulate in float64 and store as (hi, lo) pairs of blocks (k_cov_loc_f64); the other
+//     entries are the room pass's totals, formed in float64 from its float32 sub-chunk sums and stored the same way (k_room.h, `finish`).
+// `stage`: hi[NP], lo[NP], one zero word = 2 NP + 1 float4.
 template <int P>
 __device__ __forceinline__ void group_stage_part(const SolveSrc& src, long long pid, int j, bool live, float4* stage) {
     constexpr int NP = P * (P + 1) / 2, SLOTS = (NP + 15) / 16;
@@ -56,6 +56,12 @@ __device__ __forceinline__ void group_stage_part(const SolveSrc& src, long long 
     const int f = (int)(pidc % src.F);
     const int ML = src.M_loc, NPL = ML * (ML + 1) / 2;
     const double it = live ? 1.0 : 0.0;
+    auto put = [&](int at, double a0, double a1, double a2, double a3) {
+        a0 *= it, a1 *= it, a2 *= it, a3 *= it;
+        const float4 hi = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+        stage[at] = hi;
+        stage[NP + at] = make_float4((float)(a0 - (double)hi.x), (float)(a1 - (double)hi.y), (float)(a2 - (double)hi.z), (float)(a3 - (double)hi.w));
+    };
     {
         const float4* pb = src.part + ((g * src.chunks) * src.F + f) * (long long)NP;
         const long long cs = (long long)src.F * NP;
@@ -77,9 +83,10 @@ __device__ __forceinline__ void group_stage_part(const SolveSrc& src, long long 
         }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
-            if (16 * s + j < NP) stage[16 * s + j] = make_float4((float)(acc[s][0] * it), (float)(acc[s][1] * it), (float)(acc[s][2] * it), (float)(acc[s][3] * it));
+            if (16 * s + j < NP) put(16 * s + j, acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
     }
-    if (ML > 0) {                                       // leading M_loc x M_loc block: the step-1 partial sums, (hi, lo)
+    if (ML > 0) {                                       // leading M_loc x M_loc block: the step-1 partial sums OVER what the main blocks held there
+        DISCO_GROUP_SYNC();                             // (program order between the lanes' stores to the same words)
         const float4* pl = src.part_loc + ((g * src.chunks_loc) * src.F + f) * (long long)NPL;
         const long long csl = (long long)src.F * NPL;
         for (int q = j; q < NPL; q += 16) {
@@ -91,55 +98,43 @@ __device__ __forceinline__ void group_stage_part(const SolveSrc& src, long long 
                 a2 += (double)v.z;
                 a3 += (double)v.w;
             }
-            a0 *= it, a1 *= it, a2 *= it, a3 *= it;
-            const float4 hi = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
-            stage[NP + q] = hi;
-            stage[NP + NPL + q] = make_float4((float)(a0 - (double)hi.x), (float)(a1 - (double)hi.y), (float)(a2 - (double)hi.z), (float)(a3 - (double)hi.w));
+            int r = 0, q0 = 0;                          // q = tri_ML(r, c): the row whose run [q0, q0 + ML - r) holds q
+            while (q0 + ML - r <= q) q0 += ML - r, ++r;
+            const int c = r + (q - q0);
+            put(r * P - (r * (r - 1)) / 2 + (c - r), a0, a1, a2, a3);
         }
     }
-    if (j == 0) stage[NP + 2 * NPL] = make_float4(0.f, 0.f, 0.f, 0.f);     // what the lanes >= P read, and the `lo` of every entry outside the leading block
+    if (j == 0) stage[2 * NP] = make_float4(0.f, 0.f, 0.f, 0.f);           // what the lanes >= P read
     DISCO_GROUP_SYNC();
 }
 // Row j of the staged pencil in ONE pass over its entries: Rnn's row in float64 (`b`: the Cholesky takes it at once), Rxx's row as its
-// float32 head `a_hi` (what crosses the squarings for the Rayleigh quotient: d0 only enters through d0 / (d0 + mu)) plus the `lo` halves of
-// its leading-block entries `a_lo` (c < LMAX), from which the caller forms the float64 row when the whitening begins.  Entry (j, c) sits at
-// upper-triangle coordinates (lo, hi) = (min, max); lower triangle = conj(upper); the diagonal is real.  Branch-free on purpose (integer
-// selects as masks, signs as factors): hipcc otherwise wraps every entry in its own exec-masked block with a wait of its own.
-constexpr int DPP_LMAX = 8;         // M_loc <= 8 (mics per node)
+// float32 head `a_hi` (what crosses the squarings for the Rayleigh quotient: d0 only enters through d0 / (d0 + mu)) plus the `lo` halves
+// `a_lo`, from which the caller forms the float64 row when the whitening begins.  Entry (j, c) sits at upper-triangle coordinates
+// (lo, hi) = (min, max); lower triangle = conj(upper); the diagonal is real.  Branch-free on purpose (integer selects as masks, signs as
+// factors): hipcc otherwise wraps every entry in its own exec-masked block with a wait of its own.
+// (P = 16 has no register left for 16 `lo` halves of Rxx -- the kernel may not spill, build.py -- and no room-pass shape: it keeps those of
+// the leading 8 columns, the widest step-1 block; Rnn's row takes every `lo` either way.)
 template <int P>
-__device__ __forceinline__ void group_stage_rows(const float4* stage, int ML, int j, c64* b, c32* a_hi, c32* a_lo) {
-    constexpr int NP = P * (P + 1) / 2;
-    const int NPL = ML * (ML + 1) / 2, ZERO = NP + 2 * NPL;
+constexpr int dpp_lo_cols() { return P <= 15 ? P : 8; }
+template <int P>
+__device__ __forceinline__ void group_stage_rows(const float4* stage, int j, c64* b, c32* a_hi, c32* a_lo) {
+    constexpr int NP = P * (P + 1) / 2, ZERO = 2 * NP;
     const auto isel = [](bool c, int x, int y) { return y + ((x - y) & -(int)c); };
     const int base_j = j * P - (j * (j - 1)) / 2 - j;                 // + c for c >= j
-    const int base_l = NP + j * ML - (j * (j - 1)) / 2 - j;
 #pragma unroll
     for (int c = 0; c < P; ++c) {
         const bool up = c >= j;
-        int idx = isel(up, base_j + c, (c * P - (c * (c - 1)) / 2 - c) + j);
-        int idl = ZERO;
-        if (ML > 0) {                                   // (uniform)
-            const int il = isel(up, base_l + c, NP + (c * ML - (c * (c - 1)) / 2 - c) + j);
-            const bool loc = (up ? c : j) < ML;
-            idx = isel(loc, il, idx);
-            if (c < DPP_LMAX) idl = isel(loc && j < P, il + NPL, ZERO);
-        }
-        idx = isel(j < P, idx, ZERO);
-        float4 v = stage[idx];
+        const int idx = isel(up, base_j + c, (c * P - (c * (c - 1)) / 2 - c) + j);
+        float4 v = stage[isel(j < P, idx, ZERO)];
+        float4 l = stage[isel(j < P, idx + NP, ZERO)];
         DISCO_CONSUME(v.y);                             // all four words are read, whatever the selects below keep
         DISCO_CONSUME(v.w);
+        DISCO_CONSUME(l.y);
+        DISCO_CONSUME(l.w);
         const float sg = c == j ? 0.f : (up ? 1.f : -1.f);
         a_hi[c] = make_float2(v.x, v.y * sg);
-        double bx = (double)v.z, by = (double)(v.w * sg);
-        if (c < DPP_LMAX) {                             // entries (j, c) with c >= M_loc read the zero word
-            float4 l = stage[idl];
-            DISCO_CONSUME(l.y);
-            DISCO_CONSUME(l.w);
-            a_lo[c] = make_float2(l.x, l.y * sg);
-            bx += (double)l.z;
-            by += (double)(l.w * sg);
-        }
-        b[c] = make_double2(bx, by);
+        if (c < dpp_lo_cols<P>()) a_lo[c] = make_float2(l.x, l.y * sg);
+        b[c] = make_double2((double)v.z + (double)l.z, (double)(v.w * sg) + (double)(l.w * sg));
     }
     DISCO_GROUP_SYNC();                                 // the block is reused (transposition of Y) once every lane has its rows
 }
@@ -159,10 +154,10 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(DppSolveGeom<P>::THREADS, 2) voi
 
     c32 rowA[P];                                        // row j of Rxx in float32: all that crosses the squarings (the Rayleigh quotient's)
     c64 a[P];                                           // row j of Rnn, then of its Cholesky factor
-    c32 rowA_lo[DPP_LMAX];                              // FROM_PART: the `lo` halves of its leading-block entries
+    c32 rowA_lo[dpp_lo_cols<P>()];                      // FROM_PART: the `lo` halves of its entries
     if constexpr (FROM_PART) {
         group_stage_part<P>(src, pid, j, live, reinterpret_cast<float4*>(Mm));
-        group_stage_rows<P>(reinterpret_cast<const float4*>(Mm), src.M_loc, j, a, rowA, rowA_lo);
+        group_stage_rows<P>(reinterpret_cast<const float4*>(Mm), j, a, rowA, rowA_lo);
 #pragma unroll
         for (int c = 0; c < P; ++c) a[c].x = (c == j && !live) ? 1.0 : a[c].x;           // a pencil that does not exist: Rxx = 0, Rnn = I
     } else {
@@ -216,7 +211,8 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(DppSolveGeom<P>::THREADS, 2) voi
     if constexpr (FROM_PART) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {                   // row j of Rxx in float64 from (hi, lo)
-            const double lx = i < DPP_LMAX ? (double)rowA_lo[i < DPP_LMAX ? i : 0].x : 0.0, ly = i < DPP_LMAX ? (double)rowA_lo[i < DPP_LMAX ? i : 0].y : 0.0;
+            constexpr int LC = dpp_lo_cols<P>();
+            const double lx = i < LC ? (double)rowA_lo[i < LC ? i : 0].x : 0.0, ly = i < LC ? (double)rowA_lo[i < LC ? i : 0].y : 0.0;
             g[i] = make_double2((double)rowA[i].x + lx, -((double)rowA[i].y + ly));
         }
     } else {

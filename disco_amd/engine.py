@@ -225,11 +225,11 @@ class Engine:
         return hw, ref
 
     def selftest_room(self, src):
-        """src (n,) float32, n a multiple of 256 -> (out_hw, out_ref), each (n // 4, 4) float32: the LDS-DMA loads and permlane swaps of
+        """src (n,) float32, n a multiple of 256 -> (out_hw, out_ref), each (n // 4, 6) float32: the LDS-DMA loads and permlane swaps of
         csrc/k_room.h through their instructions and through plain statements (include/disco_hip.h)."""
         n = src.shape[0]
         ps, ks = self.to_device(src, np.float32)
-        hw, ref = self.empty((n // 4, 4), np.float32), self.empty((n // 4, 4), np.float32)
+        hw, ref = self.empty((n // 4, 6), np.float32), self.empty((n // 4, 6), np.float32)
         self._chk(self.lib.disco_selftest_room(self.ctx, ps, n, hw.ptr, ref.ptr, self.stream))
         return hw, ref
 

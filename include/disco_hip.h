@@ -471,9 +471,9 @@ int disco_selftest_dpp(disco_ctx* ctx, const double* a, const double* b, int64_t
 
 /* Self-test of the asm primitives of the persistent room pass (disco_amd/csrc/k_room.h; no reference counterpart): the LDS-DMA loads
  * (global_load_lds_dwordx4 / _dword behind the M0 save / set / restore) + the wait for them against plain loads, and the lane-level
- * 2 x 2 transposes (v_permlane32_swap / v_permlane16_swap + add) against their __shfl_xor statement.  src: [n] float, n a multiple of
+ * 2 x 2 transposes (v_permlane32_swap / v_permlane16_swap + add, on float32 and on float64 values) against their __shfl_xor statement.  src: [n] float, n a multiple of
  * 256 -> out_hw, out_ref: [n / 4][DISCO_ROOM_SELFTEST_OPS] float (one row per lane).  Bit equality is what is asserted.  ctx may be NULL. */
-#define DISCO_ROOM_SELFTEST_OPS 4
+#define DISCO_ROOM_SELFTEST_OPS 6
 int disco_selftest_room(disco_ctx* ctx, const float* src, int64_t n, float* out_hw, float* out_ref, disco_stream s);
 
 #define DISCO_PK_SELFTEST_OPS 23

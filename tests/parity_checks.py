@@ -942,7 +942,7 @@ def check_pk_selftest(make_engine, n=4096, seed=11):
 
 
 def check_room_selftest(make_engine, n=4096, seed=17):
-    """csrc/k_room.h: lds_dma16 / lds_dma4 + vm_wait_all and lane_swap_add<32 / 16> through their instruction forms (on the emulated build:
+    """csrc/k_room.h: lds_dma16 / lds_dma4 + vm_wait_all, lane_swap_add<32 / 16> and lane_swap_add64<32 / 16> through their instruction forms (on the emulated build:
     their C++ twins) must equal plain loads / the __shfl_xor statement bit for bit, and mean what they say (NumPy)."""
     rng = np.random.default_rng(seed)
     src = rng.standard_normal(n).astype(np.float32)
@@ -957,8 +957,17 @@ def check_room_selftest(make_engine, n=4096, seed=17):
     a, b = blk[:, :64], blk[:, 64:128]
     want = np.stack([g[..., 0] + np.float32(2) * g[..., 1] + np.float32(3) * g[..., 2] + np.float32(5) * g[..., 3], blk[:, perm],
                      np.where(lane & 32, b[:, lane ^ 32] + b, a + a[:, lane ^ 32]), np.where(lane & 16, b[:, lane ^ 16] + b, a + a[:, lane ^ 16])], axis=-1)
-    err = float(np.abs(hw.reshape(-1, 64, 4) - want).max())
+    err = float(np.abs(hw.reshape(-1, 64, 6)[..., :4] - want).max())
     assert err < 1e-5, err
+    # rows 4, 5: the float64 swaps (lane_swap_add64), operands da = a (1 + 2^-23) + 1e-9 b, db = b (1 - 2^-23) - 1e-9 a; head + 1e6 x remainder
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    da, db = a64 * 1.0000001192092896 + b64 * 1e-9, b64 * 0.9999998807907104 - a64 * 1e-9
+    for row, bit in ((4, 32), (5, 16)):
+        d = np.where(lane & bit, db[:, lane ^ bit] + db, da + da[:, lane ^ bit])
+        h = d.astype(np.float32)
+        w64 = ((d - h.astype(np.float64)).astype(np.float32) * np.float32(1e6) + h)
+        e64 = float(np.abs(hw.reshape(-1, 64, 6)[..., row] - w64).max())
+        assert e64 < 1e-5, (row, e64)
     return err
 
 

@@ -4,7 +4,7 @@ GPU lane forms them -- `chunks` time chunks per node, inside a chunk sequential 
 frames that were themselves summed sequentially from zero, chunks combined in float64, rounded to complex64 -- per block class:
     s1     the M x M statistics of step 1 (also the leading block of every step-2 pencil: SKIPLOC)
     cross  the y-z entries of step 2,   zz  the z-z entries of step 2
-Usage: python tools/exp_c5_accum2.py <room> s1=<c>:<b>[u]|x|d cross=... zz=...      (x = exact sums rounded to complex64; d = exact sums in
+Usage: python tools/exp_c5_accum2.py <room> s1=<c>:<b>[u]|x|d cross=... zz=...      (x = exact sums rounded to complex64; r = float64 sums of the complex64-ROUNDED rows; d = exact sums in
 float64, unrounded; a trailing u = the float32 partial sums combined in float64 and handed over unrounded)
 Results: profiles/r04_c5_accumulation.txt"""
 import os
@@ -40,7 +40,7 @@ def emul(Vt, chunks, block, rounded=True):
         tot += acc
     return (tot / T).astype(np.complex64).astype(np.complex128) if rounded else tot / T
 
-def emul_sub(Vt, sub, rounded=False):
+def emul_sub(Vt, sub, rounded=False, f64_tree=False):
     """the room pass's order (k_room.h): `sub` interleaved float32 accumulators (frame t goes to accumulator t % sub, each sums its frames
     sequentially), combined pairwise in float32 (the lane-level halvings), ONE block: handed to the solver as it is."""
     F, T, P = Vt.shape
@@ -48,6 +48,8 @@ def emul_sub(Vt, sub, rounded=False):
     acc = [np.zeros((F, P, P), np.complex64) for _ in range(sub)]
     for t in range(T):
         acc[t % sub] += V32[:, t, :, None] * np.conjugate(V32[:, t, None, :])
+    if f64_tree:
+        acc = [sum(a.astype(np.complex128) for a in acc)]
     while len(acc) > 1:
         h = len(acc) // 2
         acc = [acc[i] + acc[i + h] for i in range(h)]
@@ -76,9 +78,14 @@ def cov(V, ref32):
             return exact
         if sp == 'd':                      # round 5: float64 sums handed to the solver UNROUNDED ((hi, lo) at the solver's door)
             return exact64
+        if sp == 'r':                      # inputs rounded to complex64 (the spectra and z the GPU holds), products and sums in float64, unrounded
+            if 'r' not in cache:
+                V64 = Vt.astype(np.complex64).astype(np.complex128)
+                cache['r'] = np.einsum('ftp,ftq->fpq', V64, np.conjugate(V64)) / T
+            return cache['r']
         if sp.startswith('s'):             # "sN": N interleaved accumulators, float32 tree, one block (the room pass)
-            if sp not in cache:
-                cache[sp] = emul_sub(Vt, int(sp[1:]))
+            if sp not in cache:                # "sNu": the N accumulators combined in FLOAT64 and handed over unrounded ((hi, lo) blocks)
+                cache[sp] = emul_sub(Vt, int(sp[1:].rstrip('u')), f64_tree=sp.endswith('u'))
             return cache[sp]
         if sp not in cache:
             unrounded = sp.endswith('u')   # "c:bu": float32 partial sums combined in float64 and NOT rounded to complex64
