@@ -83,8 +83,9 @@ extern "C" int disco_gevd_mwf_r1_pending(disco_ctx* ctx, float mu, disco_c32* w,
     src.F = ctx->F;
     src.chunks = ctx->pending_chunks;
     // The partial sums go to the solvers UNSCALED (round 5): w and t1 do not change when Rxx and Rnn are scaled together, and without the
-    // multiplication by 1 / T an entry that arrives as one float32 block (the fused step-2 pass and the room pass leave one block per node)
-    // reaches the float64 arithmetic exactly as it was summed; a product with 1 / T cost every entry a rounding (k_solve_dpp.h)
+    // multiplication by 1 / T an entry that arrives as one float32 block (the fused step-2 pass leaves one block per node) or as the (hi, lo)
+    // pair of a float64 total (k_cov_loc_f64, the room pass) reaches the float64 arithmetic exactly as it was summed; a product with 1 / T
+    // cost every entry a rounding (k_solve_dpp.h)
     src.inv_T = 1.0f;
     src.part_loc = ctx->pending_skiploc ? (const float4*)ctx->scratch : nullptr;
     src.chunks_loc = ctx->pending_skiploc ? ctx->loc_chunks : 0;
