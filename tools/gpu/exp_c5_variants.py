@@ -1,6 +1,6 @@
 """C5 (200 rooms x 8 x 8, 1024-pt, 2 iterations) on ONE batch under several kernel routes: ms per step, stage times, and the error of sampled
 rooms against the float64 oracle (computed once, in worker processes, while the GPU runs the variants).  Test / measurement tooling.
-Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [sample=0,100,199 | spread:N] [variants=_:_:cov_chunks:wide,... (the first two fields named round 4's room_sub / cov1_mode options, removed in round 5)  wide: -1 = disco_apply + disco_istft, 0 = one-pass filter + iSTFT, n > 0 = that with n frame pairs per run] [sample=0,100,199]"""
+Usage: python tools/gpu/exp_c5_variants.py out.json [rooms=200] [sample=0,100,199 | spread:N] [variants=_:_:cov_chunks:wide,... (the first two fields named round 4's room_sub / cov1_mode options, removed in round 5)  wide: -1 = disco_apply + disco_istft, 0 = one-pass filter + iSTFT, n > 0 = that with n frame pairs per run] [sample=0,100,199] [workers=N oracle processes (default: one per sampled room, up to the host's cores)]"""
 import json
 import os
 import sys
@@ -41,7 +41,7 @@ def main():
     dev = torch.device('cuda:0')
     eng = Engine(rooms=R, nodes=K, mics=M, length=L, n_fft=N, device=0)
     y, s_ref, n_ref = synth.make_rooms_torch(R, K, M, L, first_room=0, device=dev, ref_only_sn=True)
-    pool = ProcessPoolExecutor(max_workers=max(1, min(len(sample), (os.cpu_count() or 8) - 1)))
+    pool = ProcessPoolExecutor(max_workers=max(1, min(len(sample), int(kv.get('workers', 0)) or (os.cpu_count() or 8) - 1)))
     futs = {r: pool.submit(oracle_room, (y[r].cpu().numpy(), s_ref[r].cpu().numpy(), n_ref[r].cpu().numpy(), N, iters)) for r in sample}
     T, F = eng.T, eng.F
     mask = torch.empty((R, K, T, F), dtype=torch.float32, device=dev)
