@@ -61,7 +61,7 @@ EXTRAS = {
     'C2x4000': (dict(CONFIGS['C2'], rooms=4000), 5, 2, 4),
     'online1': (dict(CONFIGS['C3'], online_every=1), 2, 1, 3),
     'C5': (dict(CONFIGS['C5']), 5, 2, 8),       # round 5: 8 of the 200 rooms (an 8 x 8 room costs the oracle ~11 s on one core)
-    'C4': (dict(CONFIGS['C4']), 3, 1, 4),
+    'C4': (dict(CONFIGS['C4']), 3, 1, 32),      # 32 of the 125 rooms (a 4 x 4 room costs the oracle ~1 s); ill-posed instances classified (ILL_POSED_WEIGHT)
     'C4_bf16': (dict(CONFIGS['C4'], dnn_dtype='bf16'), 3, 1, 2),      # the networks' convolutions / GEMMs on bf16 operands (explicit switch)
 }
 
@@ -223,7 +223,30 @@ def parity_job(kind, room, yr, sr, nr, got, k0, n_fft, iters, masks=None):
     e = 0.0
     for kl in range(got.shape[0]):
         e = max(e, float(np.linalg.norm(got[kl] - refs[kl]) / np.linalg.norm(refs[kl])))
+    if kind == 'masks':
+        return int(room), e, min_statistic_weight(masks)
     return int(room), e
+
+
+# A pencil (Rss, Rnn) of a bin is built from the frames weighted m^2 and (1 - m)^2 (tango.py:369-374).  A PREDICTED mask that saturates in every
+# frame of a bin leaves one of the two statistics without frames -- sum_t m^2 or sum_t (1 - m)^2 numerically zero: a singular pencil, a problem
+# without a well-defined answer.  On C4's random-weight masks (output layer spread x 40) 13 of the 125 rooms have such a bin; the float64 oracle
+# itself moves by 1.5e-4 ... 3.3e-3 on them when every float32 mask value moves by ONE rounding, the oracle in the reference's own dtype is 30 - 80 %
+# away from it, and 7 of them sit beyond the 1e-4 bar (up to 2.5e-2) while the other 112 rooms are all within 5.7e-5
+# (profiles/r05_p_c4_conditioning_*.json, tools/gpu/exp_c4_conditioning.py).  The check therefore CLASSIFIES the instance from the masks alone --
+# the smallest total weight a statistic gets in any (step, node, bin), in units of one frame's weight -- and asserts the bar on the well-posed
+# rooms; the others are reported with their error and their weight, not asserted.
+ILL_POSED_WEIGHT = 1e-4
+
+
+def min_statistic_weight(masks):
+    import numpy as np
+    w = np.inf
+    for ms in masks:
+        for m in ms:                                       # (F, T)
+            m = np.asarray(m, np.float64)
+            w = min(w, float((m * m).sum(axis=-1).min()), float(((1.0 - m) ** 2).sum(axis=-1).min()))
+    return w
 
 
 def rank_sample_rooms(rank, R, n_rank0):
@@ -251,7 +274,7 @@ def merge_parity(local, per_rank_rows, tol):
 def gather_rank_rows(rank, world, device_index, first_room, rooms_global, worst, dist, dev, gloo=False):
     """All-gather of every rank's (device, first room, checked rooms, worst error) as one fixed-size float64 row."""
     import torch
-    row = [float(rank), float(device_index), float(first_room), float(len(rooms_global))] + [float(x) for x in rooms_global[:4]]
+    row = [float(rank), float(device_index), float(first_room), float(min(len(rooms_global), 4))] + [float(x) for x in rooms_global[:4]]
     row += [-1.0] * (8 - len(row)) + [float(worst)]
     if world == 1:
         rows = [row]
@@ -410,10 +433,13 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
         # random weights leave every mask within a few percent of 0.5, i.e. Rss ~ Rnn in every bin: a degenerate eigenproblem whose
         # dominant vector no two implementations agree on.  Spreading the output layer (as tests/test_gpu_crnn_inloop.py does) gives
         # masks over (0, 1) like a trained network's, at identical cost.
+        clip = float(os.environ.get('DISCO_BENCH_CRNN_CLIP', 0.0))
         with torch.no_grad():
             for mdl in (model_z, model_w):
                 if mdl is not None:
-                    mdl.ff.layers[0].weight.mul_(40.0)
+                    mdl.ff.layers[0].weight.mul_(float(os.environ.get('DISCO_BENCH_CRNN_SPREAD', 40.0)))
+                    if clip > 0:
+                        mdl.predict_masks = (lambda orig: lambda *a_, **k_: orig(*a_, **k_).clamp_(clip, 1.0 - clip))(mdl.predict_masks)
 
     gather_events = []                     # (start, stop) torch events around every all-gather of z (--shard nodes)
 
@@ -751,12 +777,18 @@ def stream_bench(eng, lib, torch, y, mask, update_every, H, F, chunk_hops=(1, 4,
 def finish_parity(ticket, env, timeout=900.0):
     """Wait for this rank's oracle jobs of one workload, then merge over the ranks -> parity_sample object (same on every rank)."""
     rank, world = env['rank'], env['world']
-    per_room, worst, err = {}, 0.0, None
+    per_room, worst, err, ill = {}, 0.0, None, {}
     for fut in ticket['jobs']:
+        minw = None
         try:
-            room, e = fut.result(timeout=timeout)
+            res_ = fut.result(timeout=timeout)
+            room, e = res_[0], res_[1]
+            minw = res_[2] if len(res_) > 2 else None
         except Exception as ex:                            # a checker that cannot run is a failed check, not a silent pass
             room, e, err = -1, float('inf'), repr(ex)
+        if minw is not None and minw < ILL_POSED_WEIGHT and e == e and e != float('inf'):
+            ill[int(room)] = {'rel': e, 'min_statistic_weight': minw}         # reported, not asserted (see ILL_POSED_WEIGHT)
+            continue
         per_room[int(room)] = e
         worst = max(worst, e)
     if not ticket['finite']:
@@ -765,6 +797,9 @@ def finish_parity(ticket, env, timeout=900.0):
     ps = merge_parity({'rooms': ticket['rooms_global'], 'per_room': per_room, 'worst_rel': worst}, rows, ticket['tol'])
     if err:
         ps['error'] = err
+    if ill:
+        ps['ill_posed'] = {'rooms': ill, 'criterion': f'a (step, node, bin) whose speech or noise statistic has a total weight below {ILL_POSED_WEIGHT:g} of one '
+                           "frame's (sum_t m^2 or sum_t (1 - m)^2 of the PREDICTED masks): a singular pencil; reported, not asserted -- bench.py ILL_POSED_WEIGHT"}
     return ps
 
 
@@ -801,8 +836,11 @@ def summary_rows(head_name, head, head_parity, extras):
             out.append({'stream_x_realtime_by_hops': {k: v.get('x_realtime') for k, v in r['stream'].get('chunks', {}).items()}})
         if 'graph' in r:        # the same step as one hipGraph replay: [ms_per_step, pipeline_frac]
             out.append({'hipgraph': [r['graph'].get('ms_per_step'), r['graph'].get('pipeline_frac')]})
+        if ps and ps.get('ill_posed'):      # rooms whose PREDICTED masks leave a statistic without frames: reported, not asserted (ILL_POSED_WEIGHT)
+            ip = ps['ill_posed']['rooms']
+            out.append({'ill_posed_rooms': [len(ip), len(ps.get('per_room', {})) + len(ip)], 'their_worst_rel': float('%.3g' % max(v['rel'] for v in ip.values()))})
         return out
-    rows = {'_cols': 'ms_per_step, x_realtime, pipeline_frac, dominant_kernel, dominant_frac_of_peak, traffic/alg_bytes, parity_worst_rel[, {stream x_realtime by chunk hops}][, {hipgraph: [ms_per_step, pipeline_frac]}]',
+    rows = {'_cols': 'ms_per_step, x_realtime, pipeline_frac, dominant_kernel, dominant_frac_of_peak, traffic/alg_bytes, parity_worst_rel[, {stream x_realtime by chunk hops}][, {hipgraph: [ms_per_step, pipeline_frac]}][, {ill_posed_rooms: [n, of sampled], their_worst_rel}]',
             head_name: row(head, head_parity)}
     for nm, r in extras.items():
         rows[nm] = row(r, r.get('parity_sample')) if 'error' not in r else 'error'

@@ -1,0 +1,14 @@
+"""A bench line's parity_sample -> {rooms, worst, median, histogram, the five worst rooms} (+ per_room), for sweeps with a large --parity-rooms.
+Usage: python tools/gpu/parity_hist.py line.json out.json"""
+import json
+import sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+ps = d['parity_sample']
+per = {int(r): e for r, e in ps['per_room'].items()}
+errs = sorted(per.values())
+edges = [0, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 1e9]
+out = {'workload': d['config']['workload'], 'ms_per_step': d['ms_per_step'], 'rooms_checked': len(errs), 'worst': errs[-1], 'median': errs[len(errs) // 2],
+       'histogram_edges': edges[1:-1], 'histogram': [sum(1 for e in errs if lo <= e < hi) for lo, hi in zip(edges[:-1], edges[1:])],
+       'worst_rooms': sorted(per, key=per.get, reverse=True)[:5], 'tol': ps['tol'], 'ok': ps['ok'], 'oracle': ps['oracle'], 'per_room': per}
+json.dump(out, open(sys.argv[2], 'w'))
+print({k: v for k, v in out.items() if k not in ('per_room', 'oracle')})
