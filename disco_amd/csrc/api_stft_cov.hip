@@ -36,13 +36,20 @@ static bool launch_stft_cov(int M, dim3 grid, hipStream_t st, const float* y, co
 }
 
 // frame chunks (= workgroups per node) of the fused STFT + covariance pass and the frames each of its waves streams: runs as long
-// as possible (<= 80 frames) while leaving >= ~2048 workgroups for the chip
+// as possible while leaving >= ~2048 workgroups for the chip, but NOT LONGER THAN DISCO_STFT_COV_RUN frames: a workgroup's fold sums the
+// frames of its four waves' runs in float32, and the length of that sum is what the distance of the C3 output from the float64 oracle follows
+// (the whole-batch sweep's worst room of 1000, output against the oracle: 4.1e-5 at 80 frames per wave, 2.3e-5 at 40, 1.3e-5 at 20 -- every room halves
+// with the run, profiles/r05_t_runw_parity.txt), while the pass itself is as fast at 40 or 20 as at 80 (profiles/r05_t_runw_speed.txt); what
+// more blocks cost is the solvers' fetch (k_solve_small.h: four blocks of an entry in flight together).
+#ifndef DISCO_STFT_COV_RUN
+#define DISCO_STFT_COV_RUN 40
+#endif
 namespace disco_host {
 int stft_cov_chunks(const disco_ctx* ctx, int* runw_out) {
     const long long G = (long long)ctx->geom_rooms * ctx->cfg.nodes;
     const long long chunks_wanted = std::max<long long>(1, (2048 + G - 1) / G);
     int runw = (int)((ctx->T + STFT_WAVES * chunks_wanted - 1) / (STFT_WAVES * chunks_wanted));
-    runw = std::min(80, std::max(8, runw));
+    runw = std::min(DISCO_STFT_COV_RUN, std::max(8, runw));
     if (ctx->tune_runw > 0) runw = ctx->tune_runw;
     if (runw_out) *runw_out = runw;
     return (ctx->T + STFT_WAVES * runw - 1) / (STFT_WAVES * runw);

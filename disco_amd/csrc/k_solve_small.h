@@ -450,6 +450,9 @@ __device__ __forceinline__ void gevd_solve_thread(const float* a_d, const c32* a
     gevd_solve_thread_acc<P, (P >= 6), SQ32>([&](float* d, c32* o) { copy(a_d, a_o, d, o); }, [&](float* d, c32* o) { copy(b_d, b_o, d, o); }, mu, w, t1);
 }
 
+#ifndef DISCO_SOLVE_LOAD_GROUP
+#define DISCO_SOLVE_LOAD_GROUP 4        // partial blocks of an entry fetched together by k_gevd_mwf_r1_thread's loader
+#endif
 // threads per workgroup: two waves, one for the larger pencils (the wave-cooperative fetch stages 64 * NP float4 per wave in LDS)
 template <int P>
 constexpr int solve_small_threads() { return P <= 6 ? 128 : 64; }
@@ -498,18 +501,23 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(solve_small_threads<P>()) void k
             const float4* ptr = loc ? src.part_loc + o_loc + (r * ML - (r * (r - 1)) / 2 + (c - r)) : src.part + o_main + q;
             const long long stride = loc ? (long long)src.F * NPL : (long long)src.F * NP;
             const int nch = loc ? src.chunks_loc : src.chunks;
-            // the first two blocks unconditionally (the second one weighed 0 when there is none: clamped address), so that the loads of
-            // ALL entries of the unrolled loop are independent and in flight together; further blocks, rare, in a loop
-            const float4 v0 = ptr[0], v1 = ptr[nch > 1 ? stride : 0];
-            const double m1 = nch > 1 ? 1.0 : 0.0;
-            double sx = (double)v0.x + m1 * (double)v1.x, sy = (double)v0.y + m1 * (double)v1.y;
-            double sz = (double)v0.z + m1 * (double)v1.z, sw = (double)v0.w + m1 * (double)v1.w;
-            for (int ch = 2; ch < nch; ++ch) {
-                const float4 v = ptr[ch * stride];
-                sx += (double)v.x;
-                sy += (double)v.y;
-                sz += (double)v.z;
-                sw += (double)v.w;
+            // Blocks in groups of FOUR, every load of a group unconditional (a block that does not exist re-reads block 0 and is weighed 0), so
+            // that the loads of ALL entries of the unrolled loop are independent and in flight together: the fused STFT + covariance pass
+            // leaves 4 blocks per node at BASELINE's batch sizes (runs of 40 frames per wave: the length of its float32 sums is what C3's
+            // distance from the float64 oracle follows, profiles/r05_t_*); a block count beyond 4 takes another round of the loop.
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+            for (int c0 = 0; c0 < nch; c0 += DISCO_SOLVE_LOAD_GROUP) {
+                float4 v[DISCO_SOLVE_LOAD_GROUP];
+#pragma unroll
+                for (int u = 0; u < DISCO_SOLVE_LOAD_GROUP; ++u) v[u] = ptr[(c0 + u < nch ? c0 + u : 0) * stride];
+#pragma unroll
+                for (int u = 0; u < DISCO_SOLVE_LOAD_GROUP; ++u) {
+                    const double m = c0 + u < nch ? 1.0 : 0.0;
+                    sx += m * (double)v[u].x;
+                    sy += m * (double)v[u].y;
+                    sz += m * (double)v[u].z;
+                    sw += m * (double)v[u].w;
+                }
             }
             s_tile[wv][e] = make_float4((float)(sx * it), (float)(sy * it), (float)(sz * it), (float)(sw * it));
         }
