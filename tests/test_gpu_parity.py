@@ -186,10 +186,10 @@ def test_tango_end_to_end_vs_oracle(make_engine, K, M, L, n_fft, staged):
     print(K, M, L, n_fft, staged, errs)
 
 
-# The launch geometry bench.py's headline run takes (R*K = 4000: 80 frames per STFT wave -> 2 chunks with a short last wave,
-# single-chunk covariances, 64 frame pairs per filter+iSTFT workgroup), pinned on small batches; plus geometries whose tails
-# fall differently (empty waves, one-frame last chunks).
-@pytest.mark.parametrize('R,K,M,L,n_fft,tuning', [(2, 4, 4, 160000, 512, (80, 1, 1, 64)), (1, 4, 4, 160000, 512, (80, 1, 1, 64)),
+# The launch geometry bench.py's headline run takes (R*K = 4000: 40 frames per STFT wave -> 4 chunks with a short last one -- 80 frames and
+# 2 chunks until late round 5 --, single-chunk covariances, 64 frame pairs per filter+iSTFT workgroup), pinned on small batches; plus
+# geometries whose tails fall differently (empty waves, one-frame last chunks).
+@pytest.mark.parametrize('R,K,M,L,n_fft,tuning', [(2, 4, 4, 160000, 512, (40, 1, 1, 64)), (2, 4, 4, 160000, 512, (80, 1, 1, 64)), (1, 4, 4, 160000, 512, (80, 1, 1, 64)),
                                                  (2, 4, 4, 25700, 512, (80, 1, 1, 64)), (2, 2, 3, 160000, 512, (79, 1, 1, 63)),
                                                  (2, 4, 4, 82000, 512, (40, 2, 3, 20)), (1, 2, 2, 80000, 1024, (80, 1, 1, 0)),
                                                  (2, 1, 4, 160000, 512, (80, 1, 1, 64))])
