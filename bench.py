@@ -451,7 +451,7 @@ def run_workload(name, w, steps, warmup, env, headline, n_parity_rank0, args):
             return
         eng._chk(lib.disco_mask_oracle(eng.ctx, s_ref.data_ptr(), n_ref.data_ptr(), G, mask.data_ptr(), None))
         if node_sharded:
-            ns.tango_enhance_node_sharded_torch(eng, y, mask, mask, iters=iters, out=out, gather_events=gather_events)
+            ns.tango_enhance_node_sharded_torch(eng, y, mask, mask, iters=iters, out=out, gather_events=gather_events, want_yf=False)
             return
         if online_every > 0:
             eng._chk(lib.disco_tango_online(eng.ctx, y.data_ptr(), mask.data_ptr(), mask.data_ptr(), 0.95, online_every,

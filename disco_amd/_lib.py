@@ -73,6 +73,7 @@ PROTOTYPES = {
     'disco_step2_cov_fused_reuse': (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_apply_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_step2_apply_istft_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    'disco_apply_istft_fused': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'disco_tango_enhance': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'disco_mask_ivad': (_int, [_vp, _vp, _i64, _vp, _vp]),
     'disco_rir_convolve': (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _int, _vp]),

@@ -475,6 +475,9 @@ struct ApplyIstftWideArgs {
     c32* yf;             // [R][K][T][F] or NULL (only when the caller wants the filtered spectra)
     int T, L, pairs, chunks;
     long long R;
+    // a node shard (disco_set_node_shard / disco_set_z_blocks): X, w, out, yf hold the Kl nodes [k0, k0 + Kl) of every room, Z the z of ALL K
+    // nodes in planes [K / zblk][R][zblk] (z_plane, common.h); the whole room: Kl = K, k0 = 0, zblk = K
+    int Kl, k0, zblk;
 };
 template <int N, int M, int KR>
 struct alignas(16) ApplyIstftWideShared {
@@ -503,14 +506,15 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * (N / 128 + N / 256), 1) voi
     __shared__ Sh sh;
     const int wv = wave_id(), lane = threadIdx.x & 63;
     const int T = a.T;
-    const long long n_items = a.R * K * (long long)a.chunks;
+    const long long n_items = a.R * a.Kl * (long long)a.chunks;
     long long item = (long long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
     if (item >= n_items) return;
-    const int k = (int)(item % K);
-    item /= K;
+    const int kl = (int)(item % a.Kl);
+    item /= a.Kl;
     const long long r = item % a.R;
     const int chunk = (int)(item / a.R);
-    const long long g = r * K + k;
+    const int k = a.k0 + kl;                                                 // the node's place in its room (which z rows are remote)
+    const long long g = r * a.Kl + kl;
     const int run_len = 2 * a.pairs - 1;
     const int s_base = chunk * NR * run_len;                                 // run u starts at frame (= hop segment) s_base + u * run_len
     const long long TF = (long long)T * F;
@@ -546,7 +550,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * (N / 128 + N / 256), 1) voi
 #pragma unroll
         for (int jj = 0; jj < KR; ++jj) {
             wr[jj] = make_float2(wf[M + jj].x, -1.f * wf[M + jj].y);
-            zrow[jj] = a.Z + (r * K + (jj < k ? jj : jj + 1)) * TF;
+            zrow[jj] = a.Z + z_plane(r, jj < k ? jj : jj + 1, K, a.R, a.zblk) * TF;
         }
         // granule r * 64 + lane of the tile's frame = (bin b, granule lane % MH); LDS position of that granule (k_apply_mq)
         int lgo[MH], lpos[MH];
@@ -580,7 +584,7 @@ __global__ DISCO_KERNEL_ALIGN __launch_bounds__(64 * (N / 128 + N / 256), 1) voi
         const bool n_ld = lane < NL, n_isx = lane < MH;
         const int n_jj = max(lane - MH, 0);
         const float* n_src = n_isx ? reinterpret_cast<const float*>(Xq + (long long)(F - 1) * MH + lane)
-                                   : reinterpret_cast<const float*>(a.Z + (r * K + (n_jj < k ? n_jj : n_jj + 1)) * TF + (F - 1));
+                                   : reinterpret_cast<const float*>(a.Z + z_plane(r, n_jj < k ? n_jj : n_jj + 1, K, a.R, a.zblk) * TF + (F - 1));
         const long long n_stride = n_isx ? (long long)F * M * 2 : (long long)F * 2;        // floats per frame
         fetch(0, 0, 0);
         fetch(0, 0, 1);

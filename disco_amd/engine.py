@@ -409,11 +409,17 @@ class Engine:
                                             {'r1-mwf': 1, 'mwf': 2}[type], w.ptr, self.stream))
         return w
 
-    def gevd_mwf_r1_pending(self, P, mu=None, want_t1=False):
-        """Solve straight from the partial sums the last covariance call left in the context."""
-        w = self.empty((self.R, self.Kl, self.F, P), np.complex64)
+    def gevd_mwf_r1_pending(self, P, mu=None, want_t1=False, out=None):
+        """Solve straight from the partial sums the last covariance call left in the context.
+        out: optional caller-owned (R, Kl, F, P) complex64 device array (DevBuf or torch tensor) for the filters."""
+        if out is None:
+            w = self.empty((self.R, self.Kl, self.F, P), np.complex64)
+        else:
+            assert tuple(out.shape) == (self.R, self.Kl, self.F, P) and not isinstance(out, np.ndarray)
+            w = out
+        pw, kw = self.to_device(w, np.complex64)
         t1 = self.empty((self.R, self.Kl, self.F, P), np.complex64) if want_t1 else None
-        self._chk(self.lib.disco_gevd_mwf_r1_pending(self.ctx, self.cfg.mu if mu is None else mu, w.ptr,
+        self._chk(self.lib.disco_gevd_mwf_r1_pending(self.ctx, self.cfg.mu if mu is None else mu, pw,
                                                      t1.ptr if want_t1 else None, self.stream))
         return w, t1
 
@@ -432,12 +438,38 @@ class Engine:
         self._chk(self.lib.disco_apply(self.ctx, px, pz, pw, P, int(bool(conj)), po, self.stream))
         return out
 
-    def filter_head(self, w_glo):
-        """w_glo (R, Kl, F, P) -> its local part (R, Kl, F, M): the re-compression filter of the iterated scheme."""
+    def apply_istft(self, X, w, Z, out=None, yf_out=None):
+        """iSTFT(w^H [X ; Z_-k]) in ONE pass (disco_apply_istft_fused: `apply` followed by `istft` with the filtered spectra kept on chip)
+        -> (R, Kl, L) float32, or None when the kernel is not built for this (mics, nodes) shape (the caller then runs the two calls).
+        yf_out: optional caller-owned (R, Kl, T, F) complex64 device array that also receives the filtered spectra."""
+        px, kx = self.to_device(X, np.complex64)
+        pz, kz = self.to_device(Z, np.complex64)
+        pw, kw = self.to_device(w, np.complex64)
+        if out is None:
+            out = self.empty((self.R, self.Kl, self.Lsamp), np.float32)
+        else:
+            assert int(np.prod(tuple(out.shape))) == self.R * self.Kl * self.Lsamp and not isinstance(out, np.ndarray)
+        po, ko = self.to_device(out, np.float32)
+        pyf, kyf = (None, None) if yf_out is None else self.to_device(yf_out, np.complex64)
+        rc = self.lib.disco_apply_istft_fused(self.ctx, px, pz, pw, pyf, po, self.stream)
+        if rc == -2:                                              # DISCO_E_UNSUPPORTED: shape not built
+            return None
+        self._chk(rc)
+        return out
+
+    def filter_head(self, w_glo, out=None):
+        """w_glo (R, Kl, F, P) -> its local part (R, Kl, F, M): the re-compression filter of the iterated scheme.
+        out: optional caller-owned device array for it."""
         P = int(w_glo.shape[-1])
         pw, kw = self.to_device(w_glo, np.complex64)
-        w_loc = self.empty((self.R, self.Kl, self.F, self.M), np.complex64)
-        self._chk(self.lib.disco_filter_head(self.ctx, pw, P, w_loc.ptr, self.stream))
+        if out is None:
+            w_loc = self.empty((self.R, self.Kl, self.F, self.M), np.complex64)
+            po = w_loc.ptr
+        else:
+            assert tuple(out.shape) == (self.R, self.Kl, self.F, self.M) and not isinstance(out, np.ndarray)
+            w_loc = out
+            po, ko = self.to_device(out, np.complex64)
+        self._chk(self.lib.disco_filter_head(self.ctx, pw, P, po, self.stream))
         return w_loc
 
     def noise_residual(self, X, z):

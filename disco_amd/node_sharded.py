@@ -21,7 +21,8 @@ def node_range(rank, world, K):
     return rank * kl, kl
 
 
-def _steps(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather_begin, gather_end, yf_out=None, out=None, z_shape=None, X_out=None):
+def _steps(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather_begin, gather_end, yf_out=None, out=None, z_shape=None, X_out=None,
+           want_yf=True, w_bufs=None):
     """The data flow of one (half-)batch as a GENERATOR: it yields right after every all-gather has been STARTED (gather_begin(z_local) ->
     handle) and finishes it (gather_end(handle) -> z of ALL nodes) when resumed -- so a driver that holds two half-batches can run one
     half's local kernels while the other half's exchange is on the links (tango_enhance_node_sharded_torch).  Returns, through
@@ -39,7 +40,10 @@ def _steps(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather_begin,
     X, _, _ = eng.stft_cov_fused(y_local, mask_z_local, X_out=X_out, want_cov=False)
     if hasattr(X, 'reshape'):
         X = X.reshape(R, Kl, eng.T, eng.F, M)
-    w_loc, _ = eng.gevd_mwf_r1_pending(M)
+    # w_bufs: caller-owned device arrays (w_loc (R, Kl, F, M), w_glo (R, Kl, F, M + K - 1)) -- a DevBuf per solve is a hipMalloc + hipFree per
+    # step, and hipFree waits for the device
+    wb_loc, wb_glo = w_bufs if w_bufs is not None else (None, None)
+    w_loc, _ = eng.gevd_mwf_r1_pending(M, out=wb_loc)
     z_all = w_glo = None
     for it in range(iters):
         z_loc = eng.apply(X, w_loc, out=z_out)
@@ -53,10 +57,19 @@ def _steps(eng, y_local, mask_z_local, mask_w_local, iters, z_out, gather_begin,
             eng.cov_masked(X, mask_w_local, z_all, z_all, mask_remote=True, Rss_out=False)
         else:
             eng.cov_masked(X, mask_w_local, Rss_out=False)
-        w_glo, _ = eng.gevd_mwf_r1_pending(M + eng.K - 1)
+        w_glo, _ = eng.gevd_mwf_r1_pending(M + eng.K - 1, out=wb_glo)
         if it + 1 < iters:
             # DANSE-style continuation (disco_tango_enhance_iterated): re-compress with the local part of the new filter
-            w_loc = eng.filter_head(w_glo)
+            w_loc = eng.filter_head(w_glo, out=wb_loc)
+    # the final filter + iSTFT (tango.py:445 + 528): in one pass over X and the gathered z where the kernel is built for the shape
+    # (disco_apply_istft_fused: the filtered spectra go out only when the caller handed an array for them), else the two calls
+    if eng.K > 1:
+        yfb = yf_out if want_yf else None
+        if want_yf and yfb is None:
+            yfb = eng.empty((R, Kl, eng.T, eng.F), np.complex64)
+        res = eng.apply_istft(X, w_glo, z_all, out=out, yf_out=yfb)
+        if res is not None:
+            return res.reshape(R, Kl, eng.Lsamp), yfb, z_all
     yf = eng.apply(X, w_glo, Z=z_all if eng.K > 1 else None, out=yf_out)
     out = eng.istft(yf.reshape(R * Kl, eng.T, eng.F), out=out).reshape(R, Kl, eng.Lsamp)
     return out, yf, z_all
@@ -105,7 +118,8 @@ def _half_engines(eng, n_halves):
     return cache[1]
 
 
-def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, group=None, iters=1, out=None, gather_events=None, overlap=None):
+def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, group=None, iters=1, out=None, gather_events=None, overlap=None,
+                                     want_yf=True):
     """Device-resident variant: y_local (R, Kl, M, L) float32 and the masks (R, Kl, T, F) float32 are contiguous torch tensors
     on this rank's GPU; z stays on the GPUs and is all-gathered by torch.distributed over `group` (RCCL over xGMI; every
     rank holds the same number of nodes, rank order == node order).  The library launches on the null stream, which is
@@ -120,6 +134,7 @@ def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, g
 
     out: optional (R, Kl, L) float32 torch tensor to receive the time signals.  gather_events: optional list that receives a
     (start, stop) pair of torch.cuda events per all-gather (recorded on the current stream; the caller synchronises and reads).
+    want_yf=False: the filtered spectra are not materialised where the final filter + iSTFT run as one pass (yf_local is then None).
     Returns (out_local (R, Kl, L) DevBuf or `out`, yf_local torch (R, Kl, T, F) complex64, z_all torch (R, K, T, F) complex64)."""
     import torch
     import torch.distributed as dist
@@ -165,19 +180,24 @@ def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, g
     # hipMalloc + hipFree of several GB per call (measured: 100 ms of a 113 ms step at 250 rooms)
     def buffers(rooms):
         shape = (rooms, Kl, eng.T, eng.F)
-        return dict(z=torch.empty(shape, dtype=torch.complex64, device=dev), yf=torch.empty(shape, dtype=torch.complex64, device=dev),
+        return dict(z=torch.empty(shape, dtype=torch.complex64, device=dev),
+                    yf=torch.empty(shape, dtype=torch.complex64, device=dev) if (want_yf or not fused_final) else None,
                     parts=torch.empty((W,) + shape, dtype=torch.complex64, device=dev),
+                    w=(torch.empty((rooms, Kl, eng.F, eng.M), dtype=torch.complex64, device=dev),
+                       torch.empty((rooms, Kl, eng.F, eng.M + K - 1), dtype=torch.complex64, device=dev)),
                     X=torch.empty((rooms * Kl, eng.T, eng.F, eng.M), dtype=torch.complex64, device=dev))
 
     if out is None:
         out = torch.empty((R, Kl, eng.Lsamp), dtype=torch.float32, device=dev)
+    # is the one-pass final filter + iSTFT built for this shape?  (include/disco_hip.h: disco_apply_istft_fused) -- else the two calls need yf
+    fused_final = K > 1 and eng.n_fft in (512, 1024) and (eng.M, K) in ((8, 8), (8, 6), (8, 4), (8, 2), (4, 8), (4, 6), (4, 4), (4, 3), (4, 2))
     if not overlap:
         b = buffers(R)
         begin, end = make_gather(R, b['parts'])
         eng.set_z_blocks(Kl)
         try:
             _, yf_, zrm = _drive([_steps(eng, y_local, mask_z_local, mask_w_local, iters, b['z'], begin, end, yf_out=b['yf'], out=out,
-                                         z_shape=(W, R, Kl, eng.T, eng.F), X_out=b['X'])])[0]
+                                         z_shape=(W, R, Kl, eng.T, eng.F), X_out=b['X'], want_yf=want_yf, w_bufs=b['w'])])[0]
         finally:
             eng.set_z_blocks(K)
         return out, yf_, zrm.permute(1, 0, 2, 3, 4).reshape(R, K, eng.T, eng.F)
@@ -191,13 +211,13 @@ def tango_enhance_node_sharded_torch(eng, y_local, mask_z_local, mask_w_local, g
         begin, end = make_gather(r1 - r0, b['parts'])
         kid.set_z_blocks(Kl)
         gens.append(_steps(kid, y_local[r0:r1], mask_z_local[r0:r1], mask_w_local[r0:r1], iters, b['z'], begin, end, yf_out=b['yf'],
-                           out=out[r0:r1], z_shape=(W, r1 - r0, Kl, eng.T, eng.F), X_out=b['X']))
+                           out=out[r0:r1], z_shape=(W, r1 - r0, Kl, eng.T, eng.F), X_out=b['X'], want_yf=want_yf, w_bufs=b['w']))
     try:
         res = _drive(gens)
     finally:
         for kid in kids:
             kid.set_z_blocks(K)
-    yf_ = torch.cat([bufs[0]['yf'], bufs[1]['yf']], dim=0)
+    yf_ = torch.cat([bufs[0]['yf'], bufs[1]['yf']], dim=0) if all(r_[1] is not None for r_ in res) else None
     z_all = torch.cat([r_[2].permute(1, 0, 2, 3, 4).reshape(-1, K, eng.T, eng.F) for r_ in res], dim=0)
     # the documented return value keeps global node order (R, K, T, F): a view-free copy made only for the caller's benefit
     return out, yf_, z_all

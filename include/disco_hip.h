@@ -283,6 +283,15 @@ int disco_step2_apply_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32*
 int disco_step2_apply_istft_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* w_loc, const disco_c32* w_glo,
                                   float* out, disco_stream s);
 
+/* disco_apply(X, Z, w, P = M + K - 1, conj_w = 1) followed by disco_istft, in one pass with z taken from HBM (tango.py:445 + 528): what a
+ * NODE SHARD ends its step 2 with -- its z rows come out of the all-gather, in the layout disco_set_z_blocks names -- and what the whole-path
+ * calls of the wide shapes end in (stage "apply2_istft", csrc/k_fused.h k_apply_istft_wide).
+ *   X [R][Kl][T][F][M], Z: the z of ALL nodes, w [R][Kl][F][P] -> out float [R][Kl][L]; yf [R][Kl][T][F] or NULL.
+ * Built for 512 / 1024-point frames and (mics, nodes) in {8, 4} x {8, 6} + (8, 4), (8, 2), (4, 4), (4, 3), (4, 2); DISCO_E_UNSUPPORTED
+ * otherwise (use the two calls). */
+int disco_apply_istft_fused(disco_ctx* ctx, const disco_c32* X, const disco_c32* Z, const disco_c32* w, disco_c32* yf,
+                            float* out, disco_stream s);
+
 /* ---- whole path -------------------------------------------------------------------------------------- */
 
 /* offline_tango(y, ..., mask_for_z='local') restricted to the y branch ("enhanced" outputs), device resident:

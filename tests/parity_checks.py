@@ -579,6 +579,48 @@ def check_node_sharded(make_engine, R=1, K=4, M=2, L=6000, world=2):
     return worst
 
 
+def check_apply_istft_sharded(make_engine, K=4, M=4, L=6000, n_fft=512, R=2, world=2, seed=8):
+    """disco_apply_istft_fused on a NODE SHARD (k_apply_istft_wide with the shard's Kl nodes and the gathered z in rank-major blocks, the
+    layout an all-gather delivers) against disco_apply + disco_istft on the same shard: the filtered spectra bit for bit, the samples to
+    rounding (one inverse transform per frame pair instead of the staged kernel's own pairing); with and without the spectra going out;
+    world = 1: the unsharded context (plain z layout).  Shapes: the narrow 4-mic ones a shard needs and a wide one."""
+    from disco_amd.node_sharded import node_range
+    rng = np.random.default_rng(seed)
+    P = M + K - 1
+    worst = 0.0
+    for q in range(world):
+        k0, kl = node_range(q, world, K)
+        e = make_engine(rooms=R, nodes=K, mics=M, length=L, n_fft=n_fft)
+        if world > 1:
+            e.set_node_shard(k0, kl)
+        T, F = e.T, e.F
+        y = rng.standard_normal((R, kl, M, L)).astype(np.float32)
+        X = e.stft(y.reshape(R * kl, M, L)).numpy().reshape(R, kl, T, F, M)
+        w = (rng.standard_normal((R, kl, F, P)) + 1j * rng.standard_normal((R, kl, F, P))).astype(np.complex64)
+        z_plain = (rng.standard_normal((R, K, T, F)) + 1j * rng.standard_normal((R, K, T, F))).astype(np.complex64)
+        if world > 1:           # rank-major [W][R][Kl][T][F], consumed as it arrives
+            z_arg = np.ascontiguousarray(z_plain.reshape(R, world, kl, T, F).transpose(1, 0, 2, 3, 4))
+            e.set_z_blocks(kl)
+        else:
+            z_arg = z_plain
+        yf_ref = e.apply(X, w, Z=z_arg)
+        out_ref = e.istft(yf_ref.reshape(R * kl, T, F)).numpy().reshape(R, kl, L)
+        yf_ref = yf_ref.numpy()
+        yf_buf = e.empty((R, kl, T, F), np.complex64)
+        out1 = e.apply_istft(X, w, z_arg, yf_out=yf_buf)
+        assert out1 is not None, 'disco_apply_istft_fused is not built for this shape'
+        out1 = out1.numpy().reshape(R, kl, L)
+        assert np.array_equal(yf_buf.numpy(), yf_ref)
+        out2 = e.apply_istft(X, w, z_arg).numpy().reshape(R, kl, L)
+        assert np.array_equal(out1, out2)
+        err = relerr(out1, out_ref)
+        assert err < 3e-6, err
+        worst = max(worst, err)
+        if world > 1:
+            e.set_z_blocks(K)
+    return worst
+
+
 def check_solver_vs_reference_golden(make_engine, golden_dir):
     """HIP solver against intern_filter outputs of the REFERENCE'S OWN CODE (tests/golden/intern_filter_ref.npz)."""
     import os

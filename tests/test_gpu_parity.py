@@ -140,9 +140,19 @@ def test_online_mwf(make_engine, R, K, M, L, n_fft, U):
     pc.check_online_mwf(make_engine, R=R, K=K, M=M, L=L, n_fft=n_fft, update_every=U)
 
 
-@pytest.mark.parametrize('K,M,world', [(4, 4, 2), (4, 2, 4), (6, 2, 3)])
+@pytest.mark.parametrize('K,M,world', [(4, 4, 2), (4, 2, 4), (6, 2, 3), (4, 4, 4), (2, 4, 2), (3, 4, 3)])
 def test_node_sharded_equals_single_gpu(make_engine, K, M, world):
+    """(the 4-mic shapes end in ONE filter + iSTFT pass on the gathered z: disco_apply_istft_fused)"""
     pc.check_node_sharded(make_engine, R=2, K=K, M=M, L=30000, world=world)
+
+
+@pytest.mark.parametrize('K,M,n_fft,L,world,R', [(4, 4, 512, 42000, 2, 3), (4, 4, 512, 160000, 4, 2), (2, 4, 512, 20000, 2, 5), (3, 4, 1024, 30000, 3, 2),
+                                                  (4, 4, 512, 9000, 1, 2), (4, 8, 512, 20000, 2, 2), (8, 8, 1024, 30000, 4, 1), (4, 4, 1024, 600, 2, 1)])
+def test_apply_istft_sharded(make_engine, K, M, n_fft, L, world, R):
+    """disco_apply_istft_fused on node shards (k_apply_istft_wide with the shard's nodes and the gathered z in rank-major blocks) against
+    disco_apply + disco_istft: the filtered spectra bit for bit, the samples to rounding; full-length clips, several chunks per node, a clip
+    shorter than a frame, the unsharded context."""
+    print(pc.check_apply_istft_sharded(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=R, world=world))
 
 
 def test_solver_vs_reference_golden(make_engine, golden_dir):

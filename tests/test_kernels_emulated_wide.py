@@ -98,6 +98,19 @@ def test_emu_edge_lengths(make_engine, n_fft):
             make_engine(rooms=1, nodes=1, mics=1, length=L, n_fft=n_fft, pad_mode='reflect')
 
 
+@pytest.mark.parametrize('K,M,n_fft,L,world,R', [(4, 4, 512, 3000, 2, 2), (4, 4, 512, 2000, 4, 1), (2, 4, 512, 3000, 2, 3), (3, 4, 1024, 5000, 3, 1),
+                                                  (4, 4, 512, 1500, 1, 1), (4, 8, 512, 3000, 2, 1)])
+def test_emu_apply_istft_sharded(make_engine, K, M, n_fft, L, world, R):
+    """disco_apply_istft_fused on node shards (rank-major z blocks) == disco_apply + disco_istft."""
+    print(pc.check_apply_istft_sharded(make_engine, K=K, M=M, L=L, n_fft=n_fft, R=R, world=world))
+
+
+@pytest.mark.parametrize('K,M,world', [(4, 4, 2), (2, 4, 2)])
+def test_emu_node_sharded_one_pass_final(make_engine, K, M, world):
+    """The node-sharded driver on shapes whose final filter + iSTFT run as one pass on the gathered z: == the single-GPU path and the oracle."""
+    print(pc.check_node_sharded(make_engine, R=1, K=K, M=M, L=4000, world=world))
+
+
 def test_emu_node_sharded_torch_one_rank(make_engine):
     """Same check as the GPU suite's (one-rank group), here with CPU tensors over gloo on the emulated build."""
     print(pc.check_node_sharded_torch_one_rank(make_engine, 'cpu', 'gloo', K=3, M=2, L=4096, iters=2))
