@@ -1,10 +1,13 @@
 #!/bin/bash
 # FINAL-state pass of a round on the committed sources (round 4: r4_final.sh): GPU suite, the plain bench line, kernel stats + HBM counters (+ calibration) of
 # C3 / C5 / C2 / C2x4000, SQ / LDS counters of C3 / C5, side lines (overlap off, node-sharded, online every 8).   Usage: final_pass.sh <tag>
+# PART=a: the suite and the plain line only; PART=b: the profile / counter passes and the side lines only (two calls when the GPU budget is short)
 TAG=${1:-r05_zz}
+PART=${PART:-ab}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 mkdir -p gpurun_out
 T0=$(date +%s)
+if [[ $PART == *a* ]]; then
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc $? ($(( $(date +%s) - T0 )) s)"; grep -E "passed|failed" gpurun_out/${TAG}_tests.log | tail -2; grep -E "^FAILED|^E  " gpurun_out/${TAG}_tests.log | head -10
 T1=$(date +%s)
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc $? ($(( $(date +%s) - T1 )) s)"; tail -3 gpurun_out/${TAG}_bench_default.err
@@ -20,12 +23,16 @@ for k, v in d.get('configs', {}).items():
     print(k, round(v['ms_per_step'], 3), 'ms', 'xRT', round(v['x_realtime'], 1), rf.get('kernel', '')[:40], rf.get('frac'), 'pipe', (rf.get('pipeline') or {}).get('frac'), 'parity', (v.get('parity_sample') or {}).get('worst_rel_all_ranks'), 'ok', (v.get('parity_sample') or {}).get('ok'), rf.get('sanity_errors'))
     print('   ', {s: x['ms'] for s, x in (v.get('stages') or {}).items()})
 PY
+fi
+if [[ $PART == *b* ]]; then
 bash tools/profile_round.sh ${TAG}_C3 2>&1 | tail -9
 bash tools/profile_round.sh ${TAG}_C5 --config C5 2>&1 | tail -12
 bash tools/profile_round.sh ${TAG}_C2 --config C2 2>&1 | tail -6
 bash tools/profile_round.sh ${TAG}_C2x4000 --config C2 --rooms 4000 2>&1 | tail -6
+if [[ -z "$SKIP_ALU" ]]; then
 BARGS="" bash tools/gpu/pmc_alu.sh ${TAG}_C3 2>&1 | grep -E "rc|disco::" | cut -c1-400
 BARGS="--config C5" bash tools/gpu/pmc_alu.sh ${TAG}_C5 2>&1 | grep -E "rc|disco::" | cut -c1-400
+fi
 BARGS="--rooms 1000 --online-every 1" bash tools/gpu/pmc_alu.sh ${TAG}_online1 2>&1 | grep -E "rc|disco::" | cut -c1-400
 python - <<PY
 # the online mode's VALU-issue roofline reads this copy (bench.py: profiles/pmc_alu_online1.json), stamped with the digest of the kernel sources
@@ -48,4 +55,5 @@ for n in ('C3_overlap0', 'nodeshard', 'online8'):
     except Exception as e:
         print(n, 'failed', e)
 PY
+fi
 echo "total $(( $(date +%s) - T0 )) s"
