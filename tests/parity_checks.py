@@ -813,6 +813,39 @@ def check_node_sharded_torch_one_rank(make_engine, device, backend, K=3, M=2, L=
     return errs
 
 
+def check_node_sharded_torch_want_yf(make_engine, device, backend, K=2, M=4, L=4096, iters=1):
+    """tango_enhance_node_sharded_torch(want_yf=False) on a shape whose final filter + iSTFT run as one pass on the gathered z: the filtered
+    spectra are not materialised (None comes back), the samples are those of the default call bit for bit; plain and with two half-batches."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from disco_amd import synth
+    from disco_amd.node_sharded import tango_enhance_node_sharded_torch
+    R = 3
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    eng = make_engine(rooms=R, nodes=K, mics=M, length=L)
+    mask = eng.mask_oracle(s[:, :, 0].reshape(R * K, L), n[:, :, 0].reshape(R * K, L)).reshape(R, K, eng.T, eng.F).numpy()
+    eng.set_node_shard(0, K)
+    own_group = not dist.is_initialized()
+    if own_group:
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group(backend, init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        yt, mt = torch.from_numpy(y).to(device), torch.from_numpy(mask).to(device)
+        for overlap in (False, True):
+            out_a, yf_a, _ = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=iters, overlap=overlap)
+            out_b, yf_b, _ = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=iters, overlap=overlap, want_yf=False)
+            assert yf_a is not None and yf_b is None
+            assert torch.equal(out_a.cpu(), out_b.cpu())
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    return True
+
+
 def check_solver_sizes(make_engine, sizes=range(1, 17), n=300, tol=2e-6):
     """P = 1..16 (C5 needs 15): HIP float64 solver vs the numpy eigh closed form on rank-1-plus-noise pencils."""
     rng = np.random.default_rng(11)

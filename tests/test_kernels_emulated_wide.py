@@ -98,6 +98,12 @@ def test_emu_edge_lengths(make_engine, n_fft):
             make_engine(rooms=1, nodes=1, mics=1, length=L, n_fft=n_fft, pad_mode='reflect')
 
 
+@pytest.mark.parametrize('iters', [1, 2])
+def test_emu_node_sharded_torch_without_yf(make_engine, iters):
+    """want_yf=False: no filtered spectra where the final filter + iSTFT run as one pass, the same samples bit for bit."""
+    assert pc.check_node_sharded_torch_want_yf(make_engine, 'cpu', 'gloo', K=2, M=4, L=4096, iters=iters)
+
+
 @pytest.mark.parametrize('K,M,n_fft,L,world,R', [(4, 4, 512, 3000, 2, 2), (4, 4, 512, 2000, 4, 1), (2, 4, 512, 3000, 2, 3), (3, 4, 1024, 5000, 3, 1),
                                                   (4, 4, 512, 1500, 1, 1), (4, 8, 512, 3000, 2, 1)])
 def test_emu_apply_istft_sharded(make_engine, K, M, n_fft, L, world, R):
