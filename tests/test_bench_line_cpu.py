@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on CPU against the line the final GPU pass committed (profiles/r05_zz_bench_default.json): the keys the
+"""The bench line's contract, checked on CPU against the line the final GPU pass committed (profiles/r05_zzz_bench_default.json): the keys the
 driver reads, the two objects the tier asks for (`roofline`, `cpu_baseline`), and the compact `summary` -- the LAST key, small enough that a
 record keeping only the tail of the line still has every workload's numbers -- rebuilt here by bench.summary_rows from the line's own fields."""
 import json
@@ -7,7 +7,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-LINE = os.path.join(REPO, 'profiles', 'r05_zz_bench_default.json')
+LINE = os.path.join(REPO, 'profiles', 'r05_zzz_bench_default.json')
 
 
 def _line():
