@@ -98,6 +98,23 @@ def test_emu_edge_lengths(make_engine, n_fft):
             make_engine(rooms=1, nodes=1, mics=1, length=L, n_fft=n_fft, pad_mode='reflect')
 
 
+def test_emu_apply_istft_fused_errors(make_engine):
+    """disco_apply_istft_fused: a shape the one-pass kernel is not built for answers DISCO_E_UNSUPPORTED (Engine.apply_istft: None -- the
+    caller runs the two calls), a missing argument DISCO_E_ARG with a message; nothing is launched either way."""
+    import numpy as np
+    from disco_amd.engine import DiscoError
+    e = make_engine(rooms=1, nodes=3, mics=2, length=2000)                        # (2, 3): not in the table
+    X = e.empty((1, 3, e.T, e.F, 2), np.complex64)
+    Z = e.empty((1, 3, e.T, e.F), np.complex64)
+    w = e.empty((1, 3, e.F, 4), np.complex64)
+    assert e.apply_istft(X, w, Z) is None
+    assert e.lib.disco_apply_istft_fused(e.ctx, X.ptr, Z.ptr, w.ptr, None, None, None) == -1       # no output array
+    assert b'null argument' in e.lib.disco_last_error(e.ctx)
+    e4 = make_engine(rooms=1, nodes=2, mics=4, length=2000)
+    with pytest.raises(DiscoError, match='null argument'):
+        e4._chk(e4.lib.disco_apply_istft_fused(e4.ctx, None, None, None, None, None, None))
+
+
 @pytest.mark.parametrize('iters', [1, 2])
 def test_emu_node_sharded_torch_without_yf(make_engine, iters):
     """want_yf=False: no filtered spectra where the final filter + iSTFT run as one pass, the same samples bit for bit."""
