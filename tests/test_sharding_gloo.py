@@ -195,6 +195,74 @@ def test_node_sharded_device_resident_iterated_two_ranks():
         assert e1 < 1e-5 and e2 < 1e-4, (rank, e1, e2)
 
 
+def _node_worker_one_pass(rank, world, port, q):
+    """A shape whose final filter + iSTFT run as ONE pass on the gathered z (disco_apply_istft_fused: 4 nodes x 4 mics, two nodes per rank):
+    the kernel reads the z of all nodes in the rank-major blocks the all-gather delivers; two half-batches with asynchronous gathers (the
+    default for more than one rank), caller-owned filter arrays; with and without the filtered spectra."""
+    import numpy as np
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dd.init('gloo', rank, world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_build
+    from disco_amd import synth
+    from disco_amd.engine import Engine
+    from disco_amd.node_sharded import node_range, tango_enhance_node_sharded_torch
+    from oracle import stft_oracle as so
+    from oracle import tango_oracle as to
+    R, K, M, L = 3, 4, 4, 2560
+    y, s, n = synth.make_rooms_numpy(R, K=K, M=M, L=L)
+    k0, kl = node_range(rank, world, K)
+    eng = Engine(rooms=R, nodes=K, mics=M, length=L, lib=emu_build.load_emu())
+    eng.set_node_shard(k0, kl)
+    res = {}
+    for iters in (1, 2):
+        os_ = [to.offline_tango_vec(y[r], s[r], n[r], vads=['irm1', 'irm1'], precision='f64', solver='eigh', extra_iters=iters - 1)
+               for r in range(R)]
+        mask = np.stack([np.stack([o['masks_z'][k].T for k in range(k0, k0 + kl)]) for o in os_]).astype(np.float32)
+        yt = torch.from_numpy(np.ascontiguousarray(y[:, k0:k0 + kl]))
+        mt = torch.from_numpy(mask)
+        out, yf, z_all = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=iters)
+        eng.stage_timing(True)                              # (the overlapped form runs on child engines: the stages are read off the plain form)
+        out_p, _, _ = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=iters, overlap=False)
+        rep = eng.stage_report()
+        eng.stage_timing(False)
+        assert 'apply2_istft' in rep and 'istft' not in rep, sorted(rep)
+        assert float((torch.as_tensor(out_p) - torch.as_tensor(out)).abs().max()) < 1e-5
+        out_b, yf_b, _ = tango_enhance_node_sharded_torch(eng, yt, mt, mt, iters=iters, want_yf=False)
+        assert yf is not None and yf_b is None and torch.equal(torch.as_tensor(out), torch.as_tensor(out_b))
+        outn = out.numpy() if hasattr(out, 'numpy') else np.asarray(out)
+        err = 0.0
+        for r in range(R):
+            for i in range(kl):
+                ref = so.istft(os_[r]['yf'][k0 + i], L, work_dtype=np.float64)
+                err = max(err, float(np.linalg.norm(outn[r, i] - ref) / np.linalg.norm(ref)))
+                e_yf = float(np.linalg.norm(yf.numpy()[r, i].T - os_[r]['yf'][k0 + i]) / np.linalg.norm(os_[r]['yf'][k0 + i]))
+                err = max(err, e_yf)
+        res[iters] = err
+    q.put((rank, res[1], res[2]))
+    dist.destroy_process_group()
+
+
+def test_node_sharded_one_pass_final_two_ranks():
+    """Two gloo ranks with two of a room's four 4-mic nodes each: step 2 ends in the one-pass filter + iSTFT on the gathered z; samples and
+    filtered spectra against the float64 oracle, 1 and 2 step-2 iterations."""
+    _prebuild_emu()
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_node_worker_one_pass, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, world)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, e1, e2 in res:
+        assert e1 < 2e-5 and e2 < 1e-4, (rank, e1, e2)
+
+
 def test_bench_self_launches_ranks():
     """`python bench.py --gpus 2` started plainly (no torchrun, no WORLD_SIZE) must become TWO ranks: the launcher of
     disco_amd/dist.py:launch_ranks, exercised on CPU with gloo (`--selftest-launch` skips the GPU work, nothing else)."""
